@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the cvsteer hot path on MI355X.
+
+Metric (BASELINE.json): Mpix/s for the G2+H2 7-basis filter + scalar steer at 4096x4096 f32,
+and the fraction of the HBM roofline the dominant kernel reaches.
+
+A "step" = one pass of the hot path over one 4096x4096 synthetic image that is already
+resident in HBM: SteerableFiltersG2::setup's 7 separable filters (reference
+SteerableFiltersG2.cpp:62-68) + steer(theta=0.3) (G2.cpp:137-145), as ONE fused kernel launch
+(cvs_setup_steer).  Basis planes are persisted (7 planes) and g2/h2 written: 4 B read + 36 B
+written = 40 algorithmic bytes per pixel (SURVEY.md 8(d) "M2").
+
+Multi-GPU: the image/batch axis shards with no data-path collective -- every rank filters its
+own images (weak scaling); RCCL is used for the barrier and the max-over-ranks reduction only.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+ROWS = COLS = 4096
+THETA = 0.3
+BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56}
+
+
+def _dist_env():
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    return ws, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _time_steps(torch, fn, steps, warmup, barrier):
+    """W untimed warm-ups, then exactly K steps between barrier + synchronize; returns
+    (wall seconds, HIP-event milliseconds on the launch stream)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, ev0.elapsed_time(ev1)
+
+
+def _cpu_baseline(theta):
+    """The CPU restatement of the reference call sequence (oracle/, kind 'port'), one thread,
+    on a bounded sample of the same workload: full 4096x4096 images, ~10-20 s of CPU work."""
+    import numpy as np
+    import oracle  # test infrastructure used as the timed CPU baseline leg only
+    img = np.random.default_rng(1234).random((ROWS, COLS), dtype=np.float32)
+    oracle.time_g2_filter_steer(img[:256], theta, 1)  # warm caches / page in
+    reps, total = 0, 0.0
+    while total < 10.0 and reps < 16:
+        total += oracle.time_g2_filter_steer(img, theta, 1)
+        reps += 1
+    return {
+        "value": round(reps * ROWS * COLS / total / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
+        "sample": "%d x (4096x4096 f32, 7 sepFilter2D + scalar steer), single thread, oracle/ C restatement "
+                  "(-O3 -march=native); OpenCV itself is not installed on this image" % reps,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (M1/M4/M5/G4)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--strip-rows", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import cvsteer_amd as cv
+
+    ws, rank, local_rank = _dist_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if ws > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    dev = torch.device("cuda", local_rank)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    img = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)  # i.i.d. uniform [0,1)
+    f = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+    if args.strip_rows:
+        f.set_strip_rows(args.strip_rows)
+    g = torch.empty_like(img)
+    h = torch.empty_like(img)
+    npix = ROWS * COLS
+
+    # ---- headline: filter + steer (M2), one fused launch per step ----
+    def step():
+        f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
+
+    wall, ev_ms = _time_steps(torch, step, args.steps, args.warmup, barrier)
+    if dist is not None:
+        t = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+    value = ws * args.steps * npix / wall / 1e6
+    k_ms = ev_ms / args.steps  # average launch-to-launch duration of the single kernel, HIP events
+    achieved = BYTES_PER_PIX["M2"] * npix / (k_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_basis_g2_steer_4096", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "Mpix/s for G2+H2 7-basis filter+steer at 4096x4096 f32; % HBM roofline",
+        "value": round(value, 1), "unit": "Mpix/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "G2+H2 7-basis separable pass + scalar steer (theta=0.3), one 4096x4096 f32 image "
+                               "per GPU per step, image resident in HBM, bases persisted (BASELINE configs[1])",
+                   "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "cvs::k_basis<BankG2, F_STEER>", "algorithmic_bytes_per_launch": BYTES_PER_PIX["M2"] * npix,
+                     "avg_launch_ms": round(k_ms, 5)},
+    }
+
+    # ---- secondary legs (reported, not the headline) ----
+    if not args.no_extra:
+        extra = {}
+        ksteps, kwarm = max(10, args.steps // 4), 5
+
+        def leg(name, fn, bpp, pix=npix):
+            w_, e_ = _time_steps(torch, fn, ksteps, kwarm, barrier)
+            ms = e_ / ksteps
+            extra[name] = {"Mpix/s": round(pix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5),
+                           "GB/s": round(bpp * pix / (ms * 1e-3) / 1e9, 1),
+                           "frac_hbm": round(bpp * pix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": bpp}
+
+        leg("M1_basis_only", lambda: f.setup(img, flags=cv.SETUP_BASIS), BYTES_PER_PIX["M1"])
+        leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"])
+        outs8 = [torch.empty_like(img) for _ in range(8)]
+        leg("M5_pipeline", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"])
+        f.setup(img, flags=cv.SETUP_FULL)
+        leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36)
+        leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), 64)
+        f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)
+        leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"])
+        leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"])
+        out["extra"] = extra
+
+    if rank == 0 and ws == 1 and not args.no_cpu:
+        out["cpu_baseline"] = _cpu_baseline(THETA)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""ctypes binding of libcvsteer_hip.so (the C ABI declared in include/cvsteer_hip.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcvsteer_hip.so")
+
+OK, E_BADARG, E_SIZE, E_HIP, E_NOMEM, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+KIND_G2, KIND_G4 = 2, 4
+MEM_HOST, MEM_DEVICE = 0, 1
+OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON = 1, 2, 3
+PLANE_BASIS0, PLANE_C1, PLANE_C2, PLANE_C3, PLANE_THETA, PLANE_STRENGTH = 0, 32, 33, 34, 35, 36
+
+
+class Plane(C.Structure):
+    """struct cvs_plane"""
+    _fields_ = [("data", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("step", C.c_size_t), ("mem", C.c_int32)]
+
+
+class CvsError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = "%s failed: %s (%d)" % (where, lib().cvs_status_string(status).decode(), status)
+        if detail:
+            msg += ": " + detail
+        super().__init__(msg)
+
+
+_PP = C.POINTER(Plane)
+_FP = C.POINTER(C.c_float)
+_IP = C.POINTER(C.c_int)
+
+# every symbol include/cvsteer_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "cvs_abi_version": (C.c_int, []),
+    "cvs_status_string": (C.c_char_p, [C.c_int]),
+    "cvs_num_basis": (C.c_int, [C.c_int]),
+    "cvs_make_taps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _FP]),
+    "cvs_basis_taps": (C.c_int, [C.c_int, C.c_int, _IP, _IP]),
+    "cvs_steer_weights": (C.c_int, [C.c_int, C.c_float, _FP]),
+    "cvs_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_void_p)]),
+    "cvs_destroy": (C.c_int, [C.c_void_p]),
+    "cvs_last_error": (C.c_char_p, [C.c_void_p]),
+    "cvs_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cvs_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cvs_get_option": (C.c_int, [C.c_void_p, C.c_int, _IP]),
+    "cvs_taps": (C.c_int, [C.c_void_p, C.c_int, _FP]),
+    "cvs_kind": (C.c_int, [C.c_void_p, _IP, _IP, _FP]),
+    "cvs_shape": (C.c_int, [C.c_void_p, _IP, _IP]),
+    "cvs_sync": (C.c_int, [C.c_void_p]),
+    "cvs_setup": (C.c_int, [C.c_void_p, _PP, C.c_uint]),
+    "cvs_setup_steer": (C.c_int, [C.c_void_p, _PP, C.c_uint, C.c_float, _PP, _PP]),
+    "cvs_state_plane": (C.c_int, [C.c_void_p, C.c_int, _PP]),
+    "cvs_read_state": (C.c_int, [C.c_void_p, C.c_int, _PP]),
+    "cvs_steer_scalar": (C.c_int, [C.c_void_p, C.c_float, _PP, _PP, _PP, _PP, _PP]),
+    "cvs_steer_map": (C.c_int, [C.c_void_p, _PP, _PP, _PP, _PP, _PP, _PP]),
+    "cvs_steer_point": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, _FP]),
+    "cvs_mag_phase": (C.c_int, [C.c_void_p, _PP, _PP, _PP, _PP]),
+    "cvs_phase_weights": (C.c_int, [C.c_void_p, _PP, _PP, C.c_float, C.c_int, C.c_float]),
+    "cvs_find": (C.c_int, [C.c_void_p, _PP, _PP, _PP, _PP, _PP]),
+    "cvs_pipeline": (C.c_int, [C.c_void_p, _PP, C.POINTER(_PP)]),
+    "cvs_normalize_u8": (C.c_int, [C.c_void_p, _PP, C.c_void_p, C.c_size_t, C.c_int]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _SO
+
+
+def lib():
+    """Load libcvsteer_hip.so.  Fails loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError(
+                "cvsteer_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C cvsteer_amd/csrc`.  There is no CPU fallback." % _SO)
+        L = C.CDLL(_SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if L.cvs_abi_version() != 1:
+            raise ImportError("cvsteer_amd: ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def abi_version():
+    return lib().cvs_abi_version()

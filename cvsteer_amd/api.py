@@ -1,0 +1,326 @@
+"""Host-side mirror of the reference's class surface (namespace fa) over the C ABI.
+
+Reference: cvsteer/SteerableFilters.h:41-50, SteerableFiltersG2.h:35-67,
+SteerableFiltersG4.h:35-57.  Method names and argument meaning follow the reference; where the
+reference fills ``cv::Mat1f&`` out-parameters, these methods return the planes.
+
+Planes may be
+  * numpy float32 arrays (host memory; results come back as numpy arrays), or
+  * torch CUDA float32 tensors (device memory; zero-copy in, results are torch tensors on the
+    same device, work is enqueued on torch's current stream).
+All arithmetic happens in libcvsteer_hip.so on the GPU; this module only marshals pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import CvsError, Plane, lib
+
+SETUP_BASIS, SETUP_ORIENT, SETUP_FULL = 1, 2, 3
+
+try:  # torch is plumbing (device memory + streams), optional for host-plane use
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+def num_basis(kind):
+    return lib().cvs_num_basis(kind)
+
+
+def make_taps(kind, idx, width, spacing):
+    """SteerableFilters::create on the idx-th tap function (host math, no GPU needed)."""
+    out = np.empty(2 * width + 1, np.float32)
+    rc = lib().cvs_make_taps(kind, idx, width, spacing, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc:
+        raise CvsError(rc, "cvs_make_taps")
+    return out
+
+
+def basis_taps(kind, p):
+    a, b = C.c_int(), C.c_int()
+    rc = lib().cvs_basis_taps(kind, p, C.byref(a), C.byref(b))
+    if rc:
+        raise CvsError(rc, "cvs_basis_taps")
+    return a.value, b.value
+
+
+def steer_weights(kind, theta):
+    out = np.empty(num_basis(kind), np.float32)
+    rc = lib().cvs_steer_weights(kind, theta, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc:
+        raise CvsError(rc, "cvs_steer_weights")
+    return out
+
+
+def _plane(a):
+    """cvs_plane view of a 2-D float32 numpy array or torch CUDA tensor (no copy)."""
+    if _is_torch(a):
+        if a.dtype != torch.float32 or a.dim() != 2 or (a.shape[1] > 1 and a.stride(1) != 1):
+            raise ValueError("torch plane must be 2-D float32 with unit column stride")
+        mem = L.MEM_DEVICE if a.is_cuda else L.MEM_HOST
+        return Plane(a.data_ptr(), a.shape[0], a.shape[1], a.stride(0) * 4 if a.shape[0] > 1 else a.shape[1] * 4, mem)
+    if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.ndim != 2 or (a.shape[1] > 1 and a.strides[1] != 4):
+        raise ValueError("numpy plane must be 2-D float32 with unit column stride")
+    step = a.strides[0] if a.shape[0] > 1 else a.shape[1] * 4
+    return Plane(a.ctypes.data, a.shape[0], a.shape[1], step, L.MEM_HOST)
+
+
+def _as_input(a):
+    """the reference converts any Mat to Mat1f unscaled (Mat1f(const Mat&)); do the same on the host side"""
+    if _is_torch(a):
+        return a if a.dtype == torch.float32 else a.to(torch.float32)
+    a = np.asarray(a)
+    return a if a.dtype == np.float32 else a.astype(np.float32)
+
+
+class SteerableFilters:
+    """fa::SteerableFilters (SteerableFilters.h:41-50): setup(image), steer(theta) -> (g, h)."""
+
+    KIND = None
+    DEFAULT_WIDTH = None
+    DEFAULT_SPACING = None
+
+    def __init__(self, image=None, width=None, spacing=None, device=None, setup_flags=None):
+        width = self.DEFAULT_WIDTH if width is None else width
+        spacing = self.DEFAULT_SPACING if spacing is None else spacing
+        if device is None:
+            device = image.device.index if (_is_torch(image) and image.is_cuda and image.device.index is not None) else 0
+        self._h = C.c_void_p()
+        rc = lib().cvs_create(self.KIND, int(width), float(spacing), int(device), C.byref(self._h))
+        if rc:
+            self._h = None
+            raise CvsError(rc, "cvs_create", "no usable HIP device -- there is no CPU fallback" if rc == L.E_HIP else "")
+        self.device = int(device)
+        self.width, self.spacing = int(width), float(spacing)
+        self._like = None
+        self._setup_flags = setup_flags
+        if image is not None:
+            self.setup(image)
+
+    # -- plumbing --
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().cvs_destroy(h)
+            except Exception:
+                pass
+
+    def _check(self, rc, where):
+        if rc:
+            raise CvsError(rc, where, lib().cvs_last_error(self._h).decode())
+
+    def _bind_stream(self, *planes):
+        if torch is not None and any(_is_torch(p) and p.is_cuda for p in planes):
+            lib().cvs_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+
+    def _new(self, shape=None):
+        shape = self.shape if shape is None else shape
+        if _is_torch(self._like) and self._like.is_cuda:
+            return torch.empty(shape, dtype=torch.float32, device=self._like.device)
+        return np.empty(shape, np.float32)
+
+    def _new_like(self, a):
+        if _is_torch(a):
+            return torch.empty(tuple(a.shape), dtype=torch.float32, device=a.device)
+        return np.empty(a.shape, np.float32)
+
+    def set_option(self, option, value):
+        self._check(lib().cvs_set_option(self._h, option, int(value)), "cvs_set_option")
+
+    def set_atan_mode(self, exact):
+        self.set_option(L.OPT_ATAN_MODE, 1 if exact else 0)
+
+    def set_strip_rows(self, rows):
+        self.set_option(L.OPT_STRIP_ROWS, rows)
+
+    def sync(self):
+        self._check(lib().cvs_sync(self._h), "cvs_sync")
+
+    @property
+    def shape(self):
+        r, c = C.c_int(), C.c_int()
+        self._check(lib().cvs_shape(self._h, C.byref(r), C.byref(c)), "cvs_shape")
+        return (r.value, c.value)
+
+    def taps(self, idx):
+        out = np.empty(2 * self.width + 1, np.float32)
+        self._check(lib().cvs_taps(self._h, idx, out.ctypes.data_as(C.POINTER(C.c_float))), "cvs_taps")
+        return out
+
+    def _state(self, which):
+        out = self._new()
+        self._bind_stream(out)
+        p = _plane(out)
+        self._check(lib().cvs_read_state(self._h, which, C.byref(p)), "cvs_read_state")
+        return out
+
+    def basis(self, p):
+        """p-th separable basis plane (the reference's protected m_g2a.. / m_g4a.. members)."""
+        return self._state(L.PLANE_BASIS0 + p)
+
+    def basis_view(self, p):
+        """zero-copy (ptr, rows, cols, step_bytes) of a device-resident basis plane"""
+        v = Plane()
+        self._check(lib().cvs_state_plane(self._h, L.PLANE_BASIS0 + p, C.byref(v)), "cvs_state_plane")
+        return v.data, v.rows, v.cols, v.step
+
+    # -- reference surface --
+    def setup(self, image, flags=None):
+        """virtual setup(const Mat1f&)"""
+        image = _as_input(image)
+        if flags is None:
+            flags = self._setup_flags if self._setup_flags is not None else self._DEFAULT_FLAGS
+        self._like = image
+        self._bind_stream(image)
+        p = _plane(image)
+        self._image_keepalive = image
+        self._check(lib().cvs_setup(self._h, C.byref(p), flags), "cvs_setup")
+
+    def setup_steer(self, image, theta, flags=SETUP_BASIS, out=None):
+        """setup(image) + steer(float theta) in one kernel launch -> (g, h)"""
+        image = _as_input(image)
+        self._like = image
+        g, h = out if out is not None else (self._new_like(image), self._new_like(image))
+        self._bind_stream(image, g, h)
+        pi, pg, ph = _plane(image), _plane(g), _plane(h)
+        self._check(lib().cvs_setup_steer(self._h, C.byref(pi), flags, float(theta), C.byref(pg), C.byref(ph)),
+                    "cvs_setup_steer")
+        return g, h
+
+    def _steer(self, theta, full, out=None):
+        n = 5 if full else 2
+        outs = list(out) if out is not None else [self._new() for _ in range(n)]
+        planes = [_plane(o) for o in outs] + [None] * (5 - n)
+        ptrs = [C.byref(p) if p is not None else None for p in planes]
+        if isinstance(theta, (int, float, np.floating)):
+            self._bind_stream(*outs)
+            self._check(lib().cvs_steer_scalar(self._h, float(theta), *ptrs), "cvs_steer_scalar")
+        else:
+            if theta is not None:
+                theta = _as_input(theta)
+                self._bind_stream(theta, *outs)
+                pt = _plane(theta)
+                tptr = C.byref(pt)
+            else:
+                self._bind_stream(*outs)
+                tptr = None
+            self._check(lib().cvs_steer_map(self._h, tptr, *ptrs), "cvs_steer_map")
+        return tuple(outs)
+
+    def steer(self, theta, full=False, out=None):
+        """steer(float theta, g, h) / steer(const Mat1f& theta, g, h); theta=None steers at the
+        dominant orientation.  full=True adds (e, magnitude, phase) (G2 only)."""
+        return self._steer(theta, full, out)
+
+
+class SteerableFiltersG2(SteerableFilters):
+    """fa::SteerableFiltersG2 (SteerableFiltersG2.h:35-67)."""
+
+    KIND = L.KIND_G2
+    DEFAULT_WIDTH = 4
+    DEFAULT_SPACING = 0.67
+    _DEFAULT_FLAGS = SETUP_FULL
+
+    def getDominantOrientationAngle(self):
+        return self._state(L.PLANE_THETA)
+
+    def getDominantOrientationStrength(self):
+        return self._state(L.PLANE_STRENGTH)
+
+    def coefficients(self):
+        """(C1, C2, C3) -- the reference's protected m_c1..m_c3"""
+        return tuple(self._state(w) for w in (L.PLANE_C1, L.PLANE_C2, L.PLANE_C3))
+
+    def steer_point(self, p, theta, full=False):
+        """steer(const cv::Point& p, theta, ...): p = (x, y) = (col, row)"""
+        out = (C.c_float * 5)()
+        self._check(lib().cvs_steer_point(self._h, int(p[0]), int(p[1]), float(theta), out), "cvs_steer_point")
+        vals = tuple(float(v) for v in out)
+        return vals if full else vals[:2]
+
+    def computeMagnitudeAndPhase(self, g2, h2):
+        mag, phase = self._new_like(g2), self._new_like(g2)
+        self._bind_stream(g2, h2, mag, phase)
+        pg, ph, pm, pp = _plane(g2), _plane(h2), _plane(mag), _plane(phase)
+        self._check(lib().cvs_mag_phase(self._h, C.byref(pg), C.byref(ph), C.byref(pm), C.byref(pp)), "cvs_mag_phase")
+        return mag, phase
+
+    def phaseWeights(self, phase, phi, signum, k=2.0):
+        lam = self._new_like(phase)
+        self._bind_stream(phase, lam)
+        pp, pl = _plane(phase), _plane(lam)
+        self._check(lib().cvs_phase_weights(self._h, C.byref(pp), C.byref(pl), float(phi), int(bool(signum)), float(k)),
+                    "cvs_phase_weights")
+        return lam
+
+    def find(self, e, phase, which=(True, True, True)):
+        """findEdges + findDarkLines + findBrightLines in one pass -> (edges, dark, bright)"""
+        outs = [self._new_like(e) if w else None for w in which]
+        self._bind_stream(e, phase, *[o for o in outs if o is not None])
+        pe, pp = _plane(e), _plane(phase)
+        planes = [_plane(o) if o is not None else None for o in outs]
+        ptrs = [C.byref(p) if p is not None else None for p in planes]
+        self._check(lib().cvs_find(self._h, C.byref(pe), C.byref(pp), *ptrs), "cvs_find")
+        return tuple(outs)
+
+    def findEdges(self, e, phase, k=2.0):
+        return self.find(e, phase, (True, False, False))[0]
+
+    def findDarkLines(self, e, phase, k=2.0):
+        return self.find(e, phase, (False, True, False))[1]
+
+    def findBrightLines(self, e, phase, k=2.0):
+        return self.find(e, phase, (False, False, True))[2]
+
+    def pipeline(self, image, out=None):
+        """the callers' whole sequence (test/test.cpp:85-90) for one image ->
+        (g2, h2, e, magnitude, phase, edges, dark, bright)"""
+        image = _as_input(image)
+        self._like = image
+        outs = list(out) if out is not None else [self._new_like(image) for _ in range(8)]
+        self._bind_stream(image, *[o for o in outs if o is not None])
+        pi = _plane(image)
+        planes = [_plane(o) if o is not None else None for o in outs]
+        arr = (C.POINTER(Plane) * 8)(*[C.pointer(p) if p is not None else None for p in planes])
+        self._check(lib().cvs_pipeline(self._h, C.byref(pi), arr), "cvs_pipeline")
+        return tuple(outs)
+
+    def normalize_u8(self, plane):
+        """cv::normalize(plane, dst, 0, 255, NORM_MINMAX, CV_8UC1) on the GPU"""
+        self._bind_stream(plane)
+        pp = _plane(plane)
+        if _is_torch(plane) and plane.is_cuda:
+            dst = torch.empty(tuple(plane.shape), dtype=torch.uint8, device=plane.device)
+            rc = lib().cvs_normalize_u8(self._h, C.byref(pp), C.c_void_p(dst.data_ptr()), dst.stride(0), L.MEM_DEVICE)
+        else:
+            dst = np.empty(plane.shape, np.uint8)
+            rc = lib().cvs_normalize_u8(self._h, C.byref(pp), C.c_void_p(dst.ctypes.data), dst.strides[0], L.MEM_HOST)
+        self._check(rc, "cvs_normalize_u8")
+        return dst
+
+
+class SteerableFiltersG4(SteerableFilters):
+    """fa::SteerableFiltersG4 (SteerableFiltersG4.h:35-57): setup + steer only."""
+
+    KIND = L.KIND_G4
+    DEFAULT_WIDTH = 6
+    DEFAULT_SPACING = 0.5
+    _DEFAULT_FLAGS = SETUP_BASIS
+
+    def getDominantOrientationAngle(self):
+        """never assigned in the reference (G4.h:55): an empty Mat"""
+        return np.empty((0, 0), np.float32)
+
+    def getDominantOrientationStrength(self):
+        return np.empty((0, 0), np.float32)
+
+    def computeMagnitudeAndPhase(self, g4, h4, magnitude=None, phase=None):
+        """empty body in the reference (G4.cpp:88-90): outputs untouched"""
+        return magnitude, phase

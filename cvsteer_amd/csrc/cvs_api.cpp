@@ -1,0 +1,681 @@
+// cvs_api.cpp -- the C ABI of libcvsteer_hip.so (declared in include/cvsteer_hip.h).
+//
+// Thin by design: argument checks, device-state ownership, host<->device staging when a
+// caller hands over host planes, and kernel dispatch.  All arithmetic on the hot path is in
+// the HIP kernels (cvs_kernels_basis.hip, cvs_kernels_point.hip); the only host arithmetic is
+// what the reference also does on the host: tap generation and scalar steering weights
+// (cvs_taps.cpp) and the single-pixel steer (G2.cpp:115-134).  No CPU fallback exists.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cvs_internal.h"
+#include "cvsteer_hip.h"
+
+using namespace cvs;
+
+struct cvs_context {
+    int kind = 0, width = 0, nb = 0, device = 0;
+    float spacing = 0.f;
+    hipStream_t stream = nullptr;
+    float taps[kMaxBasis][kMaxTaps];
+    // state planes: nb basis, then c1,c2,c3,theta,strength
+    int rows = 0, cols = 0;
+    size_t pitch = 0, plane_stride = 0;
+    float* state = nullptr;
+    size_t state_elems = 0;
+    bool have_basis = false, have_orient = false;
+    // staging arena for host planes and scratch (bump allocated per call)
+    float* arena = nullptr;
+    size_t arena_elems = 0, arena_used = 0;
+    float* minmax = nullptr;
+    int atan_mode = 0, strip_rows = 0, find_on = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(cvs_handle h, int code, const char* what)
+{
+    if (h) h->err = what;
+    return code;
+}
+
+int fail_hip(cvs_handle h, hipError_t e, const char* where)
+{
+    if (h) h->err = std::string(where) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? CVS_E_NOMEM : CVS_E_HIP;
+}
+
+#define HIP_TRY(h, expr)                                        \
+    do {                                                        \
+        hipError_t e__ = (expr);                                \
+        if (e__ != hipSuccess) return fail_hip(h, e__, #expr);  \
+    } while (0)
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+int check_plane(cvs_handle h, const cvs_plane* p, const char* name)
+{
+    if (!p || !p->data) return fail(h, CVS_E_BADARG, name);
+    if (p->rows <= 0 || p->cols <= 0) return fail(h, CVS_E_SIZE, "empty plane");
+    if (p->step < (size_t)p->cols * sizeof(float) || p->step % sizeof(float)) return fail(h, CVS_E_SIZE, "bad step");
+    if (p->mem != CVS_MEM_HOST && p->mem != CVS_MEM_DEVICE) return fail(h, CVS_E_BADARG, "bad mem kind");
+    return CVS_OK;
+}
+
+int check_same(cvs_handle h, const cvs_plane* p, int rows, int cols)
+{
+    if (p->rows != rows || p->cols != cols) return fail(h, CVS_E_SIZE, "plane size mismatch");
+    return CVS_OK;
+}
+
+// ---- staging arena: device copies of host planes for the duration of one call ----
+struct Pending {
+    const cvs_plane* host;
+    float* dev;
+    size_t pitch;
+};
+
+struct Call {
+    cvs_handle h;
+    std::vector<Pending> outs;
+    bool touched_host = false;
+    size_t need = 0;
+};
+
+int arena_reserve(cvs_handle h, size_t elems)
+{
+    if (elems <= h->arena_elems) return CVS_OK;
+    if (h->arena) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipFree(h->arena));
+        h->arena = nullptr;
+        h->arena_elems = 0;
+    }
+    HIP_TRY(h, hipMalloc(&h->arena, elems * sizeof(float)));
+    h->arena_elems = elems;
+    return CVS_OK;
+}
+
+float* arena_take(cvs_handle h, size_t elems)
+{
+    float* p = h->arena + h->arena_used;
+    h->arena_used += round_up(elems, 64);
+    return p;
+}
+
+size_t staged_elems(const cvs_plane* p)
+{
+    return (p && p->mem == CVS_MEM_HOST) ? round_up(round_up((size_t)p->cols, 64) * p->rows, 64) : 0;
+}
+
+// resolve an input plane to a device pointer (uploading host data)
+int in_ref(Call& c, const cvs_plane* p, PlaneRef& r)
+{
+    cvs_handle h = c.h;
+    if (p->mem == CVS_MEM_DEVICE) {
+        r = {p->data, p->step / sizeof(float)};
+        return CVS_OK;
+    }
+    const size_t pitch = round_up((size_t)p->cols, 64);
+    float* d = arena_take(h, pitch * p->rows);
+    HIP_TRY(h, hipMemcpy2DAsync(d, pitch * sizeof(float), p->data, p->step, (size_t)p->cols * sizeof(float), p->rows,
+                                hipMemcpyHostToDevice, h->stream));
+    c.touched_host = true;
+    r = {d, pitch};
+    return CVS_OK;
+}
+
+int out_ref(Call& c, const cvs_plane* p, PlaneRef& r)
+{
+    cvs_handle h = c.h;
+    if (!p) {
+        r = {nullptr, 0};
+        return CVS_OK;
+    }
+    if (p->mem == CVS_MEM_DEVICE) {
+        r = {p->data, p->step / sizeof(float)};
+        return CVS_OK;
+    }
+    const size_t pitch = round_up((size_t)p->cols, 64);
+    float* d = arena_take(h, pitch * p->rows);
+    c.outs.push_back({p, d, pitch});
+    r = {d, pitch};
+    return CVS_OK;
+}
+
+// download pending host outputs; host-touching calls return with the data landed
+int finish(Call& c)
+{
+    cvs_handle h = c.h;
+    for (const Pending& o : c.outs) {
+        HIP_TRY(h, hipMemcpy2DAsync(o.host->data, o.host->step, o.dev, o.pitch * sizeof(float),
+                                    (size_t)o.host->cols * sizeof(float), o.host->rows, hipMemcpyDeviceToHost, h->stream));
+        c.touched_host = true;
+    }
+    if (c.touched_host) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CVS_OK;
+}
+
+int begin(cvs_handle h, Call& c, std::initializer_list<const cvs_plane*> planes, size_t extra = 0)
+{
+    c.h = h;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t need = extra;
+    for (const cvs_plane* p : planes) need += staged_elems(p);
+    if (need) {
+        int rc = arena_reserve(h, need);
+        if (rc) return rc;
+    }
+    h->arena_used = 0;
+    return CVS_OK;
+}
+
+float* state_plane(cvs_handle h, int idx) { return h->state + (size_t)idx * h->plane_stride; }
+
+int ensure_state(cvs_handle h, int rows, int cols)
+{
+    const size_t pitch = round_up((size_t)cols, 64);
+    const size_t stride = round_up(pitch * rows, 64);
+    const size_t elems = stride * (h->nb + 5);
+    if (elems > h->state_elems) {
+        if (h->state) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipFree(h->state));
+            h->state = nullptr;
+            h->state_elems = 0;
+        }
+        HIP_TRY(h, hipMalloc(&h->state, elems * sizeof(float)));
+        h->state_elems = elems;
+    }
+    h->rows = rows;
+    h->cols = cols;
+    h->pitch = pitch;
+    h->plane_stride = stride;
+    return CVS_OK;
+}
+
+int default_strip_rows(cvs_handle h, int rows, int cols)
+{
+    if (h->strip_rows > 0) return h->strip_rows;
+    // strips whose (rows + 2W) is a multiple of the 2W+1-row unroll waste no loop iterations;
+    // aim for >= ~2048 waves so all 256 CUs hold several.
+    const int nt = 2 * h->width + 1, halo = 2 * h->width;
+    const long strips_x = (cols + 63) / 64;
+    const double ideal = (double)rows * (double)strips_x / 2048.0;
+    long k = std::lround((ideal + halo) / nt);
+    if (k < 2) k = 2;
+    if (k > 8) k = 8;
+    return (int)(k * nt - halo);
+}
+
+int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, float theta, const cvs_plane* g,
+             const cvs_plane* hq)
+{
+    if (!h) return CVS_E_BADARG;
+    int rc = check_plane(h, image, "image");
+    if (rc) return rc;
+    if (!(flags & CVS_SETUP_BASIS)) flags |= CVS_SETUP_BASIS;
+    if ((flags & CVS_SETUP_ORIENT) && h->kind != CVS_KIND_G2)
+        return fail(h, CVS_E_UNSUPPORTED, "the reference computes no orientation for G4 (G4.cpp:67-81)");
+    if (steer) {
+        if ((rc = check_plane(h, g, "g")) || (rc = check_plane(h, hq, "hq"))) return rc;
+        if ((rc = check_same(h, g, image->rows, image->cols)) || (rc = check_same(h, hq, image->rows, image->cols))) return rc;
+    }
+    const size_t pitch = round_up((size_t)image->cols, 64);
+    const bool fast = basis_fast_path(h->kind, h->width, h->taps);
+    const size_t scratch = fast ? 0 : round_up(basis_scratch_elems(h->kind, h->width, image->rows, pitch), 64);
+    Call c;
+    rc = begin(h, c, {image, steer ? g : nullptr, steer ? hq : nullptr}, scratch);
+    if (rc) return rc;
+    h->have_basis = h->have_orient = false;
+    if ((rc = ensure_state(h, image->rows, image->cols))) return rc;
+
+    BasisArgs a{};
+    PlaneRef in;
+    if ((rc = in_ref(c, image, in))) return rc;
+    a.in = in.p;
+    a.in_pitch = in.pitch;
+    a.rows = image->rows;
+    a.cols = image->cols;
+    a.basis = h->state;
+    a.pitch = h->pitch;
+    a.plane_stride = h->plane_stride;
+    a.orient = (flags & CVS_SETUP_ORIENT) ? state_plane(h, h->nb) : nullptr;
+    a.atan_mode = h->atan_mode;
+    a.strip_rows = default_strip_rows(h, a.rows, a.cols);
+    if (steer) {
+        PlaneRef rg, rh;
+        if ((rc = out_ref(c, g, rg)) || (rc = out_ref(c, hq, rh))) return rc;
+        a.steer_g = rg.p;
+        a.steer_g_pitch = rg.pitch;
+        a.steer_h = rh.p;
+        a.steer_h_pitch = rh.pitch;
+        host_steer_weights(h->kind, theta, a.steer_w);
+    }
+    float* scr = scratch ? arena_take(h, scratch) : nullptr;
+    HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
+    h->have_basis = true;
+    h->have_orient = (flags & CVS_SETUP_ORIENT) != 0;
+    return finish(c);
+}
+
+void basis_inputs(cvs_handle h, PointArgs& a)
+{
+    for (int p = 0; p < h->nb; ++p) a.in[p] = {state_plane(h, p), h->pitch};
+}
+
+int need_state(cvs_handle h, bool orient)
+{
+    if (!h) return CVS_E_BADARG;
+    if (!h->have_basis) return fail(h, CVS_E_STATE, "no setup yet");
+    if (orient && !h->have_orient) return fail(h, CVS_E_STATE, "orientation state not computed (setup without CVS_SETUP_ORIENT)");
+    return CVS_OK;
+}
+
+int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map, const cvs_plane* g, const cvs_plane* hq,
+                 const cvs_plane* e, const cvs_plane* mag, const cvs_plane* phase)
+{
+    int rc = need_state(h, false);
+    if (rc) return rc;
+    if ((rc = check_plane(h, g, "g")) || (rc = check_plane(h, hq, "hq"))) return rc;
+    const cvs_plane* all[6] = {g, hq, e, mag, phase, theta_map};
+    for (const cvs_plane* p : all) {
+        if (!p) continue;
+        if ((rc = check_plane(h, p, "plane")) || (rc = check_same(h, p, h->rows, h->cols))) return rc;
+    }
+    if (h->kind == CVS_KIND_G4 && (e || mag || phase))
+        return fail(h, CVS_E_UNSUPPORTED, "G4 has no energy / magnitude / phase in the reference (G4.cpp:88-90)");
+    if (e && (rc = need_state(h, true))) return rc;
+    if (map && !theta_map && (rc = need_state(h, true))) return rc;
+
+    Call c;
+    if ((rc = begin(h, c, {g, hq, e, mag, phase, theta_map}))) return rc;
+    PointArgs a{};
+    a.rows = h->rows;
+    a.cols = h->cols;
+    a.atan_mode = h->atan_mode;
+    basis_inputs(h, a);
+    const int nb = h->nb;
+    if (h->kind == CVS_KIND_G2 && e) {
+        for (int i = 0; i < 3; ++i) a.in[7 + i] = {state_plane(h, nb + i), h->pitch};
+    }
+    if (map) {
+        PlaneRef th;
+        if (theta_map) {
+            if ((rc = in_ref(c, theta_map, th))) return rc;
+        } else {
+            th = {state_plane(h, nb + 3), h->pitch};
+        }
+        a.in[h->kind == CVS_KIND_G2 ? 10 : 11] = th;
+    } else {
+        host_steer_weights(h->kind, theta, a.w);
+        // G2.cpp:162: float c2t(std::cos(theta * 2.0)) -- double argument, narrowed
+        a.c2t = (float)std::cos((double)theta * 2.0);
+        a.s2t = (float)std::sin((double)theta * 2.0);
+    }
+    const cvs_plane* outs[5] = {g, hq, e, mag, phase};
+    for (int o = 0; o < (h->kind == CVS_KIND_G2 ? 5 : 2); ++o)
+        if ((rc = out_ref(c, outs[o], a.out[o]))) return rc;
+    PointOp op = h->kind == CVS_KIND_G2 ? (map ? OP_G2_STEER_MAP : OP_G2_STEER_SCALAR)
+                                        : (map ? OP_G4_STEER_MAP : OP_G4_STEER_SCALAR);
+    HIP_TRY(h, launch_point(op, a, h->stream));
+    return finish(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cvs_abi_version(void) { return CVS_ABI_VERSION; }
+
+const char* cvs_status_string(int s)
+{
+    switch (s) {
+        case CVS_OK: return "ok";
+        case CVS_E_BADARG: return "bad argument";
+        case CVS_E_SIZE: return "bad size";
+        case CVS_E_HIP: return "HIP error";
+        case CVS_E_NOMEM: return "out of memory";
+        case CVS_E_STATE: return "state not available";
+        case CVS_E_UNSUPPORTED: return "unsupported for this kind";
+    }
+    return "unknown status";
+}
+
+int cvs_num_basis(int kind) { return host_num_basis(kind); }
+
+int cvs_make_taps(int kind, int idx, int width, float spacing, float* out)
+{
+    return host_make_taps(kind, idx, width, spacing, out) ? CVS_E_BADARG : CVS_OK;
+}
+
+int cvs_basis_taps(int kind, int p, int* kx, int* ky) { return host_basis_taps(kind, p, kx, ky) ? CVS_E_BADARG : CVS_OK; }
+
+int cvs_steer_weights(int kind, float theta, float* out) { return host_steer_weights(kind, theta, out) ? CVS_E_BADARG : CVS_OK; }
+
+int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
+{
+    if (!out) return CVS_E_BADARG;
+    *out = nullptr;
+    const int nb = host_num_basis(kind);
+    if (nb == 0 || width < 1 || width > kMaxWidth) return CVS_E_BADARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CVS_E_HIP;  // no CPU fallback
+    if (device < 0 || device >= ndev) return CVS_E_BADARG;
+    if (hipSetDevice(device) != hipSuccess) return CVS_E_HIP;
+    cvs_context* h = new (std::nothrow) cvs_context();
+    if (!h) return CVS_E_NOMEM;
+    h->kind = kind;
+    h->width = width;
+    h->spacing = spacing;
+    h->nb = nb;
+    h->device = device;
+    std::memset(h->taps, 0, sizeof(h->taps));
+    for (int i = 0; i < nb; ++i) host_make_taps(kind, i, width, spacing, h->taps[i]);
+    if (hipMalloc(&h->minmax, 2 * sizeof(float)) != hipSuccess) {
+        delete h;
+        return CVS_E_NOMEM;
+    }
+    *out = h;
+    return CVS_OK;
+}
+
+int cvs_destroy(cvs_handle h)
+{
+    if (!h) return CVS_E_BADARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->state) (void)hipFree(h->state);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->minmax) (void)hipFree(h->minmax);
+    delete h;
+    return CVS_OK;
+}
+
+const char* cvs_last_error(cvs_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int cvs_set_stream(cvs_handle h, void* s)
+{
+    if (!h) return CVS_E_BADARG;
+    h->stream = static_cast<hipStream_t>(s);
+    return CVS_OK;
+}
+
+int cvs_set_option(cvs_handle h, int option, int value)
+{
+    if (!h) return CVS_E_BADARG;
+    switch (option) {
+        case CVS_OPT_ATAN_MODE:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "atan mode");
+            h->atan_mode = value;
+            return CVS_OK;
+        case CVS_OPT_STRIP_ROWS:
+            if (value < 0 || value > 1 << 20) return fail(h, CVS_E_BADARG, "strip rows");
+            h->strip_rows = value;
+            return CVS_OK;
+        case CVS_OPT_FIND_ON:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "find_on");
+            h->find_on = value;
+            return CVS_OK;
+    }
+    return fail(h, CVS_E_BADARG, "unknown option");
+}
+
+int cvs_get_option(cvs_handle h, int option, int* value)
+{
+    if (!h || !value) return CVS_E_BADARG;
+    switch (option) {
+        case CVS_OPT_ATAN_MODE: *value = h->atan_mode; return CVS_OK;
+        case CVS_OPT_STRIP_ROWS: *value = h->strip_rows; return CVS_OK;
+        case CVS_OPT_FIND_ON: *value = h->find_on; return CVS_OK;
+    }
+    return fail(h, CVS_E_BADARG, "unknown option");
+}
+
+int cvs_taps(cvs_handle h, int idx, float* out)
+{
+    if (!h || !out || idx < 0 || idx >= h->nb) return CVS_E_BADARG;
+    std::memcpy(out, h->taps[idx], (2 * h->width + 1) * sizeof(float));
+    return CVS_OK;
+}
+
+int cvs_kind(cvs_handle h, int* kind, int* width, float* spacing)
+{
+    if (!h) return CVS_E_BADARG;
+    if (kind) *kind = h->kind;
+    if (width) *width = h->width;
+    if (spacing) *spacing = h->spacing;
+    return CVS_OK;
+}
+
+int cvs_shape(cvs_handle h, int* rows, int* cols)
+{
+    if (!h) return CVS_E_BADARG;
+    if (rows) *rows = h->have_basis ? h->rows : 0;
+    if (cols) *cols = h->have_basis ? h->cols : 0;
+    return CVS_OK;
+}
+
+int cvs_sync(cvs_handle h)
+{
+    if (!h) return CVS_E_BADARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CVS_OK;
+}
+
+int cvs_setup(cvs_handle h, const cvs_plane* image, unsigned flags)
+{
+    return do_setup(h, image, flags, false, 0.f, nullptr, nullptr);
+}
+
+int cvs_setup_steer(cvs_handle h, const cvs_plane* image, unsigned flags, float theta, const cvs_plane* g, const cvs_plane* hq)
+{
+    return do_setup(h, image, flags, true, theta, g, hq);
+}
+
+static int state_index(cvs_handle h, int which)
+{
+    if (which >= CVS_PLANE_BASIS0 && which < CVS_PLANE_BASIS0 + h->nb) return which - CVS_PLANE_BASIS0;
+    if (which >= CVS_PLANE_C1 && which <= CVS_PLANE_STRENGTH) return h->nb + (which - CVS_PLANE_C1);
+    return -1;
+}
+
+int cvs_state_plane(cvs_handle h, int which, cvs_plane* view)
+{
+    if (!h || !view) return CVS_E_BADARG;
+    const int idx = state_index(h, which);
+    if (idx < 0) return fail(h, CVS_E_BADARG, "unknown state plane");
+    int rc = need_state(h, idx >= h->nb);
+    if (rc) return rc;
+    view->data = state_plane(h, idx);
+    view->rows = h->rows;
+    view->cols = h->cols;
+    view->step = h->pitch * sizeof(float);
+    view->mem = CVS_MEM_DEVICE;
+    return CVS_OK;
+}
+
+int cvs_read_state(cvs_handle h, int which, const cvs_plane* dst)
+{
+    cvs_plane src;
+    int rc = cvs_state_plane(h, which, &src);
+    if (rc) return rc;
+    if ((rc = check_plane(h, dst, "dst")) || (rc = check_same(h, dst, h->rows, h->cols))) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy2DAsync(dst->data, dst->step, src.data, src.step, (size_t)h->cols * sizeof(float), h->rows,
+                                dst->mem == CVS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
+    if (dst->mem == CVS_MEM_HOST) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CVS_OK;
+}
+
+int cvs_steer_scalar(cvs_handle h, float theta, const cvs_plane* g, const cvs_plane* hq, const cvs_plane* e,
+                     const cvs_plane* mag, const cvs_plane* phase)
+{
+    if (!h) return CVS_E_BADARG;
+    return steer_common(h, false, theta, nullptr, g, hq, e, mag, phase);
+}
+
+int cvs_steer_map(cvs_handle h, const cvs_plane* theta, const cvs_plane* g, const cvs_plane* hq, const cvs_plane* e,
+                  const cvs_plane* mag, const cvs_plane* phase)
+{
+    if (!h) return CVS_E_BADARG;
+    return steer_common(h, true, 0.f, theta, g, hq, e, mag, phase);
+}
+
+int cvs_steer_point(cvs_handle h, int x, int y, float theta, float out[5])
+{
+    if (!h || !out) return CVS_E_BADARG;
+    if (h->kind != CVS_KIND_G2) return fail(h, CVS_E_UNSUPPORTED, "point steer exists for G2 only (G2.cpp:115-134)");
+    int rc = need_state(h, false);
+    if (rc) return rc;
+    if (x < 0 || y < 0 || x >= h->cols || y >= h->rows) return fail(h, CVS_E_BADARG, "point outside the image");
+    HIP_TRY(h, hipSetDevice(h->device));
+    float v[10];
+    const int n = h->have_orient ? 10 : 7;
+    // one strided gather: element (y, x) of n consecutive state planes
+    HIP_TRY(h, hipMemcpy2DAsync(v, sizeof(float), h->state + (size_t)y * h->pitch + x, h->plane_stride * sizeof(float),
+                                sizeof(float), n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    float w[7];
+    host_steer_weights(CVS_KIND_G2, theta, w);
+    // G2.cpp:121-122 (float expression, left to right)
+    const float g2 = w[0] * v[0] + w[1] * v[1] + w[2] * v[2];
+    const float h2 = w[3] * v[3] + w[4] * v[4] + w[5] * v[5] + w[6] * v[6];
+    out[0] = g2;
+    out[1] = h2;
+    if (h->have_orient) {  // G2.cpp:132-133
+        const float c2t = (float)std::cos((double)theta * 2.0), s2t = (float)std::sin((double)theta * 2.0);
+        out[2] = v[7] + (c2t * v[8]) + (s2t * v[9]);
+    } else {
+        out[2] = std::numeric_limits<float>::quiet_NaN();
+    }
+    out[3] = std::sqrt(h2 * h2 + g2 * g2);  // G2.cpp:129
+    out[4] = std::atan2(h2, g2);            // G2.cpp:128: libm atan2, no wrap
+    return CVS_OK;
+}
+
+int cvs_mag_phase(cvs_handle h, const cvs_plane* g, const cvs_plane* hq, const cvs_plane* mag, const cvs_plane* phase)
+{
+    if (!h) return CVS_E_BADARG;
+    int rc;
+    if ((rc = check_plane(h, g, "g")) || (rc = check_plane(h, hq, "hq"))) return rc;
+    if (!mag && !phase) return fail(h, CVS_E_BADARG, "no output requested");
+    for (const cvs_plane* p : {hq, mag, phase}) {
+        if (!p) continue;
+        if ((rc = check_plane(h, p, "plane")) || (rc = check_same(h, p, g->rows, g->cols))) return rc;
+    }
+    Call c;
+    if ((rc = begin(h, c, {g, hq, mag, phase}))) return rc;
+    PointArgs a{};
+    a.rows = g->rows;
+    a.cols = g->cols;
+    a.atan_mode = h->atan_mode;
+    if ((rc = in_ref(c, g, a.in[0])) || (rc = in_ref(c, hq, a.in[1]))) return rc;
+    if ((rc = out_ref(c, mag, a.out[0])) || (rc = out_ref(c, phase, a.out[1]))) return rc;
+    HIP_TRY(h, launch_point(OP_MAG_PHASE, a, h->stream));
+    return finish(c);
+}
+
+int cvs_phase_weights(cvs_handle h, const cvs_plane* phase, const cvs_plane* lambda, float phi, int signum, float k)
+{
+    (void)k;  // accepted and ignored, like the reference (G2.cpp:179-186)
+    if (!h) return CVS_E_BADARG;
+    int rc;
+    if ((rc = check_plane(h, phase, "phase")) || (rc = check_plane(h, lambda, "lambda"))) return rc;
+    if ((rc = check_same(h, lambda, phase->rows, phase->cols))) return rc;
+    Call c;
+    if ((rc = begin(h, c, {phase, lambda}))) return rc;
+    PointArgs a{};
+    a.rows = phase->rows;
+    a.cols = phase->cols;
+    a.phi = phi;
+    a.signum = signum ? 1 : 0;
+    if ((rc = in_ref(c, phase, a.in[0])) || (rc = out_ref(c, lambda, a.out[0]))) return rc;
+    HIP_TRY(h, launch_point(OP_PHASE_WEIGHTS, a, h->stream));
+    return finish(c);
+}
+
+int cvs_find(cvs_handle h, const cvs_plane* e, const cvs_plane* phase, const cvs_plane* edges, const cvs_plane* dark,
+             const cvs_plane* bright)
+{
+    if (!h) return CVS_E_BADARG;
+    int rc;
+    if ((rc = check_plane(h, e, "e")) || (rc = check_plane(h, phase, "phase"))) return rc;
+    if (!edges && !dark && !bright) return fail(h, CVS_E_BADARG, "no output requested");
+    for (const cvs_plane* p : {phase, edges, dark, bright}) {
+        if (!p) continue;
+        if ((rc = check_plane(h, p, "plane")) || (rc = check_same(h, p, e->rows, e->cols))) return rc;
+    }
+    Call c;
+    if ((rc = begin(h, c, {e, phase, edges, dark, bright}))) return rc;
+    PointArgs a{};
+    a.rows = e->rows;
+    a.cols = e->cols;
+    if ((rc = in_ref(c, e, a.in[0])) || (rc = in_ref(c, phase, a.in[1]))) return rc;
+    if ((rc = out_ref(c, edges, a.out[0])) || (rc = out_ref(c, dark, a.out[1])) || (rc = out_ref(c, bright, a.out[2]))) return rc;
+    HIP_TRY(h, launch_point(OP_FIND, a, h->stream));
+    return finish(c);
+}
+
+int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const outs[8])
+{
+    if (!h || !outs) return CVS_E_BADARG;
+    if (h->kind != CVS_KIND_G2) return fail(h, CVS_E_UNSUPPORTED, "the caller pipeline exists for G2 only");
+    int rc = check_plane(h, image, "image");
+    if (rc) return rc;
+    for (int o = 0; o < 8; ++o) {
+        if (!outs[o]) continue;
+        if ((rc = check_plane(h, outs[o], "out")) || (rc = check_same(h, outs[o], image->rows, image->cols))) return rc;
+    }
+    if ((rc = do_setup(h, image, CVS_SETUP_FULL, false, 0.f, nullptr, nullptr))) return rc;
+    Call c;
+    if ((rc = begin(h, c, {outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], outs[6], outs[7]}))) return rc;
+    PointArgs a{};
+    a.rows = h->rows;
+    a.cols = h->cols;
+    a.atan_mode = h->atan_mode;
+    a.find_on_e = h->find_on;
+    basis_inputs(h, a);
+    for (int i = 0; i < 3; ++i) a.in[7 + i] = {state_plane(h, h->nb + i), h->pitch};
+    a.in[10] = {state_plane(h, h->nb + 3), h->pitch};
+    for (int o = 0; o < 8; ++o)
+        if ((rc = out_ref(c, outs[o], a.out[o]))) return rc;
+    HIP_TRY(h, launch_point(OP_G2_PIPELINE, a, h->stream));
+    return finish(c);
+}
+
+int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem)
+{
+    if (!h || !dst) return CVS_E_BADARG;
+    int rc = check_plane(h, src, "src");
+    if (rc) return rc;
+    if (dst_step < (size_t)src->cols) return fail(h, CVS_E_SIZE, "dst_step");
+    if (dst_mem != CVS_MEM_HOST && dst_mem != CVS_MEM_DEVICE) return fail(h, CVS_E_BADARG, "dst_mem");
+    const size_t u8_elems = dst_mem == CVS_MEM_HOST ? round_up(round_up((size_t)src->cols, 256) * src->rows / 4 + 64, 64) : 0;
+    Call c;
+    if ((rc = begin(h, c, {src}, u8_elems))) return rc;
+    PlaneRef in;
+    if ((rc = in_ref(c, src, in))) return rc;
+    HIP_TRY(h, launch_minmax(in.p, in.pitch, src->rows, src->cols, h->minmax, h->stream));
+    if (dst_mem == CVS_MEM_DEVICE) {
+        HIP_TRY(h, launch_quantize_u8(in.p, in.pitch, src->rows, src->cols, h->minmax, dst, dst_step, h->stream));
+        return finish(c);
+    }
+    const size_t dpitch = round_up((size_t)src->cols, 256);
+    uint8_t* d = reinterpret_cast<uint8_t*>(arena_take(h, u8_elems));
+    HIP_TRY(h, launch_quantize_u8(in.p, in.pitch, src->rows, src->cols, h->minmax, d, dpitch, h->stream));
+    HIP_TRY(h, hipMemcpy2DAsync(dst, dst_step, d, dpitch, (size_t)src->cols, src->rows, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// cvs_device_math.h -- per-pixel device helpers shared by the basis and pointwise kernels.
+// gfx950 only.  Every helper states which reference / OpenCV step it stands for.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cvs {
+
+constexpr float kPiF = 3.14159274f;      // (float)M_PI      -- wrap threshold, SteerableFilters.cpp:50
+constexpr float kTwoPiF = 6.2831855f;    // (float)(2*M_PI)  -- wrap shift,     SteerableFilters.cpp:49
+constexpr float kHalfPiF = 1.57079637f;  // (float)M_PI_2    -- phaseWeights gate, G2.cpp:185
+
+// BORDER_REFLECT_101 (sepFilter2D default border), any distance, len >= 1.
+__host__ __device__ inline int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    const int period = 2 * len - 2;
+    p %= period;
+    if (p < 0) p += period;
+    return p < len ? p : period - p;
+}
+
+// cv::cartToPolar's angle (radians, [0, 2pi)).
+// mode 0: the OpenCV 3.4 fastAtan2 polynomial in degrees, every op separately rounded
+// (__f*_rn are never contracted), then * (float)(pi/180).  mode 1: atan2f.
+__device__ inline float angle_0_2pi(float y, float x, int mode)
+{
+    if (mode == 0) {
+        const float scale = (float)(180.0 / 3.14159265358979323846);
+        const float p1 = 0.9997878412794807f * scale;
+        const float p3 = -0.3258083974640975f * scale;
+        const float p5 = 0.1555786518463281f * scale;
+        const float p7 = -0.04432655554792128f * scale;
+        const float eps = 2.2204460492503131e-16f;  // (float)DBL_EPSILON
+        const float ax = fabsf(x), ay = fabsf(y);
+        const bool xge = ax >= ay;  // NaNs take the 'else' arm and stay NaN, like the reference
+        const float mn = xge ? ay : ax, mx = xge ? ax : ay;
+        const float c = __fdiv_rn(mn, __fadd_rn(mx, eps));
+        const float c2 = __fmul_rn(c, c);
+        float a = __fadd_rn(__fmul_rn(p7, c2), p5);
+        a = __fadd_rn(__fmul_rn(a, c2), p3);
+        a = __fadd_rn(__fmul_rn(a, c2), p1);
+        a = __fmul_rn(a, c);
+        if (!xge) a = __fsub_rn(90.f, a);
+        if (x < 0.f) a = __fsub_rn(180.f, a);
+        if (y < 0.f) a = __fsub_rn(360.f, a);
+        return __fmul_rn(a, (float)(3.14159265358979323846 / 180.0));
+    }
+    float a = atan2f(y, x);
+    if (a < 0.f) a = __fadd_rn(a, kTwoPiF);
+    return a;
+}
+
+// SteerableFilters::wrap, SteerableFilters.cpp:46-51
+__device__ inline float wrap_pi(float a) { return a > kPiF ? __fsub_rn(a, kTwoPiF) : a; }
+
+// computeMagnitudeAndPhase, G2.cpp:107-112 (cartToPolar + wrap + patchNaNs)
+__device__ inline void mag_phase(float g, float h, int mode, float& mag, float& phase)
+{
+    mag = __fsqrt_rn(__fadd_rn(__fmul_rn(g, g), __fmul_rn(h, h)));
+    float p = wrap_pi(angle_0_2pi(h, g, mode));
+    phase = (p != p) ? 0.f : p;
+}
+
+// phaseWeights, G2.cpp:179-186: lambda = cos^2(err) gated at pi/2
+__device__ inline float phase_lambda(float phase, float phi, bool signum)
+{
+    float err = signum ? fabsf(__fsub_rn(phase, phi)) : fabsf(__fsub_rn(fabsf(phase), fabsf(phi)));
+    err = fminf(err, __fsub_rn(kTwoPiF, err));
+    const float ct = cosf(err);
+    float l = __fmul_rn(ct, ct);
+    if (fabsf(err) > kHalfPiF) l = 0.f;
+    return l;
+}
+
+// G2.cpp:70-99: products, C1..C3, cartToPolar, wrap, *0.5.  b = {g2a,g2b,g2c,h2a,h2b,h2c,h2d}.
+__device__ inline void g2_orientation(const float b[7], int mode, float& c1, float& c2, float& c3,
+                                      float& theta, float& strength)
+{
+    const float A = b[0], B = b[1], C = b[2], HA = b[3], HB = b[4], HC = b[5], HD = b[6];
+    const float g2aa = __fmul_rn(A, A), g2ab = __fmul_rn(A, B), g2ac = __fmul_rn(A, C);
+    const float g2bb = __fmul_rn(B, B), g2bc = __fmul_rn(B, C), g2cc = __fmul_rn(C, C);
+    const float h2aa = __fmul_rn(HA, HA), h2ab = __fmul_rn(HA, HB), h2ac = __fmul_rn(HA, HC), h2ad = __fmul_rn(HA, HD);
+    const float h2bb = __fmul_rn(HB, HB), h2bc = __fmul_rn(HB, HC), h2bd = __fmul_rn(HB, HD);
+    const float h2cc = __fmul_rn(HC, HC), h2cd = __fmul_rn(HC, HD), h2dd = __fmul_rn(HD, HD);
+    // every MatExpr node of G2.cpp:93-95 rounds to f32; scalars distribute over (a +/- b)
+    float v1 = __fadd_rn(__fmul_rn(0.5f, g2bb), __fmul_rn(0.25f, g2ac));
+    v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.375f, g2aa), __fmul_rn(0.375f, g2cc)));
+    v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.3125f, h2aa), __fmul_rn(0.3125f, h2dd)));
+    v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.5625f, h2bb), __fmul_rn(0.5625f, h2cc)));
+    v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.375f, h2ac), __fmul_rn(0.375f, h2bd)));
+    float v2 = __fsub_rn(__fmul_rn(0.5f, g2aa), __fmul_rn(0.5f, g2cc));
+    v2 = __fadd_rn(v2, __fsub_rn(__fmul_rn(0.46875f, h2aa), __fmul_rn(0.46875f, h2dd)));
+    v2 = __fadd_rn(v2, __fsub_rn(__fmul_rn(0.28125f, h2bb), __fmul_rn(0.28125f, h2cc)));
+    v2 = __fadd_rn(v2, __fsub_rn(__fmul_rn(0.1875f, h2ac), __fmul_rn(0.1875f, h2bd)));
+    float v3 = __fsub_rn(-g2ab, g2bc);
+    v3 = __fsub_rn(v3, __fadd_rn(__fmul_rn(0.9375f, h2cd), __fmul_rn(0.9375f, h2ab)));
+    v3 = __fsub_rn(v3, __fmul_rn(1.6875f, h2bc));
+    v3 = __fsub_rn(v3, __fmul_rn(0.1875f, h2ad));
+    c1 = v1; c2 = v2; c3 = v3;
+    strength = __fsqrt_rn(__fadd_rn(__fmul_rn(v2, v2), __fmul_rn(v3, v3)));
+    theta = __fmul_rn(wrap_pi(angle_0_2pi(v3, v2, mode)), 0.5f);
+}
+
+// steer(float theta, ...) G2.cpp:143-144: (ga*A + gb*B) + gc*C, every node rounded
+__device__ inline void g2_steer_weights(const float b[7], const float w[7], float& g, float& h)
+{
+    g = __fadd_rn(__fadd_rn(__fmul_rn(w[0], b[0]), __fmul_rn(w[1], b[1])), __fmul_rn(w[2], b[2]));
+    h = __fadd_rn(__fmul_rn(w[3], b[3]), __fmul_rn(w[4], b[4]));
+    h = __fadd_rn(h, __fmul_rn(w[5], b[5]));
+    h = __fadd_rn(h, __fmul_rn(w[6], b[6]));
+}
+
+// steer(const Mat1f& theta, ...) G2.cpp:147-155: cos/sin per pixel, (scale*(a*b))*M products
+__device__ inline void g2_steer_angle(const float b[7], float theta, float& g, float& h)
+{
+    float st, ct;
+    sincosf(theta, &st, &ct);
+    const float ct2 = __fmul_rn(ct, ct), ct3 = __fmul_rn(ct2, ct);
+    const float st2 = __fmul_rn(st, st), st3 = __fmul_rn(st2, st);
+    g = __fmul_rn(ct2, b[0]);
+    g = __fadd_rn(g, __fmul_rn(__fmul_rn(-2.0f, __fmul_rn(ct, st)), b[1]));
+    g = __fadd_rn(g, __fmul_rn(st2, b[2]));
+    h = __fmul_rn(ct3, b[3]);
+    h = __fadd_rn(h, __fmul_rn(__fmul_rn(-3.0f, __fmul_rn(ct2, st)), b[4]));
+    h = __fadd_rn(h, __fmul_rn(__fmul_rn(3.0f, __fmul_rn(ct, st2)), b[5]));
+    h = __fadd_rn(h, __fmul_rn(-st3, b[6]));
+}
+
+// G4.cpp:120-121: sums left to right
+__device__ inline void g4_steer_weights(const float b[11], const float w[11], float& g, float& h)
+{
+    g = __fadd_rn(__fmul_rn(w[0], b[0]), __fmul_rn(w[1], b[1]));
+#pragma unroll
+    for (int p = 2; p < 5; p++) g = __fadd_rn(g, __fmul_rn(w[p], b[p]));
+    h = __fadd_rn(__fmul_rn(w[5], b[5]), __fmul_rn(w[6], b[6]));
+#pragma unroll
+    for (int p = 7; p < 11; p++) h = __fadd_rn(h, __fmul_rn(w[p], b[p]));
+}
+
+// G4.cpp:92-112: weight planes from cos/sin powers, then weight.mul(basis) summed l-to-r
+__device__ inline void g4_steer_angle(const float b[11], float theta, float& g, float& h)
+{
+    float st, ct;
+    sincosf(theta, &st, &ct);
+    const float ct2 = __fmul_rn(ct, ct), ct3 = __fmul_rn(ct2, ct), ct4 = __fmul_rn(ct3, ct), ct5 = __fmul_rn(ct4, ct);
+    const float st2 = __fmul_rn(st, st), st3 = __fmul_rn(st2, st), st4 = __fmul_rn(st3, st), st5 = __fmul_rn(st4, st);
+    const float w[11] = { ct4, __fmul_rn(-4.0f, __fmul_rn(ct3, st)), __fmul_rn(6.0f, __fmul_rn(ct2, st2)),
+                          __fmul_rn(-4.0f, __fmul_rn(ct, st3)), st4,
+                          ct5, __fmul_rn(-5.0f, __fmul_rn(ct4, st)), __fmul_rn(10.0f, __fmul_rn(ct3, st2)),
+                          __fmul_rn(-10.0f, __fmul_rn(ct2, st3)), __fmul_rn(5.0f, __fmul_rn(ct, st4)), -st5 };
+    g = __fmul_rn(w[0], b[0]);
+#pragma unroll
+    for (int p = 1; p < 5; p++) g = __fadd_rn(g, __fmul_rn(w[p], b[p]));
+    h = __fmul_rn(w[5], b[5]);
+#pragma unroll
+    for (int p = 6; p < 11; p++) h = __fadd_rn(h, __fmul_rn(w[p], b[p]));
+}
+
+}  // namespace cvs

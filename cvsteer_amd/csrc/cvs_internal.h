@@ -1,0 +1,85 @@
+// cvs_internal.h -- launch descriptors shared between the C-ABI layer (cvs_api.cpp) and the
+// kernel translation units.  Not part of the public boundary (that is include/cvsteer_hip.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cvs {
+
+constexpr int kMaxWidth = 32;           // generic path: up to 65 taps
+constexpr int kMaxTaps = 2 * kMaxWidth + 1;
+constexpr int kMaxBasis = 11;
+
+// One launch of the fused basis kernel ("K1").  All pitches/strides are in ELEMENTS.
+struct BasisArgs {
+    const float* in;      // image, device
+    size_t in_pitch;
+    int rows, cols;
+    float* basis;         // nb planes, plane p at basis + p*plane_stride
+    size_t pitch;         // row pitch of every state plane
+    size_t plane_stride;
+    float* orient;        // c1,c2,c3,theta,strength at orient + i*plane_stride, or nullptr
+    float* steer_g;       // fused scalar-steer outputs, or nullptr
+    size_t steer_g_pitch;
+    float* steer_h;
+    size_t steer_h_pitch;
+    float steer_w[kMaxBasis];  // scalar steering weights (host-computed)
+    int strip_rows;       // output rows per wave strip
+    int atan_mode;
+};
+
+// taps[i] = the handle's i-th tap vector (member order), 2*width+1 floats each
+hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
+                        float* scratch, hipStream_t s);
+// elements of scratch the generic-width path needs for this image (0 on the fast paths)
+size_t basis_scratch_elems(int kind, int width, int rows, size_t pitch);
+bool basis_fast_path(int kind, int width, const float (*taps)[kMaxTaps]);
+
+// ---- pointwise kernels ("K2..K5") ----
+struct PlaneRef {
+    float* p;       // nullptr = not requested
+    size_t pitch;   // elements
+};
+
+enum PointOp {
+    OP_G2_ORIENT = 0,      // in: 7 basis                     out: c1,c2,c3,theta,strength
+    OP_G2_STEER_SCALAR,    // in: 7 basis [,c1,c2,c3]          out: g,h[,e,mag,phase]
+    OP_G2_STEER_MAP,       // in: 7 basis, theta [,c1,c2,c3]   out: g,h[,e,mag,phase]
+    OP_G4_STEER_SCALAR,    // in: 11 basis                    out: g,h
+    OP_G4_STEER_MAP,       // in: 11 basis, theta             out: g,h
+    OP_MAG_PHASE,          // in: g,h                          out: mag,phase
+    OP_PHASE_WEIGHTS,      // in: phase                        out: lambda
+    OP_FIND,               // in: e,phase                      out: edges,dark,bright
+    OP_G2_PIPELINE         // in: 7 basis, theta, c1,c2,c3     out: g,h,e,mag,phase,edges,dark,bright
+};
+
+constexpr int kMaxIn = 15;
+constexpr int kMaxOut = 8;
+
+struct PointArgs {
+    int rows, cols;
+    PlaneRef in[kMaxIn];
+    PlaneRef out[kMaxOut];
+    float w[kMaxBasis];   // scalar steering weights
+    float c2t, s2t;       // cos/sin(2 theta) for the scalar-theta energy
+    float phi;            // phaseWeights
+    int signum;
+    int atan_mode;
+    int find_on_e;        // pipeline: 1 = find*(e, phase), 0 = find*(magnitude, phase)
+};
+
+hipError_t launch_point(PointOp op, const PointArgs& a, hipStream_t s);
+
+// per-image min/max + 8-bit quantise (cv::normalize NORM_MINMAX -> CV_8UC1)
+hipError_t launch_minmax(const float* src, size_t pitch, int rows, int cols, float* minmax2, hipStream_t s);
+hipError_t launch_quantize_u8(const float* src, size_t pitch, int rows, int cols, const float* minmax2,
+                              uint8_t* dst, size_t dst_step, hipStream_t s);
+
+// host-side tap math (cvs_taps.cpp, no HIP)
+int host_num_basis(int kind);
+int host_make_taps(int kind, int idx, int width, float spacing, float* out);
+int host_basis_taps(int kind, int p, int* kx, int* ky);
+int host_steer_weights(int kind, float theta, float* out);
+
+}  // namespace cvs

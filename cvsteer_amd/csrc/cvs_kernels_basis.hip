@@ -1,0 +1,341 @@
+// cvs_kernels_basis.hip -- "K1": the separable G2/H2 (7-plane) and G4/H4 (11-plane) basis
+// filter bank, fused, for gfx950 (MI355X, wave64).
+//
+// Replaces the 7 (11) cv::sepFilter2D calls of SteerableFiltersG2::setup (reference
+// cvsteer/SteerableFiltersG2.cpp:62-68) / SteerableFiltersG4::setup (SteerableFiltersG4.cpp:69-80)
+// and, in the fused epilogues, G2.cpp:70-99 (C1..C3, theta, strength) and G2.cpp:137-145 /
+// G4.cpp:114-122 (scalar steer).
+//
+// Design (HBM-bound: 4 B read + 28/44 B written per pixel, ~95/230 VALU ops per pixel):
+//  * one WAVE owns a strip 64 columns wide and `strip_rows` tall and marches down it; the four
+//    waves of a workgroup own four adjacent strips and never synchronise with each other.
+//  * per input row the wave issues one coalesced 256-B row load (+ one 2W-lane halo load),
+//    stages the 64+2W values in its private LDS line, and every lane reads its 2W+1
+//    neighbours back: the row pass.  REFLECT_101 is folded into the load addresses, so the
+//    border costs nothing in the loop.
+//  * the 6 (10) distinct row-filtered values enter a (2W+1)-deep sliding window held in
+//    VGPRs (the row loop is unrolled 2W+1 times so every window slot is a fixed register);
+//    the column pass runs on that window, also in folded symmetric / antisymmetric form.
+//  * the input is read once and every output plane is written once with 256-B row segments.
+//  * loads for the next 2W+1 rows are in flight while the current ones are filtered.
+#include <hip/hip_runtime.h>
+
+#include "cvs_device_math.h"
+#include "cvs_internal.h"
+
+namespace cvs {
+
+// ---------------------------------------------------------------------------------------
+// filter-bank descriptors: which distinct 1-D kernels exist and which (row, column) pair
+// makes each basis plane.  Kernel ids: [0, NE) even (mirror), [NE, NE+NO) odd (anti-mirror).
+// ---------------------------------------------------------------------------------------
+struct BankG2 {  // SteerableFiltersG2.cpp:62-68
+    static constexpr int KIND = 2, W = 4, NE = 3, NO = 3, NB = 7;
+    // even: E0=G21 E1=G22(=H22) E2=H24 ; odd: O0=G23 O1=H21 O2=H23 (ids 3,4,5)
+    __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 3, 1, 4, 2, 5, 1}; return t[p]; }
+    __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 3, 0, 1, 5, 2, 4}; return t[p]; }
+    static constexpr int even_member(int r) { constexpr int t[NE] = {0, 1, 6}; return t[r]; }
+    static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3, 5}; return t[r]; }
+    static constexpr int dup_a = 1, dup_b = 4;  // m_g2 == m_h2 bit for bit
+};
+
+struct BankG4 {  // SteerableFiltersG4.cpp:69-80
+    static constexpr int KIND = 4, W = 6, NE = 5, NO = 5, NB = 11;
+    // even: E0=G41 E1=G42(=H42) E2=G45 E3=H43 E4=H46 ; odd: O0=G43 O1=G44 O2=H41 O3=H44 O4=H45 (ids 5..9)
+    __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 5, 2, 6, 1, 7, 3, 9, 4, 8, 1}; return t[p]; }
+    __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 6, 2, 5, 0, 1, 8, 4, 9, 3, 7}; return t[p]; }
+    static constexpr int even_member(int r) { constexpr int t[NE] = {0, 1, 4, 7, 10}; return t[r]; }
+    static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3, 5, 8, 9}; return t[r]; }
+    static constexpr int dup_a = 1, dup_b = 6;  // m_g2 == m_h2
+};
+
+// folded taps: ev[r][i] = tap at offset +/-i (i = 0..W); od[r][i-1] = tap at offset +i (i = 1..W)
+template <class B>
+struct Folded {
+    float ev[B::NE][B::W + 1];
+    float od[B::NO][B::W];
+};
+
+enum { F_ORIENT = 1, F_STEER = 2 };
+
+// LDS hand-off inside ONE wave: DS ops of a wave execute in issue order, so only the compiler
+// must be kept from moving them across this point.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class B, int FLAGS>
+__global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B> t)
+{
+    constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
+    constexpr int LW = 64 + 2 * W;
+    __shared__ float lds[4][LW + 4];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * 4 + wv) * 64;
+    if (x0 >= a.cols) return;  // wave-uniform; waves of a workgroup never rendezvous
+    const int y0 = blockIdx.y * a.strip_rows;
+    const int yend = min(y0 + a.strip_rows, a.rows);
+    const int x = x0 + lane;
+    const bool xin = x < a.cols;
+    // REFLECT_101 source columns, fixed for the whole strip
+    const int xm = reflect101(x, a.cols);
+    const bool is_halo = lane < 2 * W;
+    const int xh = reflect101(lane < W ? x0 - W + lane : x0 + 64 + (lane - W), a.cols);
+    const int hslot = lane < W ? lane : 64 + lane;  // left halo -> [0,W), right -> [64+W, 64+2W)
+    float* line = lds[wv];
+
+    float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
+    float cur[NT], curh[NT], nxt[NT], nxth[NT];
+
+    const int nrows_in = (yend - y0) + 2 * W;
+    const int ngroups = (nrows_in + NT - 1) / NT;
+
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float* rp = a.in + (size_t)reflect101(y0 - W + j, a.rows) * a.in_pitch;
+        cur[j] = rp[xm];
+        curh[j] = is_halo ? rp[xh] : 0.f;
+        nxt[j] = 0.f;
+        nxth[j] = 0.f;
+    }
+
+    for (int g = 0; g < ngroups; ++g) {
+        if (g + 1 < ngroups) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float* rp = a.in + (size_t)reflect101(y0 - W + (g + 1) * NT + j, a.rows) * a.in_pitch;
+                nxt[j] = rp[xm];
+                nxth[j] = is_halo ? rp[xh] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            // ---- row pass: stage the line, read the 2W+1 neighbours ----
+            line[W + lane] = cur[j];
+            if (is_halo) line[hslot] = curh[j];
+            wave_lds_fence();
+            float s[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) s[k] = line[lane + k];
+            wave_lds_fence();
+
+            float sum[W + 1], dif[W + 1];
+#pragma unroll
+            for (int i = 1; i <= W; ++i) {
+                sum[i] = s[W + i] + s[W - i];
+                dif[i] = s[W + i] - s[W - i];
+            }
+#pragma unroll
+            for (int r = 0; r < NE; ++r) {
+                float acc = t.ev[r][W] * sum[W];
+#pragma unroll
+                for (int i = W - 1; i >= 1; --i) acc = fmaf(t.ev[r][i], sum[i], acc);
+                win[r][j] = fmaf(t.ev[r][0], s[W], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < NO; ++r) {
+                float acc = t.od[r][W - 1] * dif[W];
+#pragma unroll
+                for (int i = W - 1; i >= 1; --i) acc = fmaf(t.od[r][i - 1], dif[i], acc);
+                win[NE + r][j] = acc;
+            }
+
+            // ---- column pass on the window; newest row is slot j, centre is W rows back ----
+            const int yout = y0 + g * NT + j - 2 * W;
+            if (yout >= y0 && yout < yend) {  // wave-uniform
+                float b[NB];
+#pragma unroll
+                for (int p = 0; p < NB; ++p) {
+                    const int rp = B::rx(p), ck = B::cy(p);
+                    const int c = (j + 1 + W) % NT;
+                    float acc;
+                    if (ck < NE) {
+                        acc = t.ev[ck][W] * (win[rp][(j + 1 + 2 * W) % NT] + win[rp][(j + 1) % NT]);
+#pragma unroll
+                        for (int i = W - 1; i >= 1; --i)
+                            acc = fmaf(t.ev[ck][i], win[rp][(j + 1 + W + i) % NT] + win[rp][(j + 1 + W - i) % NT], acc);
+                        acc = fmaf(t.ev[ck][0], win[rp][c], acc);
+                    } else {
+                        acc = t.od[ck - NE][W - 1] * (win[rp][(j + 1 + 2 * W) % NT] - win[rp][(j + 1) % NT]);
+#pragma unroll
+                        for (int i = W - 1; i >= 1; --i)
+                            acc = fmaf(t.od[ck - NE][i - 1], win[rp][(j + 1 + W + i) % NT] - win[rp][(j + 1 + W - i) % NT], acc);
+                    }
+                    b[p] = acc;
+                }
+                if (xin) {
+                    float* orow = a.basis + (size_t)yout * a.pitch;
+#pragma unroll
+                    for (int p = 0; p < NB; ++p) orow[(size_t)p * a.plane_stride + x] = b[p];
+                    if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
+                        float c1, c2, c3, th, st;
+                        g2_orientation(b, a.atan_mode, c1, c2, c3, th, st);
+                        float* o = a.orient + (size_t)yout * a.pitch + x;
+                        o[0] = c1;
+                        o[a.plane_stride] = c2;
+                        o[2 * a.plane_stride] = c3;
+                        o[3 * a.plane_stride] = th;
+                        o[4 * a.plane_stride] = st;
+                    }
+                    if constexpr ((FLAGS & F_STEER) != 0) {
+                        float gq, hq;
+                        if constexpr (B::KIND == 2) g2_steer_weights(b, a.steer_w, gq, hq);
+                        else g4_steer_weights(b, a.steer_w, gq, hq);
+                        a.steer_g[(size_t)yout * a.steer_g_pitch + x] = gq;
+                        a.steer_h[(size_t)yout * a.steer_h_pitch + x] = hq;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            cur[j] = nxt[j];
+            curh[j] = nxth[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// generic-width fallback (any width <= kMaxWidth, any taps): two plain passes through a
+// scratch plane, one basis plane at a time.  Same summation order as the CPU reference's
+// generic RowFilter / ColumnFilter.  Not tuned: the reference's defaults (G2 w=4, G4 w=6)
+// never take this path.
+// ---------------------------------------------------------------------------------------
+struct TapVec {
+    float k[kMaxTaps];
+};
+
+__global__ __launch_bounds__(256) void k_rowpass_generic(const float* in, size_t in_pitch, int rows, int cols,
+                                                          float* out, size_t out_pitch, TapVec kx, int w)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    const float* rp = in + (size_t)y * in_pitch;
+    float acc = kx.k[0] * rp[reflect101(x - w, cols)];
+    for (int i = 1; i <= 2 * w; ++i) acc = fmaf(kx.k[i], rp[reflect101(x - w + i, cols)], acc);
+    out[(size_t)y * out_pitch + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_colpass_generic(const float* in, size_t in_pitch, int rows, int cols,
+                                                          float* out, size_t out_pitch, TapVec ky, int w)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    float acc = ky.k[0] * in[(size_t)reflect101(y - w, rows) * in_pitch + x];
+    for (int j = 1; j <= 2 * w; ++j) acc = fmaf(ky.k[j], in[(size_t)reflect101(y - w + j, rows) * in_pitch + x], acc);
+    out[(size_t)y * out_pitch + x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+template <class B>
+static bool fold_taps(const float (*taps)[kMaxTaps], Folded<B>& f)
+{
+    constexpr int W = B::W;
+    for (int r = 0; r < B::NE; ++r) {
+        const float* k = taps[B::even_member(r)];
+        for (int i = 0; i <= W; ++i) {
+            if (k[W + i] != k[W - i]) return false;
+            f.ev[r][i] = k[W + i];
+        }
+    }
+    for (int r = 0; r < B::NO; ++r) {
+        const float* k = taps[B::odd_member(r)];
+        if (k[W] != 0.0f) return false;
+        for (int i = 1; i <= W; ++i) {
+            if (k[W + i] != -k[W - i]) return false;
+            f.od[r][i - 1] = k[W + i];
+        }
+    }
+    for (int i = 0; i < 2 * W + 1; ++i)
+        if (taps[B::dup_a][i] != taps[B::dup_b][i]) return false;
+    return true;
+}
+
+bool basis_fast_path(int kind, int width, const float (*taps)[kMaxTaps])
+{
+    if (kind == 2 && width == BankG2::W) { Folded<BankG2> f; return fold_taps<BankG2>(taps, f); }
+    if (kind == 4 && width == BankG4::W) { Folded<BankG4> f; return fold_taps<BankG4>(taps, f); }
+    return false;
+}
+
+size_t basis_scratch_elems(int kind, int width, int rows, size_t pitch)
+{
+    (void)kind; (void)width;
+    return (size_t)rows * pitch;  // one plane; only touched on the generic path
+}
+
+template <class B>
+static hipError_t launch_fast(const BasisArgs& a, const Folded<B>& f, hipStream_t s)
+{
+    const int strips_x = (a.cols + 63) / 64;
+    dim3 grid((strips_x + 3) / 4, (a.rows + a.strip_rows - 1) / a.strip_rows);
+    dim3 block(256);
+    const bool orient = a.orient != nullptr && B::KIND == 2;
+    const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
+    if (orient && steer) hipLaunchKernelGGL((k_basis<B, F_ORIENT | F_STEER>), grid, block, 0, s, a, f);
+    else if (orient) hipLaunchKernelGGL((k_basis<B, F_ORIENT>), grid, block, 0, s, a, f);
+    else if (steer) hipLaunchKernelGGL((k_basis<B, F_STEER>), grid, block, 0, s, a, f);
+    else hipLaunchKernelGGL((k_basis<B, 0>), grid, block, 0, s, a, f);
+    return hipGetLastError();
+}
+
+static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
+                                 float* scratch, hipStream_t s)
+{
+    const int nb = host_num_basis(kind);
+    dim3 block(256), grid((a.cols + 255) / 256, a.rows);
+    for (int p = 0; p < nb; ++p) {
+        int ix, iy;
+        host_basis_taps(kind, p, &ix, &iy);
+        TapVec kx, ky;
+        for (int i = 0; i < 2 * width + 1; ++i) { kx.k[i] = taps[ix][i]; ky.k[i] = taps[iy][i]; }
+        hipLaunchKernelGGL(k_rowpass_generic, grid, block, 0, s, a.in, a.in_pitch, a.rows, a.cols, scratch, a.pitch, kx, width);
+        hipLaunchKernelGGL(k_colpass_generic, grid, block, 0, s, (const float*)scratch, a.pitch, a.rows, a.cols,
+                           a.basis + (size_t)p * a.plane_stride, a.pitch, ky, width);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // epilogues as separate pointwise passes
+    if (a.orient && kind == 2) {
+        PointArgs pa{};
+        pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode;
+        for (int p = 0; p < 7; ++p) pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch};
+        for (int i = 0; i < 5; ++i) pa.out[i] = {a.orient + (size_t)i * a.plane_stride, a.pitch};
+        e = launch_point(OP_G2_ORIENT, pa, s);
+        if (e != hipSuccess) return e;
+    }
+    if (a.steer_g && a.steer_h) {
+        PointArgs pa{};
+        pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode;
+        for (int p = 0; p < nb; ++p) { pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch}; pa.w[p] = a.steer_w[p]; }
+        pa.out[0] = {a.steer_g, a.steer_g_pitch};
+        pa.out[1] = {a.steer_h, a.steer_h_pitch};
+        e = launch_point(kind == 2 ? OP_G2_STEER_SCALAR : OP_G4_STEER_SCALAR, pa, s);
+    }
+    return e;
+}
+
+hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
+                        float* scratch, hipStream_t s)
+{
+    if (kind == 2 && width == BankG2::W) {
+        Folded<BankG2> f;
+        if (fold_taps<BankG2>(taps, f)) return launch_fast<BankG2>(a, f, s);
+    }
+    if (kind == 4 && width == BankG4::W) {
+        Folded<BankG4> f;
+        if (fold_taps<BankG4>(taps, f)) return launch_fast<BankG4>(a, f, s);
+    }
+    return launch_generic(kind, width, taps, a, scratch, s);
+}
+
+}  // namespace cvs

@@ -1,0 +1,255 @@
+// cvs_kernels_point.hip -- "K2..K5": the per-pixel stages of the cvsteer hot path for gfx950.
+//
+// Each reference stage is a chain of full-image OpenCV temporaries (cv::Mat::mul, MatExpr,
+// cartToPolar, polarToCart, compare/copyTo ...).  Here every stage is ONE streaming pass:
+// read each needed plane once (16 B per lane when rows are 16-B aligned), do the whole
+// per-pixel expression in registers, write each requested output once.  All are HBM-bound.
+// This file is built with -ffp-contract=off: products and sums round separately, like the
+// reference's separate cv::Mat nodes.
+//
+//   OP_G2_ORIENT        SteerableFiltersG2.cpp:70-99
+//   OP_G2_STEER_SCALAR  SteerableFiltersG2.cpp:137-145, 157-165
+//   OP_G2_STEER_MAP     SteerableFiltersG2.cpp:147-155, 167-177
+//   OP_G4_STEER_SCALAR  SteerableFiltersG4.cpp:114-122
+//   OP_G4_STEER_MAP     SteerableFiltersG4.cpp:92-112
+//   OP_MAG_PHASE        SteerableFiltersG2.cpp:107-112
+//   OP_PHASE_WEIGHTS    SteerableFiltersG2.cpp:179-186
+//   OP_FIND             SteerableFiltersG2.cpp:194-212 (three maps in one pass)
+//   OP_G2_PIPELINE      test/test.cpp:86-90 / example/steer.cpp:87-90 in one pass
+#include <hip/hip_runtime.h>
+
+#include "cvs_device_math.h"
+#include "cvs_internal.h"
+
+namespace cvs {
+
+template <PointOp OP> struct OpShape;
+template <> struct OpShape<OP_G2_ORIENT> { static constexpr int NIN = 7, NOUT = 5; };
+template <> struct OpShape<OP_G2_STEER_SCALAR> { static constexpr int NIN = 10, NOUT = 5; };  // 7 basis, c1..c3
+template <> struct OpShape<OP_G2_STEER_MAP> { static constexpr int NIN = 11, NOUT = 5; };     // 7 basis, c1..c3, theta
+template <> struct OpShape<OP_G4_STEER_SCALAR> { static constexpr int NIN = 11, NOUT = 2; };
+template <> struct OpShape<OP_G4_STEER_MAP> { static constexpr int NIN = 12, NOUT = 2; };     // 11 basis, theta
+template <> struct OpShape<OP_MAG_PHASE> { static constexpr int NIN = 2, NOUT = 2; };
+template <> struct OpShape<OP_PHASE_WEIGHTS> { static constexpr int NIN = 1, NOUT = 1; };
+template <> struct OpShape<OP_FIND> { static constexpr int NIN = 2, NOUT = 3; };
+template <> struct OpShape<OP_G2_PIPELINE> { static constexpr int NIN = 11, NOUT = 8; };      // 7 basis, c1..c3, theta
+
+// one pixel.  in[] / out[] follow the OpShape order; `need_*` are wave-uniform.
+template <PointOp OP>
+__device__ __forceinline__ void point_eval(const float* in, float* out, const PointArgs& a, bool need_e, bool need_mp)
+{
+    if constexpr (OP == OP_G2_ORIENT) {
+        g2_orientation(in, a.atan_mode, out[0], out[1], out[2], out[3], out[4]);
+    } else if constexpr (OP == OP_G2_STEER_SCALAR) {
+        g2_steer_weights(in, a.w, out[0], out[1]);
+        if (need_e) out[2] = __fadd_rn(__fadd_rn(in[7], __fmul_rn(a.c2t, in[8])), __fmul_rn(a.s2t, in[9]));
+        if (need_mp) mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
+    } else if constexpr (OP == OP_G2_STEER_MAP) {
+        const float th = in[10];
+        g2_steer_angle(in, th, out[0], out[1]);
+        if (need_e) {  // G2.cpp:174-176
+            float s2, c2;
+            sincosf(__fmul_rn(th, 2.0f), &s2, &c2);
+            out[2] = __fadd_rn(__fadd_rn(in[7], __fmul_rn(in[8], c2)), __fmul_rn(in[9], s2));
+        }
+        if (need_mp) mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
+    } else if constexpr (OP == OP_G4_STEER_SCALAR) {
+        g4_steer_weights(in, a.w, out[0], out[1]);
+    } else if constexpr (OP == OP_G4_STEER_MAP) {
+        g4_steer_angle(in, in[11], out[0], out[1]);
+    } else if constexpr (OP == OP_MAG_PHASE) {
+        mag_phase(in[0], in[1], a.atan_mode, out[0], out[1]);
+    } else if constexpr (OP == OP_PHASE_WEIGHTS) {
+        out[0] = phase_lambda(in[0], a.phi, a.signum != 0);
+    } else if constexpr (OP == OP_FIND) {
+        out[0] = __fmul_rn(in[0], phase_lambda(in[1], kHalfPiF, false));  // findEdges      G2.cpp:201-204
+        out[1] = __fmul_rn(in[0], phase_lambda(in[1], 0.f, true));        // findDarkLines  G2.cpp:205-208
+        out[2] = __fmul_rn(in[0], phase_lambda(in[1], kPiF, true));       // findBrightLines G2.cpp:209-212
+    } else if constexpr (OP == OP_G2_PIPELINE) {
+        const float th = in[10];
+        g2_steer_angle(in, th, out[0], out[1]);
+        float s2, c2;
+        sincosf(__fmul_rn(th, 2.0f), &s2, &c2);
+        out[2] = __fadd_rn(__fadd_rn(in[7], __fmul_rn(in[8], c2)), __fmul_rn(in[9], s2));
+        mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
+        const float en = a.find_on_e ? out[2] : out[3];
+        out[5] = __fmul_rn(en, phase_lambda(out[4], kHalfPiF, false));
+        out[6] = __fmul_rn(en, phase_lambda(out[4], 0.f, true));
+        out[7] = __fmul_rn(en, phase_lambda(out[4], kPiF, true));
+    }
+}
+
+// VEC = 4: rows are walked in float4 units (host guarantees 16-B aligned pointers/pitches and
+// cols % 4 == 0); VEC = 1: plain dwords.  blockIdx.y strides rows, x threads stride columns.
+template <PointOp OP, int VEC>
+__global__ __launch_bounds__(256) void k_point(const PointArgs a)
+{
+    constexpr int NIN = OpShape<OP>::NIN, NOUT = OpShape<OP>::NOUT;
+    const int ncv = a.cols / VEC;
+    // wave-uniform "is this optional stage requested" flags
+    bool need_e = false, need_mp = false;
+    if constexpr (OP == OP_G2_STEER_SCALAR || OP == OP_G2_STEER_MAP) {
+        need_e = a.out[2].p != nullptr;
+        need_mp = a.out[3].p != nullptr || a.out[4].p != nullptr;
+    }
+    for (int row = blockIdx.y; row < a.rows; row += gridDim.y) {
+        for (int cv = blockIdx.x * blockDim.x + threadIdx.x; cv < ncv; cv += gridDim.x * blockDim.x) {
+            float vin[NIN][VEC];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                if (a.in[i].p) {
+                    const float* src = a.in[i].p + (size_t)row * a.in[i].pitch + (size_t)cv * VEC;
+                    if constexpr (VEC == 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(src);
+                        vin[i][0] = v.x; vin[i][1] = v.y; vin[i][2] = v.z; vin[i][3] = v.w;
+                    } else {
+                        vin[i][0] = *src;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) vin[i][k] = 0.f;
+                }
+            }
+            float vout[NOUT][VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float pin[NIN], pout[NOUT];
+#pragma unroll
+                for (int i = 0; i < NIN; ++i) pin[i] = vin[i][k];
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) pout[o] = 0.f;
+                point_eval<OP>(pin, pout, a, need_e, need_mp);
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) vout[o][k] = pout[o];
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                if (a.out[o].p) {
+                    float* dst = a.out[o].p + (size_t)row * a.out[o].pitch + (size_t)cv * VEC;
+                    if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(vout[o][0], vout[o][1], vout[o][2], vout[o][3]);
+                    else *dst = vout[o][0];
+                }
+            }
+        }
+    }
+}
+
+static bool vec4_ok(const PointArgs& a, int nin, int nout)
+{
+    if (a.cols % 4) return false;
+    for (int i = 0; i < nin; ++i)
+        if (a.in[i].p && (((uintptr_t)a.in[i].p & 15) || (a.in[i].pitch & 3))) return false;
+    for (int o = 0; o < nout; ++o)
+        if (a.out[o].p && (((uintptr_t)a.out[o].p & 15) || (a.out[o].pitch & 3))) return false;
+    return true;
+}
+
+template <PointOp OP>
+static hipError_t launch_op(const PointArgs& a, hipStream_t s)
+{
+    constexpr int NIN = OpShape<OP>::NIN, NOUT = OpShape<OP>::NOUT;
+    const bool v4 = vec4_ok(a, NIN, NOUT);
+    const int ncv = v4 ? a.cols / 4 : a.cols;
+    dim3 block(256);
+    int gx = (ncv + 255) / 256;
+    if (gx > 64) gx = 64;
+    int gy = a.rows;
+    const int cap = 256 * 16;  // ~16 workgroups per CU, then stride
+    if ((long)gx * gy > cap) gy = cap / gx > 0 ? cap / gx : 1;
+    dim3 grid(gx, gy);
+    if (v4) hipLaunchKernelGGL((k_point<OP, 4>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_point<OP, 1>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_point(PointOp op, const PointArgs& a, hipStream_t s)
+{
+    if (a.rows <= 0 || a.cols <= 0) return hipErrorInvalidValue;
+    switch (op) {
+        case OP_G2_ORIENT: return launch_op<OP_G2_ORIENT>(a, s);
+        case OP_G2_STEER_SCALAR: return launch_op<OP_G2_STEER_SCALAR>(a, s);
+        case OP_G2_STEER_MAP: return launch_op<OP_G2_STEER_MAP>(a, s);
+        case OP_G4_STEER_SCALAR: return launch_op<OP_G4_STEER_SCALAR>(a, s);
+        case OP_G4_STEER_MAP: return launch_op<OP_G4_STEER_MAP>(a, s);
+        case OP_MAG_PHASE: return launch_op<OP_MAG_PHASE>(a, s);
+        case OP_PHASE_WEIGHTS: return launch_op<OP_PHASE_WEIGHTS>(a, s);
+        case OP_FIND: return launch_op<OP_FIND>(a, s);
+        case OP_G2_PIPELINE: return launch_op<OP_G2_PIPELINE>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------
+// cv::normalize(src, dst, 0, 255, NORM_MINMAX, CV_8UC1)  (test/test.cpp:92-94,
+// example/steer.cpp:96-98): per-image min/max, then saturate_cast<uchar>(v*scale + shift).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int float_key(float v)
+{
+    const int b = __float_as_int(v);
+    return b >= 0 ? b : b ^ 0x7fffffff;  // monotone map float -> int
+}
+__device__ __forceinline__ float key_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+__global__ void k_minmax_init(int* mm)
+{
+    mm[0] = 0x7fffffff;
+    mm[1] = (int)0x80000000;
+}
+
+__global__ __launch_bounds__(256) void k_minmax(const float* src, size_t pitch, int rows, int cols, int* mm)
+{
+    float lo = INFINITY, hi = -INFINITY;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+            const float v = src[(size_t)row * pitch + c];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], float_key(lo));
+        atomicMax(&mm[1], float_key(hi));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_quantize_u8(const float* src, size_t pitch, int rows, int cols,
+                                                      const int* mm, uint8_t* dst, size_t dst_step)
+{
+    const float lo = key_float(mm[0]), hi = key_float(mm[1]);
+    const double d = (double)hi - (double)lo;
+    const double scale_d = d > 2.2204460492503131e-16 ? 255.0 / d : 0.0;
+    const float scale = (float)scale_d, shift = (float)(-(double)lo * scale_d);
+    for (int row = blockIdx.y; row < rows; row += gridDim.y)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+            const float v = __fadd_rn(__fmul_rn(src[(size_t)row * pitch + c], scale), shift);
+            int q = __float2int_rn(v);  // cvRound: half to even
+            q = q < 0 ? 0 : q > 255 ? 255 : q;
+            dst[(size_t)row * dst_step + c] = (uint8_t)q;
+        }
+}
+
+hipError_t launch_minmax(const float* src, size_t pitch, int rows, int cols, float* minmax2, hipStream_t s)
+{
+    int* mm = reinterpret_cast<int*>(minmax2);
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, s, mm);
+    int gx = (cols + 255) / 256; if (gx > 16) gx = 16;
+    int gy = rows > 256 ? 256 : rows;
+    hipLaunchKernelGGL(k_minmax, dim3(gx, gy), dim3(256), 0, s, src, pitch, rows, cols, mm);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_u8(const float* src, size_t pitch, int rows, int cols, const float* minmax2,
+                              uint8_t* dst, size_t dst_step, hipStream_t s)
+{
+    int gx = (cols + 255) / 256; if (gx > 16) gx = 16;
+    int gy = rows > 256 ? 256 : rows;
+    hipLaunchKernelGGL(k_quantize_u8, dim3(gx, gy), dim3(256), 0, s, src, pitch, rows, cols,
+                       reinterpret_cast<const int*>(minmax2), dst, dst_step);
+    return hipGetLastError();
+}
+
+}  // namespace cvs

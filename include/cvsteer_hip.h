@@ -1,0 +1,169 @@
+/*
+ * cvsteer_hip.h -- C ABI of libcvsteer_hip.so: the MI355X (gfx950) engine behind the
+ * fa::SteerableFilters / SteerableFiltersG2 / SteerableFiltersG4 classes of
+ * headupinclouds/cvsteer.
+ *
+ * The reference has no FFI layer: its boundary is the C++ class surface
+ * (cvsteer/SteerableFilters.h:41-50, SteerableFiltersG2.h:35-67, SteerableFiltersG4.h:35-57)
+ * and every arithmetic step is an OpenCV call.  Each entry point below names the reference
+ * member function (file:line) whose work it replaces.  The C++ facade in
+ * the include/cvsteer/ headers keep the reference's class/method names on top of this ABI;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns an int status (CVS_OK = 0, negative = error); nothing throws.
+ *  - images are `cvs_plane`: row-major f32, `step` bytes between rows (multiple of 4,
+ *    >= cols*4), living in host memory (CVS_MEM_HOST) or in the handle's device
+ *    (CVS_MEM_DEVICE).  cv::Mat1f maps 1:1: {(float*)m.data, m.rows, m.cols, m.step}.
+ *  - a handle owns its state planes (basis, C1..C3, theta, strength) in device memory;
+ *    callers own every plane they pass in.  State stays valid until the next cvs_setup.
+ *  - all device work is enqueued on the handle's HIP stream (default: the null stream;
+ *    cvs_set_stream to share e.g. PyTorch's current stream).  Calls with only DEVICE planes
+ *    are asynchronous; calls that touch a HOST plane return after the data has landed.
+ *  - a handle is not re-entrant; different handles may be used from different threads.
+ *  - there is no CPU fallback: without a usable HIP device cvs_create fails with CVS_E_HIP.
+ */
+#ifndef CVSTEER_HIP_H
+#define CVSTEER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVS_ABI_VERSION 1
+
+/* status codes */
+enum {
+    CVS_OK = 0,
+    CVS_E_BADARG = -1,      /* null pointer, unknown enum, bad index */
+    CVS_E_SIZE = -2,        /* empty image, mismatched plane sizes, bad step */
+    CVS_E_HIP = -3,         /* HIP runtime error (see cvs_last_error) */
+    CVS_E_NOMEM = -4,       /* device or host allocation failed */
+    CVS_E_STATE = -5,       /* state not available (no setup yet / orientation not computed) */
+    CVS_E_UNSUPPORTED = -6  /* operation the reference does not define for this kind */
+};
+
+enum { CVS_KIND_G2 = 2, CVS_KIND_G4 = 4 };
+enum { CVS_MEM_HOST = 0, CVS_MEM_DEVICE = 1 };
+
+/* cvs_setup flags */
+enum {
+    CVS_SETUP_BASIS = 1u,   /* the 7 (G2) / 11 (G4) separable basis planes */
+    CVS_SETUP_ORIENT = 2u,  /* + C1,C2,C3, dominant angle, strength (G2 only) */
+    CVS_SETUP_FULL = 3u
+};
+
+/* options for cvs_set_option */
+enum {
+    CVS_OPT_ATAN_MODE = 1,   /* 0 = OpenCV-compatible fastAtan2 polynomial (default), 1 = exact atan2f */
+    CVS_OPT_STRIP_ROWS = 2,  /* rows per wave strip of the basis kernel (tuning; 0 = default) */
+    CVS_OPT_FIND_ON = 3      /* cvs_pipeline: 0 = find*(magnitude, phase) as the reference's callers do
+                                (test/test.cpp:88-90), 1 = find*(e, phase) */
+};
+
+/* state planes addressable through cvs_state_plane / cvs_read_state */
+enum {
+    CVS_PLANE_BASIS0 = 0,    /* + p, p < cvs_num_basis(kind): m_g2a..m_h2d / m_g4a..m_h4f */
+    CVS_PLANE_C1 = 32, CVS_PLANE_C2 = 33, CVS_PLANE_C3 = 34,
+    CVS_PLANE_THETA = 35,    /* getDominantOrientationAngle()    */
+    CVS_PLANE_STRENGTH = 36  /* getDominantOrientationStrength() */
+};
+
+typedef struct cvs_plane {
+    float* data;
+    int32_t rows;
+    int32_t cols;
+    size_t step;   /* bytes */
+    int32_t mem;   /* CVS_MEM_HOST | CVS_MEM_DEVICE */
+} cvs_plane;
+
+typedef struct cvs_context* cvs_handle;
+
+/* ---------------- library / host-only helpers (no GPU needed) ---------------- */
+int cvs_abi_version(void);
+const char* cvs_status_string(int status);
+/* number of 1-D tap vectors == number of basis planes: 7 (G2), 11 (G4) */
+int cvs_num_basis(int kind);
+/* SteerableFilters::create (SteerableFilters.cpp:33-42) applied to the idx-th tap function
+ * (SteerableFiltersG2.cpp:35-42 order m_g1,m_g2,m_g3,m_h1..m_h4; SteerableFiltersG4.cpp:34-45
+ * order m_g1..m_g5,m_h1..m_h6).  out: 2*width+1 floats. */
+int cvs_make_taps(int kind, int idx, int width, float spacing, float* out);
+/* which taps build basis plane p: sepFilter2D(image, kx=taps[*kx], ky=taps[*ky])
+ * (SteerableFiltersG2.cpp:62-68, SteerableFiltersG4.cpp:69-80) */
+int cvs_basis_taps(int kind, int p, int* kx, int* ky);
+/* scalar steering weights for theta (SteerableFiltersG2.cpp:140-142, G4.cpp:116-119):
+ * out[0..2]=ga,gb,gc out[3..6]=ha..hd (G2) ; out[0..4]=ga..ge out[5..10]=ha..hf (G4) */
+int cvs_steer_weights(int kind, float theta, float* out);
+
+/* ---------------- handle ---------------- */
+/* SteerableFiltersG2::SteerableFiltersG2 / G4 ctor minus setup (G2.cpp:44-56, G4.cpp:47-63):
+ * builds the tap vectors, binds HIP device `device`. */
+int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out);
+int cvs_destroy(cvs_handle h);
+const char* cvs_last_error(cvs_handle h);
+int cvs_set_stream(cvs_handle h, void* hip_stream);
+int cvs_set_option(cvs_handle h, int option, int value);
+int cvs_get_option(cvs_handle h, int option, int* value);
+/* the handle's idx-th tap vector (m_g1.. members), 2*width+1 floats */
+int cvs_taps(cvs_handle h, int idx, float* out);
+int cvs_kind(cvs_handle h, int* kind, int* width, float* spacing);
+/* size of the image of the last cvs_setup (0,0 before) */
+int cvs_shape(cvs_handle h, int* rows, int* cols);
+int cvs_sync(cvs_handle h);
+
+/* ---------------- the hot path ---------------- */
+/* SteerableFiltersG2::setup (G2.cpp:60-100) / SteerableFiltersG4::setup (G4.cpp:67-81).
+ * One fused kernel: the image is read once; the row pass, the column pass and (with
+ * CVS_SETUP_ORIENT) the C1..C3 / cartToPolar / wrap / *0.5 steps run in registers. */
+int cvs_setup(cvs_handle h, const cvs_plane* image, unsigned flags);
+
+/* setup + steer(float theta, g, hq) in the same kernel launch: G2.cpp:60-100 followed by
+ * G2.cpp:137-145 (G4.cpp:67-81 + G4.cpp:114-122).  This is the headline "filter+steer" unit. */
+int cvs_setup_steer(cvs_handle h, const cvs_plane* image, unsigned flags, float theta,
+                    const cvs_plane* g, const cvs_plane* hq);
+
+/* device view of a state plane (zero copy; valid until the next setup) */
+int cvs_state_plane(cvs_handle h, int which, cvs_plane* view);
+/* copy a state plane out (getDominantOrientationAngle()/Strength() getters, G2.h:40-41,
+ * and the protected m_g2a.. members for tests) */
+int cvs_read_state(cvs_handle h, int which, const cvs_plane* dst);
+
+/* steer(float theta, g2, h2) G2.cpp:137-145 / G4.cpp:114-122; with e, mag, phase non-NULL:
+ * steer(float theta, g2, h2, e, magnitude, phase) G2.cpp:157-165.  G4: e/mag/phase must be NULL. */
+int cvs_steer_scalar(cvs_handle h, float theta, const cvs_plane* g, const cvs_plane* hq,
+                     const cvs_plane* e, const cvs_plane* mag, const cvs_plane* phase);
+/* steer(const Mat1f& theta, ...) G2.cpp:147-155, :167-177 / G4.cpp:92-112.
+ * theta == NULL steers at the handle's own dominant-orientation plane (what both reference
+ * callers do: test/test.cpp:86, example/steer.cpp:87). */
+int cvs_steer_map(cvs_handle h, const cvs_plane* theta, const cvs_plane* g, const cvs_plane* hq,
+                  const cvs_plane* e, const cvs_plane* mag, const cvs_plane* phase);
+/* steer(const cv::Point& p, theta, g2, h2, e, magnitude, phase) G2.cpp:115-134 (p.x=col, p.y=row).
+ * out = {g2, h2, e, magnitude, phase}; e is NaN when orientation state is absent. */
+int cvs_steer_point(cvs_handle h, int x, int y, float theta, float out[5]);
+
+/* computeMagnitudeAndPhase G2.cpp:107-112 (cartToPolar, wrap, patchNaNs) */
+int cvs_mag_phase(cvs_handle h, const cvs_plane* g, const cvs_plane* hq,
+                  const cvs_plane* mag, const cvs_plane* phase);
+/* static phaseWeights G2.cpp:179-186 (k accepted and ignored, like the reference) */
+int cvs_phase_weights(cvs_handle h, const cvs_plane* phase, const cvs_plane* lambda,
+                      float phi, int signum, float k);
+/* findEdges / findDarkLines / findBrightLines G2.cpp:194-212 in one pass; any output may be NULL */
+int cvs_find(cvs_handle h, const cvs_plane* e, const cvs_plane* phase,
+             const cvs_plane* edges, const cvs_plane* dark, const cvs_plane* bright);
+
+/* the whole caller sequence of test/test.cpp:85-90 / example/steer.cpp:86-90 for one image:
+ * setup(FULL) -> steer(theta_dom, g2,h2,e,mag,phase) -> find*(mag|e, phase).
+ * outs[8] = {g2, h2, e, magnitude, phase, edges, dark, bright}; any entry may be NULL. */
+int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const outs[8]);
+
+/* per-image min/max (cv::normalize NORM_MINMAX, test.cpp:92-94 / steer.cpp:96-98) and the
+ * 8-bit quantise that follows; dst is rows*cols bytes with dst_step bytes per row. */
+int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVSTEER_HIP_H */
