@@ -61,13 +61,15 @@ def steer_weights(kind, theta):
 def _plane(a):
     """cvs_plane view of a 2-D float32 numpy array or torch CUDA tensor (no copy)."""
     if _is_torch(a):
-        if a.dtype != torch.float32 or a.dim() != 2 or (a.shape[1] > 1 and a.stride(1) != 1):
+        if a.dtype != torch.float32 or a.dim() != 2 or (a.numel() and a.shape[1] > 1 and a.stride(1) != 1):
             raise ValueError("torch plane must be 2-D float32 with unit column stride")
         mem = L.MEM_DEVICE if a.is_cuda else L.MEM_HOST
         return Plane(a.data_ptr(), a.shape[0], a.shape[1], a.stride(0) * 4 if a.shape[0] > 1 else a.shape[1] * 4, mem)
-    if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.ndim != 2 or (a.shape[1] > 1 and a.strides[1] != 4):
-        raise ValueError("numpy plane must be 2-D float32 with unit column stride")
-    step = a.strides[0] if a.shape[0] > 1 else a.shape[1] * 4
+    if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.ndim != 2:
+        raise ValueError("numpy plane must be 2-D float32")
+    if a.size and a.shape[1] > 1 and a.strides[1] != 4:
+        raise ValueError("numpy plane must have unit column stride")
+    step = a.strides[0] if (a.shape[0] > 1 and a.size) else a.shape[1] * 4
     return Plane(a.ctypes.data, a.shape[0], a.shape[1], step, L.MEM_HOST)
 
 

@@ -35,7 +35,7 @@ struct cvs_context {
     float* arena = nullptr;
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
-    int atan_mode = 0, strip_rows = 0, find_on = 0;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0;
     std::string err;
 };
 
@@ -63,8 +63,9 @@ size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 int check_plane(cvs_handle h, const cvs_plane* p, const char* name)
 {
-    if (!p || !p->data) return fail(h, CVS_E_BADARG, name);
+    if (!p) return fail(h, CVS_E_BADARG, name);
     if (p->rows <= 0 || p->cols <= 0) return fail(h, CVS_E_SIZE, "empty plane");
+    if (!p->data) return fail(h, CVS_E_BADARG, name);
     if (p->step < (size_t)p->cols * sizeof(float) || p->step % sizeof(float)) return fail(h, CVS_E_SIZE, "bad step");
     if (p->mem != CVS_MEM_HOST && p->mem != CVS_MEM_DEVICE) return fail(h, CVS_E_BADARG, "bad mem kind");
     return CVS_OK;
@@ -205,15 +206,31 @@ int ensure_state(cvs_handle h, int rows, int cols)
 int default_strip_rows(cvs_handle h, int rows, int cols)
 {
     if (h->strip_rows > 0) return h->strip_rows;
-    // strips whose (rows + 2W) is a multiple of the 2W+1-row unroll waste no loop iterations;
-    // aim for >= ~2048 waves so all 256 CUs hold several.
+    // strips whose (rows + 2W) is a multiple of the 2W+1-row unroll waste no loop iterations.
+    // Measured on MI355X at 4096x4096 (tools/tune.py, streaming stores): the 7-plane G2 kernel is
+    // fastest with short strips (10-19 rows: ~14k waves keep every CU's store queues busy and the
+    // extra halo rows are L2 hits); the register-heavy 11-plane G4 kernel (2 waves/SIMD) prefers
+    // long strips (~131 rows) that amortise its 12 halo rows of row-pass work.
     const int nt = 2 * h->width + 1, halo = 2 * h->width;
     const long strips_x = (cols + 63) / 64;
     const double ideal = (double)rows * (double)strips_x / 2048.0;
     long k = std::lround((ideal + halo) / nt);
+    const long kmax = h->kind == CVS_KIND_G2 ? 3 : 11;
     if (k < 2) k = 2;
-    if (k > 8) k = 8;
+    if (k > kmax) k = kmax;
     return (int)(k * nt - halo);
+}
+
+// Streaming (nontemporal) stores: measured on MI355X (tools/membench.hip), "1 plane in, 7 out"
+// reaches ~5.9 TB/s with nt stores vs ~4.0 TB/s with plain stores once the planes no longer fit
+// the 256 MiB Infinity Cache.  Small frames whose whole state stays cache-resident keep plain
+// stores so the next per-pixel kernel finds them on die.
+int use_nt_stores(cvs_handle h, size_t npix)
+{
+    if (h->store_policy == 1) return 0;
+    if (h->store_policy == 2) return 1;
+    const size_t state_bytes = npix * sizeof(float) * (size_t)(h->nb + 5);
+    return state_bytes > (size_t)96 << 20;
 }
 
 int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, float theta, const cvs_plane* g,
@@ -251,6 +268,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.orient = (flags & CVS_SETUP_ORIENT) ? state_plane(h, h->nb) : nullptr;
     a.atan_mode = h->atan_mode;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols);
+    a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     if (steer) {
         PlaneRef rg, rh;
         if ((rc = out_ref(c, g, rg)) || (rc = out_ref(c, hq, rh))) return rc;
@@ -326,6 +344,7 @@ int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map
         if ((rc = out_ref(c, outs[o], a.out[o]))) return rc;
     PointOp op = h->kind == CVS_KIND_G2 ? (map ? OP_G2_STEER_MAP : OP_G2_STEER_SCALAR)
                                         : (map ? OP_G4_STEER_MAP : OP_G4_STEER_SCALAR);
+    a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     HIP_TRY(h, launch_point(op, a, h->stream));
     return finish(c);
 }
@@ -425,6 +444,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "find_on");
             h->find_on = value;
             return CVS_OK;
+        case CVS_OPT_STORE_POLICY:
+            if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "store policy");
+            h->store_policy = value;
+            return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -436,6 +459,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_ATAN_MODE: *value = h->atan_mode; return CVS_OK;
         case CVS_OPT_STRIP_ROWS: *value = h->strip_rows; return CVS_OK;
         case CVS_OPT_FIND_ON: *value = h->find_on; return CVS_OK;
+        case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -581,6 +605,7 @@ int cvs_mag_phase(cvs_handle h, const cvs_plane* g, const cvs_plane* hq, const c
     a.atan_mode = h->atan_mode;
     if ((rc = in_ref(c, g, a.in[0])) || (rc = in_ref(c, hq, a.in[1]))) return rc;
     if ((rc = out_ref(c, mag, a.out[0])) || (rc = out_ref(c, phase, a.out[1]))) return rc;
+    a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     HIP_TRY(h, launch_point(OP_MAG_PHASE, a, h->stream));
     return finish(c);
 }
@@ -600,6 +625,7 @@ int cvs_phase_weights(cvs_handle h, const cvs_plane* phase, const cvs_plane* lam
     a.phi = phi;
     a.signum = signum ? 1 : 0;
     if ((rc = in_ref(c, phase, a.in[0])) || (rc = out_ref(c, lambda, a.out[0]))) return rc;
+    a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     HIP_TRY(h, launch_point(OP_PHASE_WEIGHTS, a, h->stream));
     return finish(c);
 }
@@ -622,6 +648,7 @@ int cvs_find(cvs_handle h, const cvs_plane* e, const cvs_plane* phase, const cvs
     a.cols = e->cols;
     if ((rc = in_ref(c, e, a.in[0])) || (rc = in_ref(c, phase, a.in[1]))) return rc;
     if ((rc = out_ref(c, edges, a.out[0])) || (rc = out_ref(c, dark, a.out[1])) || (rc = out_ref(c, bright, a.out[2]))) return rc;
+    a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     HIP_TRY(h, launch_point(OP_FIND, a, h->stream));
     return finish(c);
 }
@@ -649,6 +676,7 @@ int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const ou
     a.in[10] = {state_plane(h, h->nb + 3), h->pitch};
     for (int o = 0; o < 8; ++o)
         if ((rc = out_ref(c, outs[o], a.out[o]))) return rc;
+    a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     HIP_TRY(h, launch_point(OP_G2_PIPELINE, a, h->stream));
     return finish(c);
 }

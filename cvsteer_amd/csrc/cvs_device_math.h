@@ -1,5 +1,7 @@
 // cvs_device_math.h -- per-pixel device helpers shared by the basis and pointwise kernels.
 // gfx950 only.  Every helper states which reference / OpenCV step it stands for.
+// Both kernel translation units are built with -ffp-contract=off, so each __f*_rn / operator
+// below is one separately rounded f32 operation (HIP's __fmul_rn is a plain '*').
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,7 +24,7 @@ __host__ __device__ inline int reflect101(int p, int len)
 
 // cv::cartToPolar's angle (radians, [0, 2pi)).
 // mode 0: the OpenCV 3.4 fastAtan2 polynomial in degrees, every op separately rounded
-// (__f*_rn are never contracted), then * (float)(pi/180).  mode 1: atan2f.
+// (contraction is off), then * (float)(pi/180).  mode 1: atan2f.
 __device__ inline float angle_0_2pi(float y, float x, int mode)
 {
     if (mode == 0) {

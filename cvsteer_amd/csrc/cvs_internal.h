@@ -27,6 +27,7 @@ struct BasisArgs {
     float steer_w[kMaxBasis];  // scalar steering weights (host-computed)
     int strip_rows;       // output rows per wave strip
     int atan_mode;
+    int nt_stores;        // 1 = nontemporal (streaming) output stores
 };
 
 // taps[i] = the handle's i-th tap vector (member order), 2*width+1 floats each
@@ -67,6 +68,7 @@ struct PointArgs {
     int signum;
     int atan_mode;
     int find_on_e;        // pipeline: 1 = find*(e, phase), 0 = find*(magnitude, phase)
+    int nt_stores;        // 1 = nontemporal (streaming) output stores
 };
 
 hipError_t launch_point(PointOp op, const PointArgs& a, hipStream_t s);

@@ -67,7 +67,15 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <class B, int FLAGS>
+// output store: STREAM = nontemporal streaming store (bypasses cache allocation; see cvs_api.cpp use_nt_stores)
+template <bool STREAM>
+__device__ __forceinline__ void put(float* p, float v)
+{
+    if constexpr (STREAM) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <class B, int FLAGS, bool STREAM>
 __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B> t)
 {
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
@@ -171,23 +179,23 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
                 if (xin) {
                     float* orow = a.basis + (size_t)yout * a.pitch;
 #pragma unroll
-                    for (int p = 0; p < NB; ++p) orow[(size_t)p * a.plane_stride + x] = b[p];
+                    for (int p = 0; p < NB; ++p) put<STREAM>(orow + (size_t)p * a.plane_stride + x, b[p]);
                     if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
                         float c1, c2, c3, th, st;
                         g2_orientation(b, a.atan_mode, c1, c2, c3, th, st);
                         float* o = a.orient + (size_t)yout * a.pitch + x;
-                        o[0] = c1;
-                        o[a.plane_stride] = c2;
-                        o[2 * a.plane_stride] = c3;
-                        o[3 * a.plane_stride] = th;
-                        o[4 * a.plane_stride] = st;
+                        put<STREAM>(o, c1);
+                        put<STREAM>(o + a.plane_stride, c2);
+                        put<STREAM>(o + 2 * a.plane_stride, c3);
+                        put<STREAM>(o + 3 * a.plane_stride, th);
+                        put<STREAM>(o + 4 * a.plane_stride, st);
                     }
                     if constexpr ((FLAGS & F_STEER) != 0) {
                         float gq, hq;
                         if constexpr (B::KIND == 2) g2_steer_weights(b, a.steer_w, gq, hq);
                         else g4_steer_weights(b, a.steer_w, gq, hq);
-                        a.steer_g[(size_t)yout * a.steer_g_pitch + x] = gq;
-                        a.steer_h[(size_t)yout * a.steer_h_pitch + x] = hq;
+                        put<STREAM>(a.steer_g + (size_t)yout * a.steer_g_pitch + x, gq);
+                        put<STREAM>(a.steer_h + (size_t)yout * a.steer_h_pitch + x, hq);
                     }
                 }
             }
@@ -281,10 +289,19 @@ static hipError_t launch_fast(const BasisArgs& a, const Folded<B>& f, hipStream_
     dim3 block(256);
     const bool orient = a.orient != nullptr && B::KIND == 2;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
-    if (orient && steer) hipLaunchKernelGGL((k_basis<B, F_ORIENT | F_STEER>), grid, block, 0, s, a, f);
-    else if (orient) hipLaunchKernelGGL((k_basis<B, F_ORIENT>), grid, block, 0, s, a, f);
-    else if (steer) hipLaunchKernelGGL((k_basis<B, F_STEER>), grid, block, 0, s, a, f);
-    else hipLaunchKernelGGL((k_basis<B, 0>), grid, block, 0, s, a, f);
+    const int flags = (orient ? F_ORIENT : 0) | (steer ? F_STEER : 0);
+#define CVS_LAUNCH(FL)                                                                         \
+    do {                                                                                       \
+        if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true>), grid, block, 0, s, a, f);  \
+        else hipLaunchKernelGGL((k_basis<B, FL, false>), grid, block, 0, s, a, f);             \
+    } while (0)
+    switch (flags) {
+        case 0: CVS_LAUNCH(0); break;
+        case F_ORIENT: CVS_LAUNCH(F_ORIENT); break;
+        case F_STEER: CVS_LAUNCH(F_STEER); break;
+        default: CVS_LAUNCH(F_ORIENT | F_STEER); break;
+    }
+#undef CVS_LAUNCH
     return hipGetLastError();
 }
 
@@ -307,7 +324,7 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
     // epilogues as separate pointwise passes
     if (a.orient && kind == 2) {
         PointArgs pa{};
-        pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode;
+        pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
         for (int p = 0; p < 7; ++p) pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch};
         for (int i = 0; i < 5; ++i) pa.out[i] = {a.orient + (size_t)i * a.plane_stride, a.pitch};
         e = launch_point(OP_G2_ORIENT, pa, s);
@@ -315,7 +332,7 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
     }
     if (a.steer_g && a.steer_h) {
         PointArgs pa{};
-        pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode;
+        pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
         for (int p = 0; p < nb; ++p) { pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch}; pa.w[p] = a.steer_w[p]; }
         pa.out[0] = {a.steer_g, a.steer_g_pitch};
         pa.out[1] = {a.steer_h, a.steer_h_pitch};

@@ -81,7 +81,7 @@ __device__ __forceinline__ void point_eval(const float* in, float* out, const Po
 
 // VEC = 4: rows are walked in float4 units (host guarantees 16-B aligned pointers/pitches and
 // cols % 4 == 0); VEC = 1: plain dwords.  blockIdx.y strides rows, x threads stride columns.
-template <PointOp OP, int VEC>
+template <PointOp OP, int VEC, bool NT>
 __global__ __launch_bounds__(256) void k_point(const PointArgs a)
 {
     constexpr int NIN = OpShape<OP>::NIN, NOUT = OpShape<OP>::NOUT;
@@ -126,8 +126,15 @@ __global__ __launch_bounds__(256) void k_point(const PointArgs a)
             for (int o = 0; o < NOUT; ++o) {
                 if (a.out[o].p) {
                     float* dst = a.out[o].p + (size_t)row * a.out[o].pitch + (size_t)cv * VEC;
-                    if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(vout[o][0], vout[o][1], vout[o][2], vout[o][3]);
-                    else *dst = vout[o][0];
+                    if constexpr (VEC == 4) {
+                        typedef float f4 __attribute__((ext_vector_type(4)));
+                        const f4 v = {vout[o][0], vout[o][1], vout[o][2], vout[o][3]};
+                        if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+                        else *reinterpret_cast<f4*>(dst) = v;
+                    } else {
+                        if constexpr (NT) __builtin_nontemporal_store(vout[o][0], dst);
+                        else *dst = vout[o][0];
+                    }
                 }
             }
         }
@@ -157,8 +164,10 @@ static hipError_t launch_op(const PointArgs& a, hipStream_t s)
     const int cap = 256 * 16;  // ~16 workgroups per CU, then stride
     if ((long)gx * gy > cap) gy = cap / gx > 0 ? cap / gx : 1;
     dim3 grid(gx, gy);
-    if (v4) hipLaunchKernelGGL((k_point<OP, 4>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_point<OP, 1>), grid, block, 0, s, a);
+    if (v4 && a.nt_stores) hipLaunchKernelGGL((k_point<OP, 4, true>), grid, block, 0, s, a);
+    else if (v4) hipLaunchKernelGGL((k_point<OP, 4, false>), grid, block, 0, s, a);
+    else if (a.nt_stores) hipLaunchKernelGGL((k_point<OP, 1, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_point<OP, 1, false>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

@@ -60,8 +60,10 @@ enum {
 enum {
     CVS_OPT_ATAN_MODE = 1,   /* 0 = OpenCV-compatible fastAtan2 polynomial (default), 1 = exact atan2f */
     CVS_OPT_STRIP_ROWS = 2,  /* rows per wave strip of the basis kernel (tuning; 0 = default) */
-    CVS_OPT_FIND_ON = 3      /* cvs_pipeline: 0 = find*(magnitude, phase) as the reference's callers do
+    CVS_OPT_FIND_ON = 3,     /* cvs_pipeline: 0 = find*(magnitude, phase) as the reference's callers do
                                 (test/test.cpp:88-90), 1 = find*(e, phase) */
+    CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
+                                256 MiB Infinity Cache), 1 = plain, 2 = always nontemporal (tuning) */
 };
 
 /* state planes addressable through cvs_state_plane / cvs_read_state */

@@ -1,0 +1,140 @@
+// membench.hip -- store/load pattern micro-benchmarks for MI355X: what access shape does the
+// HBM system want for "1 plane in, 7 planes out" (the basis kernel's traffic)?
+// Build: hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o tools/membench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+constexpr int N = 4096;          // rows = cols
+constexpr int NP = 7;
+
+// P1: ideal linear streaming: each thread float4, block = 4 KiB contiguous, grid-stride
+__global__ __launch_bounds__(256) void p1_linear(const float4* in, float4* out, size_t n4, size_t plane4)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = in[i];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { float4 w = v; w.x += p; out[p * plane4 + i] = w; }
+    }
+}
+
+// P2: wave marches down a 64-col strip, dword per lane (K1 today). block = 4 adjacent strips.
+template <bool NT>
+__global__ __launch_bounds__(256) void p2_strip(const float* in, float* out, int strip_rows, size_t plane)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = (blockIdx.x * 4 + wv) * 64 + lane;
+    const int y0 = blockIdx.y * strip_rows;
+    for (int y = y0; y < y0 + strip_rows && y < N; ++y) {
+        float v = in[(size_t)y * N + x];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float* d = out + p * plane + (size_t)y * N + x;
+            if (NT) __builtin_nontemporal_store(v + p, d); else *d = v + p;
+        }
+    }
+}
+
+// P3: wave marches down a (64*V)-col strip, V floats per lane (8 or 16 B stores)
+template <int V, bool NT>
+__global__ __launch_bounds__(256) void p3_strip_vec(const float* in, float* out, int strip_rows, size_t plane)
+{
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = ((blockIdx.x * 4 + wv) * 64 + lane) * V;
+    const int y0 = blockIdx.y * strip_rows;
+    for (int y = y0; y < y0 + strip_rows && y < N; ++y) {
+        vec v = *reinterpret_cast<const vec*>(in + (size_t)y * N + x);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            vec w = v; w[0] += p;
+            vec* d = reinterpret_cast<vec*>(out + p * plane + (size_t)y * N + x);
+            if (NT) __builtin_nontemporal_store(w, d); else *d = w;
+        }
+    }
+}
+
+// P4: block of 256 threads covers 256 cols x R rows tile, threads iterate rows; stores dword but the
+// 4 waves write 1 KiB contiguous (same as P2) -- variant: block = 4 waves stacked vertically
+__global__ __launch_bounds__(256) void p4_vert(const float* in, float* out, int strip_rows, size_t plane)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y0 = (blockIdx.y * 4 + wv) * strip_rows;
+    for (int y = y0; y < y0 + strip_rows && y < N; ++y) {
+        float v = in[(size_t)y * N + x];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) out[p * plane + (size_t)y * N + x] = v + p;
+    }
+}
+
+// P5: write-only (no read), strip pattern dword
+__global__ __launch_bounds__(256) void p5_wonly(float* out, int strip_rows, size_t plane)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = (blockIdx.x * 4 + wv) * 64 + lane;
+    const int y0 = blockIdx.y * strip_rows;
+    for (int y = y0; y < y0 + strip_rows && y < N; ++y) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) out[p * plane + (size_t)y * N + x] = (float)(y + p);
+    }
+}
+
+// P6: pure copy float4 (1 in, 1 out)
+__global__ __launch_bounds__(256) void p6_copy(const float4* in, float4* out, size_t n4)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+
+// P7: strip pattern where a wave covers 64 cols but processes RB rows per iteration with lanes
+// remapped so each store instruction writes 4 rows x 64 B?  (worse locality; control)
+// P8: transposed-through-registers: wave owns 256 cols x strip; each lane float4 (=P3<4>)
+
+template <class F>
+static float timeit(F f, int reps = 20)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms / reps;
+}
+
+int main()
+{
+    const size_t plane = (size_t)N * N;
+    float *in, *out;
+    CK(hipMalloc(&in, plane * 4)); CK(hipMalloc(&out, plane * 4 * NP));
+    std::vector<float> h(plane); for (size_t i = 0; i < plane; ++i) h[i] = (float)(i % 977) * 1e-3f;
+    CK(hipMemcpy(in, h.data(), plane * 4, hipMemcpyHostToDevice));
+    const double bytes8 = plane * 4.0 * 8, bytes7 = plane * 4.0 * 7, bytes2 = plane * 4.0 * 2;
+    auto rep = [&](const char* name, float ms, double bytes) { printf("%-44s %8.4f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6); };
+
+    for (int g : {1024, 2048, 4096, 8192})
+        { char nm[64]; snprintf(nm, 64, "P6 copy float4 grid=%d", g); rep(nm, timeit([&] { p6_copy<<<g, 256>>>((const float4*)in, (float4*)out, plane / 4); }), bytes2); }
+    for (int g : {1024, 2048, 4096, 8192, 16384})
+        { char nm[64]; snprintf(nm, 64, "P1 linear 1in/7out float4 grid=%d", g); rep(nm, timeit([&] { p1_linear<<<g, 256>>>((const float4*)in, (float4*)out, plane / 4, plane / 4); }), bytes8); }
+    for (int sr : {16, 32, 64, 128, 256, 512}) {
+        char nm[64];
+        snprintf(nm, 64, "P2 strip dword sr=%d", sr); rep(nm, timeit([&] { p2_strip<false><<<dim3(N / 256, (N + sr - 1) / sr), 256>>>(in, out, sr, plane); }), bytes8);
+        snprintf(nm, 64, "P2 strip dword NT sr=%d", sr); rep(nm, timeit([&] { p2_strip<true><<<dim3(N / 256, (N + sr - 1) / sr), 256>>>(in, out, sr, plane); }), bytes8);
+    }
+    for (int sr : {16, 32, 64, 128, 256}) {
+        char nm[64];
+        snprintf(nm, 64, "P3 strip float2 sr=%d", sr); rep(nm, timeit([&] { p3_strip_vec<2, false><<<dim3(N / 512, (N + sr - 1) / sr), 256>>>(in, out, sr, plane); }), bytes8);
+        snprintf(nm, 64, "P3 strip float4 sr=%d", sr); rep(nm, timeit([&] { p3_strip_vec<4, false><<<dim3(N / 1024, (N + sr - 1) / sr), 256>>>(in, out, sr, plane); }), bytes8);
+        snprintf(nm, 64, "P3 strip float4 NT sr=%d", sr); rep(nm, timeit([&] { p3_strip_vec<4, true><<<dim3(N / 1024, (N + sr - 1) / sr), 256>>>(in, out, sr, plane); }), bytes8);
+    }
+    for (int sr : {16, 64, 256}) {
+        char nm[64];
+        snprintf(nm, 64, "P4 vertical-block dword sr=%d", sr); rep(nm, timeit([&] { p4_vert<<<dim3(N / 64, (N + 4 * sr - 1) / (4 * sr)), 256>>>(in, out, sr, plane); }), bytes8);
+        snprintf(nm, 64, "P5 write-only strip dword sr=%d", sr); rep(nm, timeit([&] { p5_wonly<<<dim3(N / 256, (N + sr - 1) / sr), 256>>>(out, sr, plane); }), bytes7);
+    }
+    return 0;
+}

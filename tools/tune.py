@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""tools/tune.py -- sweep the basis kernel's launch knobs on the GPU box (strip rows x store policy)."""
+import os, sys, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cvsteer_amd as cv
+from cvsteer_amd import _lib as L
+
+def timeit(fn, steps=30, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    img = torch.rand((n, n), device="cuda")
+    g, h = torch.empty_like(img), torch.empty_like(img)
+    for kind, cls, bpp in (("G2", cv.SteerableFiltersG2, 32), ("G4", cv.SteerableFiltersG4, 48)):
+        f = cls(None)
+        nt_, halo = (9, 8) if kind == "G2" else (13, 12)
+        for pol in (1, 2):
+            f.set_option(L.OPT_STORE_POLICY, pol)
+            for k in (2, 3, 4, 6, 8, 11, 15, 22):
+                sr = k * nt_ - halo
+                f.set_strip_rows(sr)
+                ms = timeit(lambda: f.setup(img, flags=cv.SETUP_BASIS))
+                ms2 = timeit(lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h)))
+                print("%s policy=%s strip_rows=%3d  basis %.4f ms %7.0f Mpix/s %6.0f GB/s (%.1f%%) | +steer %.4f ms %7.0f Mpix/s %6.0f GB/s" % (
+                    kind, "plain" if pol == 1 else "nt", sr, ms, n*n/ms/1e3, bpp*n*n/ms/1e6, bpp*n*n/ms/1e6/80,
+                    ms2, n*n/ms2/1e3, (bpp+8)*n*n/ms2/1e6), flush=True)
+
+if __name__ == "__main__":
+    main()
