@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""tools/collect_profiles.py ROUND -- condense gpurun_out/ (scratch) rocprofv3 output of tools/profile.sh
+into profiles/ (tracked): kernel-stats CSV, the bench line of the profiled run, the PMC traffic
+summary with the gfx950 corrections, and profiles/traffic.json (read by bench.py)."""
+import collections, csv, glob, json, os, re, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs(P, exist_ok=True)
+
+def short(n):
+    n = re.sub(r"\((cvs::PointArgs|cvs::BasisArgs|float const\*|float\*|float4|int\*).*", "", n)
+    return n.replace("void ", "")
+
+# 1. kernel stats of `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu`
+stats = glob.glob(os.path.join(G, "prof_stats", "*", "*_kernel_stats.csv"))
+if stats:
+    rows = [r for r in csv.DictReader(open(stats[0])) if "cvs::" in r["Name"]]
+    with open(os.path.join(P, "%s_kernel_stats.csv" % rnd), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    line = [l for l in open(os.path.join(G, "prof_stats.log")) if l.startswith("{")]
+    if line:
+        open(os.path.join(P, "%s_bench_under_rocprof.json" % rnd), "w").write(line[-1])
+
+# 2. PMC passes (separate runs, counters only): FETCH_SIZE / WRITE_SIZE per kernel, in KB
+def pmc(tag, sub):
+    agg = collections.defaultdict(list)
+    for fn in glob.glob(os.path.join(G, sub % tag, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] == tag:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+fetch, write = pmc("FETCH_SIZE", "pmc_%s"), pmc("WRITE_SIZE", "pmc_%s")
+cal_f, cal_w = pmc("FETCH_SIZE", "pmc_cal_%s"), pmc("WRITE_SIZE", "pmc_cal_%s")
+plane = 4096 * 4096 * 4
+summary = {
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `python3 bench.py --steps 3 --warmup 1 --no-cpu` "
+              "(no tracing combined); counters are KB per dispatch, averaged over dispatches of the kernel. "
+              "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of streamed read bytes -> x2; "
+              "WRITE_SIZE is exact.  Both factors re-calibrated here on tools/membench kernels of KNOWN traffic in the same "
+              "access shapes (dword/lane strips, float4 linear; plain and nontemporal stores).",
+    "calibration": {k: {"FETCH_SIZE_bytes": cal_f.get(k), "WRITE_SIZE_bytes": cal_w.get(k),
+                        "known_read_bytes": 0 if "wonly" in k else plane,
+                        "known_write_bytes": plane if "copy" in k else 7 * plane} for k in sorted(cal_w)},
+    "kernels": {},
+}
+for k in sorted(write):
+    if "cvs::" not in k:
+        continue
+    f2 = 2.0 * fetch.get(k, 0.0)
+    summary["kernels"][k] = {"FETCH_SIZE_bytes_raw": fetch.get(k), "read_bytes_corrected_x2": f2,
+                             "WRITE_SIZE_bytes": write[k], "hbm_bytes_per_launch": f2 + write[k]}
+json.dump(summary, open(os.path.join(P, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
+
+key = "cvs::k_basis<cvs::BankG2, 2, true>"
+if key in summary["kernels"]:
+    t = summary["kernels"][key]
+    json.dump({"k_basis_g2_steer_4096": {"hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
+                                         "read_bytes": round(t["read_bytes_corrected_x2"]), "write_bytes": round(t["WRITE_SIZE_bytes"]),
+                                         "algorithmic_bytes_per_launch": 40 * 4096 * 4096,
+                                         "source": "profiles/%s_pmc_traffic.json" % rnd}},
+              open(os.path.join(P, "traffic.json"), "w"), indent=1)
+print(open(os.path.join(P, "%s_kernel_stats.csv" % rnd)).read())
+print(json.dumps(summary["kernels"], indent=1)[:1500])
