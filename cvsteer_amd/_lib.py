@@ -57,6 +57,7 @@ SIGNATURES = {
     "cvs_steer_map": (C.c_int, [C.c_void_p, _PP, _PP, _PP, _PP, _PP, _PP]),
     "cvs_steer_point": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, _FP]),
     "cvs_mag_phase": (C.c_int, [C.c_void_p, _PP, _PP, _PP, _PP]),
+    "cvs_wrap": (C.c_int, [C.c_void_p, _PP, _PP]),
     "cvs_phase_weights": (C.c_int, [C.c_void_p, _PP, _PP, C.c_float, C.c_int, C.c_float]),
     "cvs_find": (C.c_int, [C.c_void_p, _PP, _PP, _PP, _PP, _PP]),
     "cvs_pipeline": (C.c_int, [C.c_void_p, _PP, C.POINTER(_PP)]),

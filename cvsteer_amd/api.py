@@ -254,6 +254,14 @@ class SteerableFiltersG2(SteerableFilters):
         self._check(lib().cvs_mag_phase(self._h, C.byref(pg), C.byref(ph), C.byref(pm), C.byref(pp)), "cvs_mag_phase")
         return mag, phase
 
+    def wrap(self, angle):
+        """SteerableFilters::wrap (SteerableFilters.cpp:46-51)"""
+        out = self._new_like(angle)
+        self._bind_stream(angle, out)
+        pa, po = _plane(angle), _plane(out)
+        self._check(lib().cvs_wrap(self._h, C.byref(pa), C.byref(po)), "cvs_wrap")
+        return out
+
     def phaseWeights(self, phase, phi, signum, k=2.0):
         lam = self._new_like(phase)
         self._bind_stream(phase, lam)

@@ -630,6 +630,23 @@ int cvs_phase_weights(cvs_handle h, const cvs_plane* phase, const cvs_plane* lam
     return finish(c);
 }
 
+int cvs_wrap(cvs_handle h, const cvs_plane* angle, const cvs_plane* out)
+{
+    if (!h) return CVS_E_BADARG;
+    int rc;
+    if ((rc = check_plane(h, angle, "angle")) || (rc = check_plane(h, out, "out"))) return rc;
+    if ((rc = check_same(h, out, angle->rows, angle->cols))) return rc;
+    Call c;
+    if ((rc = begin(h, c, {angle, out}))) return rc;
+    PointArgs a{};
+    a.rows = angle->rows;
+    a.cols = angle->cols;
+    if ((rc = in_ref(c, angle, a.in[0])) || (rc = out_ref(c, out, a.out[0]))) return rc;
+    a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
+    HIP_TRY(h, launch_point(OP_WRAP, a, h->stream));
+    return finish(c);
+}
+
 int cvs_find(cvs_handle h, const cvs_plane* e, const cvs_plane* phase, const cvs_plane* edges, const cvs_plane* dark,
              const cvs_plane* bright)
 {

@@ -52,7 +52,8 @@ enum PointOp {
     OP_MAG_PHASE,          // in: g,h                          out: mag,phase
     OP_PHASE_WEIGHTS,      // in: phase                        out: lambda
     OP_FIND,               // in: e,phase                      out: edges,dark,bright
-    OP_G2_PIPELINE         // in: 7 basis, theta, c1,c2,c3     out: g,h,e,mag,phase,edges,dark,bright
+    OP_G2_PIPELINE,        // in: 7 basis, theta, c1,c2,c3     out: g,h,e,mag,phase,edges,dark,bright
+    OP_WRAP                // in: angle                        out: wrapped angle
 };
 
 constexpr int kMaxIn = 15;

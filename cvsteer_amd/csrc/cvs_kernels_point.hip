@@ -15,6 +15,7 @@
 //   OP_MAG_PHASE        SteerableFiltersG2.cpp:107-112
 //   OP_PHASE_WEIGHTS    SteerableFiltersG2.cpp:179-186
 //   OP_FIND             SteerableFiltersG2.cpp:194-212 (three maps in one pass)
+//   OP_WRAP             SteerableFilters.cpp:46-51
 //   OP_G2_PIPELINE      test/test.cpp:86-90 / example/steer.cpp:87-90 in one pass
 #include <hip/hip_runtime.h>
 
@@ -32,6 +33,7 @@ template <> struct OpShape<OP_G4_STEER_MAP> { static constexpr int NIN = 12, NOU
 template <> struct OpShape<OP_MAG_PHASE> { static constexpr int NIN = 2, NOUT = 2; };
 template <> struct OpShape<OP_PHASE_WEIGHTS> { static constexpr int NIN = 1, NOUT = 1; };
 template <> struct OpShape<OP_FIND> { static constexpr int NIN = 2, NOUT = 3; };
+template <> struct OpShape<OP_WRAP> { static constexpr int NIN = 1, NOUT = 1; };
 template <> struct OpShape<OP_G2_PIPELINE> { static constexpr int NIN = 11, NOUT = 8; };      // 7 basis, c1..c3, theta
 
 // one pixel.  in[] / out[] follow the OpShape order; `need_*` are wave-uniform.
@@ -65,6 +67,8 @@ __device__ __forceinline__ void point_eval(const float* in, float* out, const Po
         out[0] = __fmul_rn(in[0], phase_lambda(in[1], kHalfPiF, false));  // findEdges      G2.cpp:201-204
         out[1] = __fmul_rn(in[0], phase_lambda(in[1], 0.f, true));        // findDarkLines  G2.cpp:205-208
         out[2] = __fmul_rn(in[0], phase_lambda(in[1], kPiF, true));       // findBrightLines G2.cpp:209-212
+    } else if constexpr (OP == OP_WRAP) {
+        out[0] = wrap_pi(in[0]);
     } else if constexpr (OP == OP_G2_PIPELINE) {
         const float th = in[10];
         g2_steer_angle(in, th, out[0], out[1]);
@@ -184,6 +188,7 @@ hipError_t launch_point(PointOp op, const PointArgs& a, hipStream_t s)
         case OP_PHASE_WEIGHTS: return launch_op<OP_PHASE_WEIGHTS>(a, s);
         case OP_FIND: return launch_op<OP_FIND>(a, s);
         case OP_G2_PIPELINE: return launch_op<OP_G2_PIPELINE>(a, s);
+        case OP_WRAP: return launch_op<OP_WRAP>(a, s);
     }
     return hipErrorInvalidValue;
 }

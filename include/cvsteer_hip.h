@@ -149,6 +149,8 @@ int cvs_steer_point(cvs_handle h, int x, int y, float theta, float out[5]);
 /* computeMagnitudeAndPhase G2.cpp:107-112 (cartToPolar, wrap, patchNaNs) */
 int cvs_mag_phase(cvs_handle h, const cvs_plane* g, const cvs_plane* hq,
                   const cvs_plane* mag, const cvs_plane* phase);
+/* SteerableFilters::wrap, SteerableFilters.cpp:46-51: out = angle > pi ? angle - 2pi : angle */
+int cvs_wrap(cvs_handle h, const cvs_plane* angle, const cvs_plane* out);
 /* static phaseWeights G2.cpp:179-186 (k accepted and ignored, like the reference) */
 int cvs_phase_weights(cvs_handle h, const cvs_plane* phase, const cvs_plane* lambda,
                       float phi, int signum, float k);
