@@ -7,6 +7,7 @@
 // (cvs_taps.cpp) and the single-pixel steer (G2.cpp:115-134).  No CPU fallback exists.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -234,7 +235,7 @@ int use_nt_stores(cvs_handle h, size_t npix)
 }
 
 int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, float theta, const cvs_plane* g,
-             const cvs_plane* hq)
+             const cvs_plane* hq, const cvs_plane* const* pipe_outs = nullptr)
 {
     if (!h) return CVS_E_BADARG;
     int rc = check_plane(h, image, "image");
@@ -247,10 +248,18 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         if ((rc = check_same(h, g, image->rows, image->cols)) || (rc = check_same(h, hq, image->rows, image->cols))) return rc;
     }
     const size_t pitch = round_up((size_t)image->cols, 64);
-    const bool fast = basis_fast_path(h->kind, h->width, h->taps);
-    const size_t scratch = fast ? 0 : round_up(basis_scratch_elems(h->kind, h->width, image->rows, pitch), 64);
+    size_t max_pitch = std::max(pitch, image->step / sizeof(float));
+    if (steer) max_pitch = std::max(max_pitch, std::max(g->step, hq->step) / sizeof(float));
+    if (pipe_outs)
+        for (int k = 0; k < 8; ++k)
+            if (pipe_outs[k]) max_pitch = std::max(max_pitch, pipe_outs[k]->step / sizeof(float));
+    const bool may_generic = basis_may_need_scratch(h->kind, h->width, h->taps, image->rows, image->cols, max_pitch);
+    const size_t scratch = may_generic ? round_up(basis_scratch_elems(h->kind, h->width, image->rows, pitch), 64) : 0;
     Call c;
-    rc = begin(h, c, {image, steer ? g : nullptr, steer ? hq : nullptr}, scratch);
+    const cvs_plane* po[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (pipe_outs)
+        for (int k = 0; k < 8; ++k) po[k] = pipe_outs[k];
+    rc = begin(h, c, {image, steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7]}, scratch);
     if (rc) return rc;
     h->have_basis = h->have_orient = false;
     if ((rc = ensure_state(h, image->rows, image->cols))) return rc;
@@ -277,6 +286,12 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         a.steer_h = rh.p;
         a.steer_h_pitch = rh.pitch;
         host_steer_weights(h->kind, theta, a.steer_w);
+    }
+    if (pipe_outs) {
+        a.pipe = 1;
+        a.find_on_e = h->find_on;
+        for (int k = 0; k < 8; ++k)
+            if ((rc = out_ref(c, po[k], a.pipe_out[k]))) return rc;
     }
     float* scr = scratch ? arena_take(h, scratch) : nullptr;
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
@@ -680,22 +695,8 @@ int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const ou
         if (!outs[o]) continue;
         if ((rc = check_plane(h, outs[o], "out")) || (rc = check_same(h, outs[o], image->rows, image->cols))) return rc;
     }
-    if ((rc = do_setup(h, image, CVS_SETUP_FULL, false, 0.f, nullptr, nullptr))) return rc;
-    Call c;
-    if ((rc = begin(h, c, {outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], outs[6], outs[7]}))) return rc;
-    PointArgs a{};
-    a.rows = h->rows;
-    a.cols = h->cols;
-    a.atan_mode = h->atan_mode;
-    a.find_on_e = h->find_on;
-    basis_inputs(h, a);
-    for (int i = 0; i < 3; ++i) a.in[7 + i] = {state_plane(h, h->nb + i), h->pitch};
-    a.in[10] = {state_plane(h, h->nb + 3), h->pitch};
-    for (int o = 0; o < 8; ++o)
-        if ((rc = out_ref(c, outs[o], a.out[o]))) return rc;
-    a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
-    HIP_TRY(h, launch_point(OP_G2_PIPELINE, a, h->stream));
-    return finish(c);
+    // one launch: filter bank, orientation and the whole caller sequence in the kernel's epilogue
+    return do_setup(h, image, CVS_SETUP_FULL, false, 0.f, nullptr, nullptr, outs);
 }
 
 int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem)

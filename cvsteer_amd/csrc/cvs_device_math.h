@@ -22,6 +22,43 @@ __host__ __device__ inline int reflect101(int p, int len)
     return p < len ? p : period - p;
 }
 
+// cos/sin for cv::polarToCart (G2.cpp:151,175,183; documented accuracy ~1e-6).
+// The angles on this path are bounded -- theta_dom in (-pi/2, pi/2], 2*theta in (-pi, pi], the
+// phase error in [0, pi] -- so a two-constant Cody-Waite reduction to |r| <= pi/4 plus the classic
+// single-precision minimax polynomials (~1 ulp) is enough and is ~25 instructions, small enough to
+// live in the fused basis kernel's unrolled epilogue.  |x| > 8 (only reachable through
+// caller-supplied theta maps / phi) falls back to the library routine.
+__device__ __forceinline__ void sincos_small(float x, float& s, float& c)
+{
+    const float k = rintf(__fmul_rn(x, 0.636619772f));            // x * 2/pi
+    float r = fmaf(-k, 1.5707963705062866f, x);                    // - k * float(pi/2)
+    r = fmaf(-k, -4.371139000186243e-08f, r);                      // - k * (pi/2 - float(pi/2))
+    const float z = __fmul_rn(r, r);
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    const float sr = fmaf(__fmul_rn(ps, z), r, r);
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    const float cr = fmaf(__fmul_rn(pc, z), z, fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k & 3;
+    const float ss = (q & 1) ? cr : sr, cs = (q & 1) ? sr : cr;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cs : cs;
+}
+
+__device__ __forceinline__ void sincos_any(float x, float& s, float& c)
+{
+    if (fabsf(x) <= 8.0f) sincos_small(x, s, c);
+    else sincosf(x, &s, &c);
+}
+
+__device__ __forceinline__ float cos_any(float x)
+{
+    float s, c;
+    sincos_any(x, s, c);
+    return c;
+}
+
 // cv::cartToPolar's angle (radians, [0, 2pi)).
 // mode 0: the OpenCV 3.4 fastAtan2 polynomial in degrees, every op separately rounded
 // (contraction is off), then * (float)(pi/180).  mode 1: atan2f.
@@ -65,11 +102,16 @@ __device__ inline void mag_phase(float g, float h, int mode, float& mag, float& 
 }
 
 // phaseWeights, G2.cpp:179-186: lambda = cos^2(err) gated at pi/2
-__device__ inline float phase_lambda(float phase, float phi, bool signum)
+// BOUNDED: the caller guarantees |err| <= 8 (phase in (-pi, pi], phi in {0, pi/2, pi})
+template <bool BOUNDED = false>
+__device__ __forceinline__ float phase_lambda(float phase, float phi, bool signum)
 {
     float err = signum ? fabsf(__fsub_rn(phase, phi)) : fabsf(__fsub_rn(fabsf(phase), fabsf(phi)));
     err = fminf(err, __fsub_rn(kTwoPiF, err));
-    const float ct = cosf(err);
+    float st_, ct;
+    if constexpr (BOUNDED) sincos_small(err, st_, ct);
+    else sincos_any(err, st_, ct);
+    (void)st_;
     float l = __fmul_rn(ct, ct);
     if (fabsf(err) > kHalfPiF) l = 0.f;
     return l;
@@ -114,10 +156,12 @@ __device__ inline void g2_steer_weights(const float b[7], const float w[7], floa
 }
 
 // steer(const Mat1f& theta, ...) G2.cpp:147-155: cos/sin per pixel, (scale*(a*b))*M products
-__device__ inline void g2_steer_angle(const float b[7], float theta, float& g, float& h)
+template <bool BOUNDED = false>
+__device__ __forceinline__ void g2_steer_angle(const float b[7], float theta, float& g, float& h)
 {
     float st, ct;
-    sincosf(theta, &st, &ct);
+    if constexpr (BOUNDED) sincos_small(theta, st, ct);
+    else sincos_any(theta, st, ct);
     const float ct2 = __fmul_rn(ct, ct), ct3 = __fmul_rn(ct2, ct);
     const float st2 = __fmul_rn(st, st), st3 = __fmul_rn(st2, st);
     g = __fmul_rn(ct2, b[0]);
@@ -144,7 +188,7 @@ __device__ inline void g4_steer_weights(const float b[11], const float w[11], fl
 __device__ inline void g4_steer_angle(const float b[11], float theta, float& g, float& h)
 {
     float st, ct;
-    sincosf(theta, &st, &ct);
+    sincos_any(theta, st, ct);
     const float ct2 = __fmul_rn(ct, ct), ct3 = __fmul_rn(ct2, ct), ct4 = __fmul_rn(ct3, ct), ct5 = __fmul_rn(ct4, ct);
     const float st2 = __fmul_rn(st, st), st3 = __fmul_rn(st2, st), st4 = __fmul_rn(st3, st), st5 = __fmul_rn(st4, st);
     const float w[11] = { ct4, __fmul_rn(-4.0f, __fmul_rn(ct3, st)), __fmul_rn(6.0f, __fmul_rn(ct2, st2)),

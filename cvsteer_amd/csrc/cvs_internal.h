@@ -11,6 +11,11 @@ constexpr int kMaxWidth = 32;           // generic path: up to 65 taps
 constexpr int kMaxTaps = 2 * kMaxWidth + 1;
 constexpr int kMaxBasis = 11;
 
+struct PlaneRef {
+    float* p;       // nullptr = not requested
+    size_t pitch;   // elements
+};
+
 // One launch of the fused basis kernel ("K1").  All pitches/strides are in ELEMENTS.
 struct BasisArgs {
     const float* in;      // image, device
@@ -28,6 +33,10 @@ struct BasisArgs {
     int strip_rows;       // output rows per wave strip
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
+    // fused caller pipeline (needs orient): g2,h2,e,mag,phase,edges,dark,bright at theta_dom
+    int pipe;             // 1 = run the pipeline epilogue
+    int find_on_e;        // 1 = find*(e, phase), 0 = find*(magnitude, phase)
+    PlaneRef pipe_out[8]; // any entry may be {nullptr, 0}
 };
 
 // taps[i] = the handle's i-th tap vector (member order), 2*width+1 floats each
@@ -36,13 +45,9 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
 // elements of scratch the generic-width path needs for this image (0 on the fast paths)
 size_t basis_scratch_elems(int kind, int width, int rows, size_t pitch);
 bool basis_fast_path(int kind, int width, const float (*taps)[kMaxTaps]);
+bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], int rows, int cols, size_t max_pitch);
 
 // ---- pointwise kernels ("K2..K5") ----
-struct PlaneRef {
-    float* p;       // nullptr = not requested
-    size_t pitch;   // elements
-};
-
 enum PointOp {
     OP_G2_ORIENT = 0,      // in: 7 basis                     out: c1,c2,c3,theta,strength
     OP_G2_STEER_SCALAR,    // in: 7 basis [,c1,c2,c3]          out: g,h[,e,mag,phase]

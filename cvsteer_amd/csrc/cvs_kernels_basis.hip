@@ -31,6 +31,7 @@ namespace cvs {
 // ---------------------------------------------------------------------------------------
 struct BankG2 {  // SteerableFiltersG2.cpp:62-68
     static constexpr int KIND = 2, W = 4, NE = 3, NO = 3, NB = 7;
+    static constexpr int MIN_WAVES = 4;  // waves per SIMD the register allocator must leave room for
     // even: E0=G21 E1=G22(=H22) E2=H24 ; odd: O0=G23 O1=H21 O2=H23 (ids 3,4,5)
     __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 3, 1, 4, 2, 5, 1}; return t[p]; }
     __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 3, 0, 1, 5, 2, 4}; return t[p]; }
@@ -41,6 +42,7 @@ struct BankG2 {  // SteerableFiltersG2.cpp:62-68
 
 struct BankG4 {  // SteerableFiltersG4.cpp:69-80
     static constexpr int KIND = 4, W = 6, NE = 5, NO = 5, NB = 11;
+    static constexpr int MIN_WAVES = 2;
     // even: E0=G41 E1=G42(=H42) E2=G45 E3=H43 E4=H46 ; odd: O0=G43 O1=G44 O2=H41 O3=H44 O4=H45 (ids 5..9)
     __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 5, 2, 6, 1, 7, 3, 9, 4, 8, 1}; return t[p]; }
     __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 6, 2, 5, 0, 1, 8, 4, 9, 3, 7}; return t[p]; }
@@ -56,7 +58,7 @@ struct Folded {
     float od[B::NO][B::W];
 };
 
-enum { F_ORIENT = 1, F_STEER = 2 };
+enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4 };  // F_PIPE implies F_ORIENT
 
 // LDS hand-off inside ONE wave: DS ops of a wave execute in issue order, so only the compiler
 // must be kept from moving them across this point.
@@ -67,12 +69,40 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// output store: STREAM = nontemporal streaming store (bypasses cache allocation; see cvs_api.cpp use_nt_stores)
-template <bool STREAM>
-__device__ __forceinline__ void put(float* p, float v)
+// Addressing idiom: buffer instructions.  A plane is a raw buffer resource (4 SGPRs, built from
+// wave-uniform values only), the row is the scalar offset (one SGPR, `soffset`), the lane's column
+// is a per-lane BYTE offset that is fixed for the whole strip (one VGPR shared by every load and
+// store of the kernel).  No per-access 64-bit VALU address arithmetic, no address VGPR pairs.
+// Planes are addressed with 32-bit offsets: a plane may be up to 4 GiB (32768 x 32768 f32).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+// A lane offset at or above every legal num_records (planes are < 2 GiB on this path): the
+// hardware range check turns such a load into 0 and drops such a store, with no exec-mask branch
+// and -- whether or not the scalar row offset takes part in the check -- no 32-bit wrap.
+constexpr unsigned kLaneOff = 0x80000000u;
+constexpr size_t kMaxPlaneBytes = 0x7ffffff0ull;
+
+// BORDER_REFLECT_101 when at most one reflection is needed (-len < p < 2*len - 1): two scalar
+// compare/selects.  The launcher sends images too small for this to the generic path.
+__device__ __forceinline__ int reflect1(int p, int len)
 {
-    if constexpr (STREAM) __builtin_nontemporal_store(v, p);
-    else *p = v;
+    p = p < 0 ? -p : p;
+    return p >= len ? 2 * len - 2 - p : p;
+}
+
+__device__ __forceinline__ rsrc_t plane_rsrc(const float* base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
+                                             (int)(bytes > kMaxPlaneBytes ? kMaxPlaneBytes : bytes), 0x00020000);
+}
+__device__ __forceinline__ float bld(rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));
+}
+template <bool STREAM>
+__device__ __forceinline__ void bst(rsrc_t r, unsigned lane_off, unsigned row_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_off, row_off, STREAM ? 2 : 0);  // aux 2 = nt
 }
 
 template <class B, int FLAGS, bool STREAM>
@@ -90,42 +120,55 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
     const int yend = min(y0 + a.strip_rows, a.rows);
     const int x = x0 + lane;
     const bool xin = x < a.cols;
-    // REFLECT_101 source columns, fixed for the whole strip
-    const int xm = reflect101(x, a.cols);
+    // REFLECT_101 source columns, fixed for the whole strip.  Columns beyond cols+W feed no valid
+    // output; they are clamped so the address stays inside the row.
+    const int xm = min(reflect1(x, a.cols), a.cols - 1);
     const bool is_halo = lane < 2 * W;
-    const int xh = reflect101(lane < W ? x0 - W + lane : x0 + 64 + (lane - W), a.cols);
+    const int xh = min(reflect1(lane < W ? x0 - W + lane : x0 + 64 + (lane - W), a.cols), a.cols - 1);
+    // per-lane byte offsets; kLaneOff = "this lane does not take part" (hardware range check)
+    const unsigned xb = xin ? (unsigned)x * 4u : kLaneOff;
+    const unsigned xmb = (unsigned)xm * 4u;
+    const unsigned xhb = is_halo ? (unsigned)xh * 4u : kLaneOff;
     const int hslot = lane < W ? lane : 64 + lane;  // left halo -> [0,W), right -> [64+W, 64+2W)
     float* line = lds[wv];
+    // buffer resources (wave-uniform): input plane, state planes
+    const size_t plane_bytes = (size_t)a.rows * a.pitch * sizeof(float);
+    const unsigned pitch_b = (unsigned)(a.pitch * sizeof(float));
+    const rsrc_t r_in = plane_rsrc(a.in, (size_t)a.rows * a.in_pitch * sizeof(float));
+    const unsigned in_pitch_b = (unsigned)(a.in_pitch * sizeof(float));
 
     float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
-    float cur[NT], curh[NT], nxt[NT], nxth[NT];
+    float pre[NT], preh[NT];  // prefetched input rows (main lane value, halo-lane value)
 
     const int nrows_in = (yend - y0) + 2 * W;
     const int ngroups = (nrows_in + NT - 1) / NT;
 
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const float* rp = a.in + (size_t)reflect101(y0 - W + j, a.rows) * a.in_pitch;
-        cur[j] = rp[xm];
-        curh[j] = is_halo ? rp[xh] : 0.f;
-        nxt[j] = 0.f;
-        nxth[j] = 0.f;
+        const unsigned ro = (unsigned)reflect1(y0 - W + j, a.rows) * in_pitch_b;
+        pre[j] = bld(r_in, xmb, ro);
+        preh[j] = bld(r_in, xhb, ro);
     }
 
     for (int g = 0; g < ngroups; ++g) {
-        if (g + 1 < ngroups) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float* rp = a.in + (size_t)reflect101(y0 - W + (g + 1) * NT + j, a.rows) * a.in_pitch;
-                nxt[j] = rp[xm];
-                nxth[j] = is_halo ? rp[xh] : 0.f;
-            }
-        }
+        // Prefetch for the NEXT group is issued unconditionally (straight-line code: no phi copies,
+        // no early waits); in the last group the lane offsets are kLaneOff, so the hardware range
+        // check drops those loads without touching memory.
+        const bool more = g + 1 < ngroups;  // wave-uniform
+        const unsigned nxmb = more ? xmb : kLaneOff, nxhb = more ? xhb : kLaneOff;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            const float v = pre[j], vh = preh[j];
+            // the register just consumed is refilled at once with the same row of the next group:
+            // a full group (2W+1 rows) of loads stays in flight with a single set of registers
+            {
+                const unsigned ro = (unsigned)reflect1(y0 - W + (g + 1) * NT + j, a.rows) * in_pitch_b;
+                pre[j] = bld(r_in, nxmb, ro);
+                preh[j] = bld(r_in, nxhb, ro);
+            }
             // ---- row pass: stage the line, read the 2W+1 neighbours ----
-            line[W + lane] = cur[j];
-            if (is_halo) line[hslot] = curh[j];
+            line[W + lane] = v;
+            if (is_halo) line[hslot] = vh;
             wave_lds_fence();
             float s[NT];
 #pragma unroll
@@ -176,34 +219,49 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
                     }
                     b[p] = acc;
                 }
-                if (xin) {
-                    float* orow = a.basis + (size_t)yout * a.pitch;
+                // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
+                const unsigned orow = (unsigned)yout * pitch_b;
 #pragma unroll
-                    for (int p = 0; p < NB; ++p) put<STREAM>(orow + (size_t)p * a.plane_stride + x, b[p]);
-                    if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
-                        float c1, c2, c3, th, st;
-                        g2_orientation(b, a.atan_mode, c1, c2, c3, th, st);
-                        float* o = a.orient + (size_t)yout * a.pitch + x;
-                        put<STREAM>(o, c1);
-                        put<STREAM>(o + a.plane_stride, c2);
-                        put<STREAM>(o + 2 * a.plane_stride, c3);
-                        put<STREAM>(o + 3 * a.plane_stride, th);
-                        put<STREAM>(o + 4 * a.plane_stride, st);
-                    }
-                    if constexpr ((FLAGS & F_STEER) != 0) {
-                        float gq, hq;
-                        if constexpr (B::KIND == 2) g2_steer_weights(b, a.steer_w, gq, hq);
-                        else g4_steer_weights(b, a.steer_w, gq, hq);
-                        put<STREAM>(a.steer_g + (size_t)yout * a.steer_g_pitch + x, gq);
-                        put<STREAM>(a.steer_h + (size_t)yout * a.steer_h_pitch + x, hq);
+                for (int p = 0; p < NB; ++p)
+                    bst<STREAM>(plane_rsrc(a.basis + (size_t)p * a.plane_stride, plane_bytes), xb, orow, b[p]);
+                if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
+                    float c1, c2, c3, th, st;
+                    g2_orientation(b, a.atan_mode, c1, c2, c3, th, st);
+                    const float ov[5] = {c1, c2, c3, th, st};
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        bst<STREAM>(plane_rsrc(a.orient + (size_t)k * a.plane_stride, plane_bytes), xb, orow, ov[k]);
+                    if constexpr ((FLAGS & F_PIPE) != 0) {
+                        // the callers' sequence (test/test.cpp:86-90) on values still in registers:
+                        // steer at theta_dom, energy, magnitude/phase, the three feature maps
+                        float q[8];
+                        // theta_dom in (-pi/2, pi/2]: the bounded cos/sin path, no library call
+                        g2_steer_angle<true>(b, th, q[0], q[1]);
+                        float s2, cc2;
+                        sincos_small(__fmul_rn(th, 2.0f), s2, cc2);
+                        q[2] = __fadd_rn(__fadd_rn(c1, __fmul_rn(c2, cc2)), __fmul_rn(c3, s2));
+                        mag_phase(q[0], q[1], a.atan_mode, q[3], q[4]);
+                        const float en = a.find_on_e ? q[2] : q[3];
+                        q[5] = __fmul_rn(en, phase_lambda<true>(q[4], kHalfPiF, false));
+                        q[6] = __fmul_rn(en, phase_lambda<true>(q[4], 0.f, true));
+                        q[7] = __fmul_rn(en, phase_lambda<true>(q[4], kPiF, true));
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (a.pipe_out[k].p)
+                                bst<STREAM>(plane_rsrc(a.pipe_out[k].p, (size_t)a.rows * a.pipe_out[k].pitch * sizeof(float)), xb,
+                                            (unsigned)yout * (unsigned)(a.pipe_out[k].pitch * sizeof(float)), q[k]);
                     }
                 }
+                if constexpr ((FLAGS & F_STEER) != 0) {
+                    float gq, hq;
+                    if constexpr (B::KIND == 2) g2_steer_weights(b, a.steer_w, gq, hq);
+                    else g4_steer_weights(b, a.steer_w, gq, hq);
+                    bst<STREAM>(plane_rsrc(a.steer_g, (size_t)a.rows * a.steer_g_pitch * sizeof(float)), xb,
+                                (unsigned)yout * (unsigned)(a.steer_g_pitch * sizeof(float)), gq);
+                    bst<STREAM>(plane_rsrc(a.steer_h, (size_t)a.rows * a.steer_h_pitch * sizeof(float)), xb,
+                                (unsigned)yout * (unsigned)(a.steer_h_pitch * sizeof(float)), hq);
+                }
             }
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            cur[j] = nxt[j];
-            curh[j] = nxth[j];
         }
     }
 }
@@ -281,6 +339,14 @@ size_t basis_scratch_elems(int kind, int width, int rows, size_t pitch)
     return (size_t)rows * pitch;  // one plane; only touched on the generic path
 }
 
+// conservative: true whenever launch_basis may take the generic path for this geometry
+bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], int rows, int cols, size_t max_pitch)
+{
+    if (!basis_fast_path(kind, width, taps)) return true;
+    if (rows < 3 * width + 1 || cols < width + 1) return true;
+    return (size_t)rows * max_pitch * sizeof(float) > kMaxPlaneBytes;
+}
+
 template <class B>
 static hipError_t launch_fast(const BasisArgs& a, const Folded<B>& f, hipStream_t s)
 {
@@ -289,17 +355,24 @@ static hipError_t launch_fast(const BasisArgs& a, const Folded<B>& f, hipStream_
     dim3 block(256);
     const bool orient = a.orient != nullptr && B::KIND == 2;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
-    const int flags = (orient ? F_ORIENT : 0) | (steer ? F_STEER : 0);
+    const bool pipe = orient && a.pipe;
+    const int flags = pipe ? (F_ORIENT | F_PIPE) : ((orient ? F_ORIENT : 0) | (steer ? F_STEER : 0));
 #define CVS_LAUNCH(FL)                                                                         \
     do {                                                                                       \
         if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true>), grid, block, 0, s, a, f);  \
         else hipLaunchKernelGGL((k_basis<B, FL, false>), grid, block, 0, s, a, f);             \
     } while (0)
-    switch (flags) {
-        case 0: CVS_LAUNCH(0); break;
-        case F_ORIENT: CVS_LAUNCH(F_ORIENT); break;
-        case F_STEER: CVS_LAUNCH(F_STEER); break;
-        default: CVS_LAUNCH(F_ORIENT | F_STEER); break;
+    if constexpr (B::KIND == 2) {
+        switch (flags) {
+            case 0: CVS_LAUNCH(0); break;
+            case F_ORIENT: CVS_LAUNCH(F_ORIENT); break;
+            case F_STEER: CVS_LAUNCH(F_STEER); break;
+            case F_ORIENT | F_STEER: CVS_LAUNCH(F_ORIENT | F_STEER); break;
+            default: CVS_LAUNCH(F_ORIENT | F_PIPE); break;
+        }
+    } else {
+        if (steer) CVS_LAUNCH(F_STEER);
+        else CVS_LAUNCH(0);
     }
 #undef CVS_LAUNCH
     return hipGetLastError();
@@ -330,6 +403,17 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
         e = launch_point(OP_G2_ORIENT, pa, s);
         if (e != hipSuccess) return e;
     }
+    if (a.orient && kind == 2 && a.pipe) {
+        PointArgs pa{};
+        pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
+        pa.find_on_e = a.find_on_e;
+        for (int p = 0; p < 7; ++p) pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch};
+        for (int i = 0; i < 3; ++i) pa.in[7 + i] = {a.orient + (size_t)i * a.plane_stride, a.pitch};
+        pa.in[10] = {a.orient + (size_t)3 * a.plane_stride, a.pitch};
+        for (int k = 0; k < 8; ++k) pa.out[k] = a.pipe_out[k];
+        e = launch_point(OP_G2_PIPELINE, pa, s);
+        if (e != hipSuccess) return e;
+    }
     if (a.steer_g && a.steer_h) {
         PointArgs pa{};
         pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
@@ -341,9 +425,23 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
     return e;
 }
 
+static bool fast_geometry_ok(const BasisArgs& a, int width)
+{
+    // single-step reflection (reflect1) and 31-bit plane offsets: see k_basis
+    if (a.rows < 3 * width + 1 || a.cols < width + 1) return false;
+    const size_t in_bytes = (size_t)a.rows * a.in_pitch * sizeof(float);
+    const size_t st_bytes = (size_t)a.rows * a.pitch * sizeof(float);
+    size_t mx = in_bytes > st_bytes ? in_bytes : st_bytes;
+    if (a.steer_g) { mx = max(mx, (size_t)a.rows * a.steer_g_pitch * sizeof(float)); mx = max(mx, (size_t)a.rows * a.steer_h_pitch * sizeof(float)); }
+    for (int k = 0; k < 8; ++k)
+        if (a.pipe && a.pipe_out[k].p) mx = max(mx, (size_t)a.rows * a.pipe_out[k].pitch * sizeof(float));
+    return mx <= kMaxPlaneBytes;
+}
+
 hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
                         float* scratch, hipStream_t s)
 {
+    if (!fast_geometry_ok(a, width)) return launch_generic(kind, width, taps, a, scratch, s);
     if (kind == 2 && width == BankG2::W) {
         Folded<BankG2> f;
         if (fold_taps<BankG2>(taps, f)) return launch_fast<BankG2>(a, f, s);

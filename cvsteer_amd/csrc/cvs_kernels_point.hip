@@ -51,7 +51,7 @@ __device__ __forceinline__ void point_eval(const float* in, float* out, const Po
         g2_steer_angle(in, th, out[0], out[1]);
         if (need_e) {  // G2.cpp:174-176
             float s2, c2;
-            sincosf(__fmul_rn(th, 2.0f), &s2, &c2);
+            sincos_any(__fmul_rn(th, 2.0f), s2, c2);
             out[2] = __fadd_rn(__fadd_rn(in[7], __fmul_rn(in[8], c2)), __fmul_rn(in[9], s2));
         }
         if (need_mp) mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
@@ -73,7 +73,7 @@ __device__ __forceinline__ void point_eval(const float* in, float* out, const Po
         const float th = in[10];
         g2_steer_angle(in, th, out[0], out[1]);
         float s2, c2;
-        sincosf(__fmul_rn(th, 2.0f), &s2, &c2);
+        sincos_any(__fmul_rn(th, 2.0f), s2, c2);
         out[2] = __fadd_rn(__fadd_rn(in[7], __fmul_rn(in[8], c2)), __fmul_rn(in[9], s2));
         mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
         const float en = a.find_on_e ? out[2] : out[3];
