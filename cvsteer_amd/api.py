@@ -222,6 +222,28 @@ class SteerableFilters:
         return self._steer(theta, full, out)
 
 
+    # -- adjacent component: Gaussian pyramid, not part of the reference --
+    def pyrDown(self, image):
+        """one pyramid level with cv::pyrDown semantics: ((rows+1)//2, (cols+1)//2)"""
+        image = _as_input(image)
+        shape = ((image.shape[0] + 1) // 2, (image.shape[1] + 1) // 2)
+        if _is_torch(image):
+            dst = torch.empty(shape, dtype=torch.float32, device=image.device)
+        else:
+            dst = np.empty(shape, np.float32)
+        self._bind_stream(image, dst)
+        ps, pd = _plane(image), _plane(dst)
+        self._check(lib().cvs_pyr_down(self._h, C.byref(ps), C.byref(pd)), "cvs_pyr_down")
+        return dst
+
+    def pyramid(self, image, levels):
+        """[image, pyrDown(image), ...] -- `levels` planes"""
+        out = [_as_input(image)]
+        for _ in range(levels - 1):
+            out.append(self.pyrDown(out[-1]))
+        return out
+
+
 class SteerableFiltersG2(SteerableFilters):
     """fa::SteerableFiltersG2 (SteerableFiltersG2.h:35-67)."""
 

@@ -699,6 +699,20 @@ int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const ou
     return do_setup(h, image, CVS_SETUP_FULL, false, 0.f, nullptr, nullptr, outs);
 }
 
+int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst)
+{
+    if (!h) return CVS_E_BADARG;
+    int rc;
+    if ((rc = check_plane(h, src, "src")) || (rc = check_plane(h, dst, "dst"))) return rc;
+    if ((rc = check_same(h, dst, (src->rows + 1) / 2, (src->cols + 1) / 2))) return rc;
+    Call c;
+    if ((rc = begin(h, c, {src, dst}))) return rc;
+    PlaneRef in, out;
+    if ((rc = in_ref(c, src, in)) || (rc = out_ref(c, dst, out))) return rc;
+    HIP_TRY(h, launch_pyr_down(in.p, in.pitch, src->rows, src->cols, out.p, out.pitch, h->stream));
+    return finish(c);
+}
+
 int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem)
 {
     if (!h || !dst) return CVS_E_BADARG;

@@ -246,6 +246,39 @@ __global__ __launch_bounds__(256) void k_quantize_u8(const float* src, size_t pi
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// Gaussian pyramid level (BASELINE config 3; the reference has no pyramid code): cv::pyrDown
+// semantics -- [1 4 6 4 1]/16 separable blur, REFLECT_101, keep every second pixel, output
+// ((rows+1)/2) x ((cols+1)/2).  One thread makes one output pixel from its 5x5 neighbourhood;
+// the 25 reads of neighbouring threads overlap and are served by L1/L2, HBM sees each input
+// line once: 16 B read + 4 B written per output pixel.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_down(const float* src, size_t spitch, int rows, int cols,
+                                                   float* dst, size_t dpitch, int orows, int ocols)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ocols || y >= orows) return;
+    int xi[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) xi[i] = reflect101(2 * x + i - 2, cols);
+    float rowv[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float* s = src + (size_t)reflect101(2 * y + j - 2, rows) * spitch;
+        rowv[j] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(s[xi[2]], 6.0f), __fmul_rn(__fadd_rn(s[xi[1]], s[xi[3]]), 4.0f)), s[xi[0]]), s[xi[4]]);
+    }
+    const float v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(rowv[2], 6.0f), __fmul_rn(__fadd_rn(rowv[1], rowv[3]), 4.0f)), rowv[0]), rowv[4]);
+    dst[(size_t)y * dpitch + x] = __fmul_rn(v, 1.0f / 256.0f);
+}
+
+hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s)
+{
+    const int orows = (rows + 1) / 2, ocols = (cols + 1) / 2;
+    hipLaunchKernelGGL(k_pyr_down, dim3((ocols + 63) / 64, (orows + 3) / 4), dim3(256), 0, s, src, spitch, rows, cols, dst, dpitch, orows, ocols);
+    return hipGetLastError();
+}
+
 hipError_t launch_minmax(const float* src, size_t pitch, int rows, int cols, float* minmax2, hipStream_t s)
 {
     int* mm = reinterpret_cast<int*>(minmax2);

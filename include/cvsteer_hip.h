@@ -163,6 +163,11 @@ int cvs_find(cvs_handle h, const cvs_plane* e, const cvs_plane* phase,
  * outs[8] = {g2, h2, e, magnitude, phase, edges, dark, bright}; any entry may be NULL. */
 int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const outs[8]);
 
+/* One Gaussian-pyramid level (BASELINE config 3; absent from the reference): cv::pyrDown
+ * semantics -- 5-tap [1 4 6 4 1]/16 separable blur, BORDER_REFLECT_101, every second pixel.
+ * dst must be ((rows+1)/2) x ((cols+1)/2). */
+int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst);
+
 /* per-image min/max (cv::normalize NORM_MINMAX, test.cpp:92-94 / steer.cpp:96-98) and the
  * 8-bit quantise that follows; dst is rows*cols bytes with dst_step bytes per row. */
 int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem);

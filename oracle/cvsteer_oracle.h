@@ -104,6 +104,9 @@ void ora_find(const float* e, const float* phase, size_t n, float* edges, float*
 void ora_g4_steer_scalar(const float* basis, size_t n, float theta, float* g4, float* h4);
 void ora_g4_steer_map(const float* basis, size_t n, const float* theta, float* g4, float* h4);
 
+/* cv::pyrDown restated (config 3 pyramid; not in the reference, unpinned). dst is ((rows+1)/2) x ((cols+1)/2) dense */
+void ora_pyr_down(const float* src, int rows, int cols, size_t src_step_elems, float* dst);
+
 /* ---- timing legs for bench.py cpu_baseline (reference call sequence, one thread) ---- */
 /* G2: 7 sepFilter2D + scalar steer (M2).  returns seconds for `reps` repetitions */
 double ora_time_g2_filter_steer(const float* src, int rows, int cols, float theta, int reps);

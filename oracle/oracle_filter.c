@@ -420,6 +420,36 @@ void ora_g4_steer_map(const float* b, size_t n, const float* theta, float* g4, f
     }
 }
 
+/* cv::pyrDown(src, dst) with default size ((cols+1)/2, (rows+1)/2) and BORDER_REFLECT_101
+ * (BORDER_DEFAULT): 5x5 Gaussian [1 4 6 4 1]/16 (x) [1 4 6 4 1]/16, then every second pixel.
+ * NOT part of the reference (it has no pyramid code): restated from the
+ * OpenCV documentation for BASELINE config 3; [recalled] float path = integer-weight row sum,
+ * integer-weight column sum, one multiply by 1/256.  Parity for this function is unpinned. */
+void ora_pyr_down(const float* src, int rows, int cols, size_t sstep, float* dst)
+{
+    int orows = (rows + 1) / 2, ocols = (cols + 1) / 2;
+    float* rowbuf = (float*)malloc((size_t)rows * ocols * sizeof(float));
+    for (int y = 0; y < rows; y++) {
+        const float* s = src + (size_t)y * sstep;
+        for (int x = 0; x < ocols; x++) {
+            float c = s[ora_reflect101(2 * x, cols)];
+            float l1 = s[ora_reflect101(2 * x - 1, cols)], r1 = s[ora_reflect101(2 * x + 1, cols)];
+            float l2 = s[ora_reflect101(2 * x - 2, cols)], r2 = s[ora_reflect101(2 * x + 2, cols)];
+            rowbuf[(size_t)y * ocols + x] = c * 6.0f + (l1 + r1) * 4.0f + l2 + r2;
+        }
+    }
+    for (int y = 0; y < orows; y++) {
+        const float* r0 = rowbuf + (size_t)ora_reflect101(2 * y - 2, rows) * ocols;
+        const float* r1 = rowbuf + (size_t)ora_reflect101(2 * y - 1, rows) * ocols;
+        const float* r2 = rowbuf + (size_t)ora_reflect101(2 * y, rows) * ocols;
+        const float* r3 = rowbuf + (size_t)ora_reflect101(2 * y + 1, rows) * ocols;
+        const float* r4 = rowbuf + (size_t)ora_reflect101(2 * y + 2, rows) * ocols;
+        for (int x = 0; x < ocols; x++)
+            dst[(size_t)y * ocols + x] = (r2[x] * 6.0f + (r1[x] + r3[x]) * 4.0f + r0[x] + r4[x]) * (1.0f / 256.0f);
+    }
+    free(rowbuf);
+}
+
 /* cpu_baseline leg: the reference call sequence for the headline unit of work --
  * 7 x sepFilter2D (G2.cpp:62-68) + scalar steer (G2.cpp:137-145) -- single thread. */
 double ora_time_g2_filter_steer(const float* src, int rows, int cols, float theta, int reps)

@@ -197,6 +197,14 @@ def g4_steer_map(b, theta):
     return g, h
 
 
+def pyr_down(src):
+    src = _f32(src)
+    rows, cols = src.shape
+    dst = np.empty(((rows + 1) // 2, (cols + 1) // 2), np.float32)
+    lib().ora_pyr_down(_fp(src), rows, cols, C.c_size_t(cols), _fp(dst))
+    return dst
+
+
 def time_g2_filter_steer(src, theta, reps=1):
     src = _f32(src)
     return lib().ora_time_g2_filter_steer(_fp(src), src.shape[0], src.shape[1], C.c_float(theta), reps)

@@ -384,3 +384,34 @@ def test_frame_1080p_pipeline_band(cv, ora):
     oed, odk, obr = ora.find(outs[3][500:540], outs[4][500:540])
     for got, want in zip(outs[5:], (oed, odk, obr)):
         assert np.abs(got[500:540] - want).max() <= 1e-6
+
+
+# ----------------------------------------------------------------------------- pyramid (config 3)
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 5), (37, 51), (64, 64), (185, 256), (1080, 1920)])
+def test_pyr_down_matches_oracle(cv, ora, shape):
+    img = rand_image(*shape, seed=17)
+    f = cv.SteerableFiltersG2(None)
+    got = f.pyrDown(img)
+    assert np.array_equal(got, ora.pyr_down(img))  # same op order, contraction off: bit-identical
+
+
+def test_pyramid_5_levels_8192(cv, ora):
+    """BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image"""
+    import torch
+    n = 8192
+    x = torch.rand((n, n), generator=torch.Generator(device="cuda").manual_seed(3), device="cuda")
+    f = cv.SteerableFiltersG2(None)
+    levels = f.pyramid(x, 5)
+    assert [tuple(l.shape) for l in levels] == [(8192, 8192), (4096, 4096), (2048, 2048), (1024, 1024), (512, 512)]
+    # pyramid construction: bands of level 1 and the whole of level 4 against the oracle
+    x0 = x.cpu().numpy()
+    l1 = ora.pyr_down(x0[:132])  # rows 0..65 of level 1 need rows 0..131+2 of level 0; keep the safe part
+    assert np.array_equal(levels[1][:64].cpu().numpy(), l1[:64])
+    assert np.array_equal(levels[4].cpu().numpy(), ora.pyr_down(levels[3].cpu().numpy()))
+    # filter bank on every level: oracle on a band (top border included)
+    for lv in levels:
+        f.setup(lv, flags=cv.SETUP_BASIS)
+        h = lv[:48].cpu().numpy()
+        band = ora.basis(2, h, 4, 0.67, f64=True)
+        for p in (0, 3, 6):
+            assert np.abs(f.basis(p)[:44].cpu().numpy() - band[p][:44]).max() <= TOL

@@ -170,3 +170,19 @@ def test_phase_weights_reference_semantics(ora):
     assert lam_bright[4] == pytest.approx(np.cos(np.pi - 3.0) ** 2, rel=1e-5)
     # k is ignored (G2.cpp:179-186)
     assert np.array_equal(ora.phase_weights(ph, 0.0, True, k=7.0), lam_dark)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 5), (37, 51), (64, 64), (185, 256)])
+def test_pyr_down_matches_scipy_mirror(ora, shape):
+    """config 3 helper (not in the reference): cv::pyrDown semantics restated; scipy 'mirror' == REFLECT_101"""
+    from scipy.ndimage import correlate1d
+    img = rand_image(*shape, seed=13)
+    k = np.array([1, 4, 6, 4, 1], np.float64) / 16
+    a = img.astype(np.float64)
+    if shape[1] > 1:
+        a = correlate1d(a, k, axis=1, mode="mirror")
+    if shape[0] > 1:
+        a = correlate1d(a, k, axis=0, mode="mirror")
+    got = ora.pyr_down(img)
+    assert got.shape == ((shape[0] + 1) // 2, (shape[1] + 1) // 2)
+    assert np.abs(got - a[::2, ::2]).max() <= 5e-7
