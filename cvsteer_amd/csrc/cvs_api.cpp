@@ -36,7 +36,7 @@ struct cvs_context {
     float* arena = nullptr;
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1;
     std::string err;
 };
 
@@ -278,6 +278,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.atan_mode = h->atan_mode;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
+    a.g4_split = h->g4_split;
     if (steer) {
         PlaneRef rg, rh;
         if ((rc = out_ref(c, g, rg)) || (rc = out_ref(c, hq, rh))) return rc;
@@ -463,6 +464,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "store policy");
             h->store_policy = value;
             return CVS_OK;
+        case CVS_OPT_G4_SPLIT:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "g4 split");
+            h->g4_split = value;
+            return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -475,6 +480,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_STRIP_ROWS: *value = h->strip_rows; return CVS_OK;
         case CVS_OPT_FIND_ON: *value = h->find_on; return CVS_OK;
         case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
+        case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }

@@ -33,6 +33,7 @@ struct BasisArgs {
     int strip_rows;       // output rows per wave strip
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
+    int g4_split;         // 1 = run the G4 bank as two launches (G half, H half)
     // fused caller pipeline (needs orient): g2,h2,e,mag,phase,edges,dark,bright at theta_dom
     int pipe;             // 1 = run the pipeline epilogue
     int find_on_e;        // 1 = find*(e, phase), 0 = find*(magnitude, phase)

@@ -38,6 +38,7 @@ struct BankG2 {  // SteerableFiltersG2.cpp:62-68
     static constexpr int even_member(int r) { constexpr int t[NE] = {0, 1, 6}; return t[r]; }
     static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3, 5}; return t[r]; }
     static constexpr int dup_a = 1, dup_b = 4;  // m_g2 == m_h2 bit for bit
+    static constexpr int PLANE0 = 0, HALF = 0;  // first basis plane written; 0 = whole bank
 };
 
 struct BankG4 {  // SteerableFiltersG4.cpp:69-80
@@ -49,6 +50,32 @@ struct BankG4 {  // SteerableFiltersG4.cpp:69-80
     static constexpr int even_member(int r) { constexpr int t[NE] = {0, 1, 4, 7, 10}; return t[r]; }
     static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3, 5, 8, 9}; return t[r]; }
     static constexpr int dup_a = 1, dup_b = 6;  // m_g2 == m_h2
+    static constexpr int PLANE0 = 0, HALF = 0;
+};
+
+// The 11-plane bank needs a 10 x 13 register window (187 VGPRs, 2 waves/SIMD).  Its G and H
+// halves share no row-filtered plane, so they also run as two launches with 65- and 78-register
+// windows; the image is read twice (the second read is an L2 / Infinity-Cache hit).
+struct BankG4G {  // planes g4a..g4e, SteerableFiltersG4.cpp:69-73
+    static constexpr int KIND = 4, W = 6, NE = 3, NO = 2, NB = 5;
+    // even: E0=G41 E1=G42 E2=G45 ; odd: O0=G43 O1=G44 (ids 3,4)
+    __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 3, 2, 4, 1}; return t[p]; }
+    __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 4, 2, 3, 0}; return t[p]; }
+    static constexpr int even_member(int r) { constexpr int t[NE] = {0, 1, 4}; return t[r]; }
+    static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3}; return t[r]; }
+    static constexpr int dup_a = 1, dup_b = 6;
+    static constexpr int PLANE0 = 0, HALF = 1;
+};
+
+struct BankG4H {  // planes h4a..h4f, SteerableFiltersG4.cpp:75-80
+    static constexpr int KIND = 4, W = 6, NE = 3, NO = 3, NB = 6;
+    // even: E0=H42 E1=H43 E2=H46 ; odd: O0=H41 O1=H44 O2=H45 (ids 3,4,5)
+    __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {3, 1, 5, 2, 4, 0}; return t[p]; }
+    __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {0, 4, 2, 5, 1, 3}; return t[p]; }
+    static constexpr int even_member(int r) { constexpr int t[NE] = {6, 7, 10}; return t[r]; }
+    static constexpr int odd_member(int r) { constexpr int t[NO] = {5, 8, 9}; return t[r]; }
+    static constexpr int dup_a = 1, dup_b = 6;
+    static constexpr int PLANE0 = 5, HALF = 2;
 };
 
 // folded taps: ev[r][i] = tap at offset +/-i (i = 0..W); od[r][i-1] = tap at offset +i (i = 1..W)
@@ -223,7 +250,7 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
                 const unsigned orow = (unsigned)yout * pitch_b;
 #pragma unroll
                 for (int p = 0; p < NB; ++p)
-                    bst<STREAM>(plane_rsrc(a.basis + (size_t)p * a.plane_stride, plane_bytes), xb, orow, b[p]);
+                    bst<STREAM>(plane_rsrc(a.basis + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xb, orow, b[p]);
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
                     float c1, c2, c3, th, st;
                     g2_orientation(b, a.atan_mode, c1, c2, c3, th, st);
@@ -253,13 +280,27 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
                     }
                 }
                 if constexpr ((FLAGS & F_STEER) != 0) {
-                    float gq, hq;
-                    if constexpr (B::KIND == 2) g2_steer_weights(b, a.steer_w, gq, hq);
-                    else g4_steer_weights(b, a.steer_w, gq, hq);
-                    bst<STREAM>(plane_rsrc(a.steer_g, (size_t)a.rows * a.steer_g_pitch * sizeof(float)), xb,
-                                (unsigned)yout * (unsigned)(a.steer_g_pitch * sizeof(float)), gq);
-                    bst<STREAM>(plane_rsrc(a.steer_h, (size_t)a.rows * a.steer_h_pitch * sizeof(float)), xb,
-                                (unsigned)yout * (unsigned)(a.steer_h_pitch * sizeof(float)), hq);
+                    const rsrc_t rg = plane_rsrc(a.steer_g, (size_t)a.rows * a.steer_g_pitch * sizeof(float));
+                    const rsrc_t rh = plane_rsrc(a.steer_h, (size_t)a.rows * a.steer_h_pitch * sizeof(float));
+                    const unsigned og = (unsigned)yout * (unsigned)(a.steer_g_pitch * sizeof(float));
+                    const unsigned oh = (unsigned)yout * (unsigned)(a.steer_h_pitch * sizeof(float));
+                    if constexpr (B::HALF == 0) {
+                        float gq, hq;
+                        if constexpr (B::KIND == 2) g2_steer_weights(b, a.steer_w, gq, hq);
+                        else g4_steer_weights(b, a.steer_w, gq, hq);
+                        bst<STREAM>(rg, xb, og, gq);
+                        bst<STREAM>(rh, xb, oh, hq);
+                    } else if constexpr (B::HALF == 1) {  // G4.cpp:120, summed left to right
+                        float gq = __fadd_rn(__fmul_rn(a.steer_w[0], b[0]), __fmul_rn(a.steer_w[1], b[1]));
+#pragma unroll
+                        for (int p = 2; p < 5; ++p) gq = __fadd_rn(gq, __fmul_rn(a.steer_w[p], b[p]));
+                        bst<STREAM>(rg, xb, og, gq);
+                    } else {  // G4.cpp:121
+                        float hq = __fadd_rn(__fmul_rn(a.steer_w[5], b[0]), __fmul_rn(a.steer_w[6], b[1]));
+#pragma unroll
+                        for (int p = 2; p < 6; ++p) hq = __fadd_rn(hq, __fmul_rn(a.steer_w[5 + p], b[p]));
+                        bst<STREAM>(rh, xb, oh, hq);
+                    }
                 }
             }
         }
@@ -447,6 +488,14 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
         if (fold_taps<BankG2>(taps, f)) return launch_fast<BankG2>(a, f, s);
     }
     if (kind == 4 && width == BankG4::W) {
+        if (a.g4_split) {
+            Folded<BankG4G> fg;
+            Folded<BankG4H> fh;
+            if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh)) {
+                hipError_t e = launch_fast<BankG4G>(a, fg, s);
+                return e != hipSuccess ? e : launch_fast<BankG4H>(a, fh, s);
+            }
+        }
         Folded<BankG4> f;
         if (fold_taps<BankG4>(taps, f)) return launch_fast<BankG4>(a, f, s);
     }

@@ -62,6 +62,7 @@ enum {
     CVS_OPT_STRIP_ROWS = 2,  /* rows per wave strip of the basis kernel (tuning; 0 = default) */
     CVS_OPT_FIND_ON = 3,     /* cvs_pipeline: 0 = find*(magnitude, phase) as the reference's callers do
                                 (test/test.cpp:88-90), 1 = find*(e, phase) */
+    CVS_OPT_G4_SPLIT = 5,    /* G4: 1 = G half and H half as two launches (default), 0 = one 11-plane launch */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
                                 256 MiB Infinity Cache), 1 = plain, 2 = always nontemporal (tuning) */
 };

@@ -22,15 +22,16 @@ def main():
     for kind, cls, bpp in (("G2", cv.SteerableFiltersG2, 32), ("G4", cv.SteerableFiltersG4, 48)):
         f = cls(None)
         nt_, halo = (9, 8) if kind == "G2" else (13, 12)
-        for pol in (1, 2):
+        for pol, split in ((1, 1), (2, 1), (2, 0)) if kind == "G4" else ((1, 1), (2, 1)):
             f.set_option(L.OPT_STORE_POLICY, pol)
+            f.set_option(L.OPT_G4_SPLIT, split)
             for k in (2, 3, 4, 6, 8, 11, 15, 22):
                 sr = k * nt_ - halo
                 f.set_strip_rows(sr)
                 ms = timeit(lambda: f.setup(img, flags=cv.SETUP_BASIS))
                 ms2 = timeit(lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h)))
-                print("%s policy=%s strip_rows=%3d  basis %.4f ms %7.0f Mpix/s %6.0f GB/s (%.1f%%) | +steer %.4f ms %7.0f Mpix/s %6.0f GB/s" % (
-                    kind, "plain" if pol == 1 else "nt", sr, ms, n*n/ms/1e3, bpp*n*n/ms/1e6, bpp*n*n/ms/1e6/80,
+                print("%s split=%d policy=%s strip_rows=%3d  basis %.4f ms %7.0f Mpix/s %6.0f GB/s (%.1f%%) | +steer %.4f ms %7.0f Mpix/s %6.0f GB/s" % (
+                    kind, split, "plain" if pol == 1 else "nt", sr, ms, n*n/ms/1e3, bpp*n*n/ms/1e6, bpp*n*n/ms/1e6/80,
                     ms2, n*n/ms2/1e3, (bpp+8)*n*n/ms2/1e6), flush=True)
 
 if __name__ == "__main__":
