@@ -58,7 +58,7 @@ for k in sorted(write):
                              "WRITE_SIZE_bytes": write[k], "hbm_bytes_per_launch": f2 + write[k]}
 json.dump(summary, open(os.path.join(P, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 
-key = "cvs::k_basis<cvs::BankG2, 2, true>"
+key = "cvs::k_basis<cvs::BankG2, 2, true>"  # F_STEER, streaming stores: the headline kernel
 if key in summary["kernels"]:
     t = summary["kernels"][key]
     json.dump({"k_basis_g2_steer_4096": {"hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
@@ -66,5 +66,21 @@ if key in summary["kernels"]:
                                          "algorithmic_bytes_per_launch": 40 * 4096 * 4096,
                                          "source": "profiles/%s_pmc_traffic.json" % rnd}},
               open(os.path.join(P, "traffic.json"), "w"), indent=1)
+# 3. SQ issue/occupancy counters (own pass)
+sq = collections.defaultdict(lambda: collections.defaultdict(list))
+for fn in glob.glob(os.path.join(G, "pmc_SQ", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(fn)):
+        k = short(r["Kernel_Name"])
+        if "cvs::" in k:
+            sq[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if sq:
+    with open(os.path.join(P, "%s_pmc_sq.csv" % rnd), "w") as f:
+        w = csv.writer(f)
+        names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"]
+        w.writerow(["Kernel"] + names + ["wait_any_frac", "wait_inst_frac", "active_frac", "valu_frac"])
+        for k in sorted(sq):
+            m = {n: (sum(sq[k][n]) / len(sq[k][n]) if sq[k][n] else 0.0) for n in names}
+            wc = m["SQ_WAVE_CYCLES"] or 1.0
+            w.writerow([k] + ["%.6g" % m[n] for n in names] + ["%.3f" % (m[x] / wc) for x in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU")])
 print(open(os.path.join(P, "%s_kernel_stats.csv" % rnd)).read())
 print(json.dumps(summary["kernels"], indent=1)[:1500])
