@@ -324,18 +324,29 @@ class SteerableFiltersG2(SteerableFilters):
         self._check(lib().cvs_pipeline(self._h, C.byref(pi), arr), "cvs_pipeline")
         return tuple(outs)
 
-    def normalize_u8(self, plane):
-        """cv::normalize(plane, dst, 0, 255, NORM_MINMAX, CV_8UC1) on the GPU"""
+    def _to_u8(self, plane, gain):
         self._bind_stream(plane)
         pp = _plane(plane)
         if _is_torch(plane) and plane.is_cuda:
             dst = torch.empty(tuple(plane.shape), dtype=torch.uint8, device=plane.device)
-            rc = lib().cvs_normalize_u8(self._h, C.byref(pp), C.c_void_p(dst.data_ptr()), dst.stride(0), L.MEM_DEVICE)
+            ptr, step, mem = C.c_void_p(dst.data_ptr()), dst.stride(0), L.MEM_DEVICE
         else:
             dst = np.empty(plane.shape, np.uint8)
-            rc = lib().cvs_normalize_u8(self._h, C.byref(pp), C.c_void_p(dst.ctypes.data), dst.strides[0], L.MEM_HOST)
-        self._check(rc, "cvs_normalize_u8")
+            ptr, step, mem = C.c_void_p(dst.ctypes.data), dst.strides[0], L.MEM_HOST
+        if gain is None:
+            rc = lib().cvs_normalize_u8(self._h, C.byref(pp), ptr, step, mem)
+        else:
+            rc = lib().cvs_convert_u8(self._h, C.byref(pp), float(gain), 0.0, ptr, step, mem)
+        self._check(rc, "cvs_normalize_u8" if gain is None else "cvs_convert_u8")
         return dst
+
+    def normalize_u8(self, plane):
+        """cv::normalize(plane, dst, 0, 255, NORM_MINMAX, CV_8UC1) on the GPU"""
+        return self._to_u8(plane, None)
+
+    def convert_u8(self, plane, gain):
+        """plane.convertTo(dst, CV_8UC1, gain) on the GPU"""
+        return self._to_u8(plane, gain)
 
 
 class SteerableFiltersG4(SteerableFilters):

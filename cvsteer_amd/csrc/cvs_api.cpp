@@ -719,29 +719,45 @@ int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst)
     return finish(c);
 }
 
-int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem)
+static int to_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem, bool minmax, float alpha, float beta)
 {
     if (!h || !dst) return CVS_E_BADARG;
     int rc = check_plane(h, src, "src");
     if (rc) return rc;
     if (dst_step < (size_t)src->cols) return fail(h, CVS_E_SIZE, "dst_step");
     if (dst_mem != CVS_MEM_HOST && dst_mem != CVS_MEM_DEVICE) return fail(h, CVS_E_BADARG, "dst_mem");
-    const size_t u8_elems = dst_mem == CVS_MEM_HOST ? round_up(round_up((size_t)src->cols, 256) * src->rows / 4 + 64, 64) : 0;
+    const size_t dpitch = round_up((size_t)src->cols, 256);
+    const size_t u8_elems = dst_mem == CVS_MEM_HOST ? round_up(dpitch * src->rows / 4 + 64, 64) : 0;
     Call c;
     if ((rc = begin(h, c, {src}, u8_elems))) return rc;
     PlaneRef in;
     if ((rc = in_ref(c, src, in))) return rc;
-    HIP_TRY(h, launch_minmax(in.p, in.pitch, src->rows, src->cols, h->minmax, h->stream));
-    if (dst_mem == CVS_MEM_DEVICE) {
-        HIP_TRY(h, launch_quantize_u8(in.p, in.pitch, src->rows, src->cols, h->minmax, dst, dst_step, h->stream));
-        return finish(c);
+    uint8_t* d = dst;
+    size_t dstep = dst_step;
+    if (dst_mem == CVS_MEM_HOST) {
+        d = reinterpret_cast<uint8_t*>(arena_take(h, u8_elems));
+        dstep = dpitch;
     }
-    const size_t dpitch = round_up((size_t)src->cols, 256);
-    uint8_t* d = reinterpret_cast<uint8_t*>(arena_take(h, u8_elems));
-    HIP_TRY(h, launch_quantize_u8(in.p, in.pitch, src->rows, src->cols, h->minmax, d, dpitch, h->stream));
-    HIP_TRY(h, hipMemcpy2DAsync(dst, dst_step, d, dpitch, (size_t)src->cols, src->rows, hipMemcpyDeviceToHost, h->stream));
+    if (minmax) {
+        HIP_TRY(h, launch_minmax(in.p, in.pitch, src->rows, src->cols, h->minmax, h->stream));
+        HIP_TRY(h, launch_quantize_u8(in.p, in.pitch, src->rows, src->cols, h->minmax, d, dstep, h->stream));
+    } else {
+        HIP_TRY(h, launch_convert_u8(in.p, in.pitch, src->rows, src->cols, alpha, beta, d, dstep, h->stream));
+    }
+    if (dst_mem == CVS_MEM_DEVICE) return finish(c);
+    HIP_TRY(h, hipMemcpy2DAsync(dst, dst_step, d, dstep, (size_t)src->cols, src->rows, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CVS_OK;
+}
+
+int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem)
+{
+    return to_u8(h, src, dst, dst_step, dst_mem, true, 0.f, 0.f);
+}
+
+int cvs_convert_u8(cvs_handle h, const cvs_plane* src, float alpha, float beta, uint8_t* dst, size_t dst_step, int dst_mem)
+{
+    return to_u8(h, src, dst, dst_step, dst_mem, false, alpha, beta);
 }
 
 }  // extern "C"

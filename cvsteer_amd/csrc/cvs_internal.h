@@ -85,6 +85,8 @@ hipError_t launch_minmax(const float* src, size_t pitch, int rows, int cols, flo
 hipError_t launch_quantize_u8(const float* src, size_t pitch, int rows, int cols, const float* minmax2,
                               uint8_t* dst, size_t dst_step, hipStream_t s);
 
+hipError_t launch_convert_u8(const float* src, size_t pitch, int rows, int cols, float alpha, float beta, uint8_t* dst,
+                             size_t dst_step, hipStream_t s);
 hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 
 // host-side tap math (cvs_taps.cpp, no HIP)

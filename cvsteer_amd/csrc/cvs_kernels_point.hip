@@ -279,6 +279,27 @@ hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, 
     return hipGetLastError();
 }
 
+// Mat::convertTo(dst, CV_8UC1, alpha, beta) (example/steer.cpp:94-96): saturate_cast<uchar>(v*alpha + beta)
+__global__ __launch_bounds__(256) void k_convert_u8(const float* src, size_t pitch, int rows, int cols, float alpha, float beta,
+                                                     uint8_t* dst, size_t dst_step)
+{
+    for (int row = blockIdx.y; row < rows; row += gridDim.y)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+            int q = __float2int_rn(__fadd_rn(__fmul_rn(src[(size_t)row * pitch + c], alpha), beta));
+            q = q < 0 ? 0 : q > 255 ? 255 : q;
+            dst[(size_t)row * dst_step + c] = (uint8_t)q;
+        }
+}
+
+hipError_t launch_convert_u8(const float* src, size_t pitch, int rows, int cols, float alpha, float beta, uint8_t* dst,
+                             size_t dst_step, hipStream_t s)
+{
+    int gx = (cols + 255) / 256; if (gx > 16) gx = 16;
+    int gy = rows > 256 ? 256 : rows;
+    hipLaunchKernelGGL(k_convert_u8, dim3(gx, gy), dim3(256), 0, s, src, pitch, rows, cols, alpha, beta, dst, dst_step);
+    return hipGetLastError();
+}
+
 hipError_t launch_minmax(const float* src, size_t pitch, int rows, int cols, float* minmax2, hipStream_t s)
 {
     int* mm = reinterpret_cast<int*>(minmax2);

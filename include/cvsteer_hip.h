@@ -172,6 +172,8 @@ int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst);
 /* per-image min/max (cv::normalize NORM_MINMAX, test.cpp:92-94 / steer.cpp:96-98) and the
  * 8-bit quantise that follows; dst is rows*cols bytes with dst_step bytes per row. */
 int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem);
+/* Mat::convertTo(dst, CV_8UC1, alpha, beta) -- the `--gain` branch of example/steer.cpp:92-97 */
+int cvs_convert_u8(cvs_handle h, const cvs_plane* src, float alpha, float beta, uint8_t* dst, size_t dst_step, int dst_mem);
 
 #ifdef __cplusplus
 }
