@@ -8,7 +8,7 @@ _SO = os.path.join(_HERE, "libcvsteer_hip.so")
 OK, E_BADARG, E_SIZE, E_HIP, E_NOMEM, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 KIND_G2, KIND_G4 = 2, 4
 MEM_HOST, MEM_DEVICE = 0, 1
-OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON, OPT_STORE_POLICY, OPT_G4_SPLIT = 1, 2, 3, 4, 5
+OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON, OPT_STORE_POLICY, OPT_G4_SPLIT, OPT_BRANCH_FREE, OPT_PLANE_PAD, OPT_XCD_MAP = 1, 2, 3, 4, 5, 6, 7, 8
 PLANE_BASIS0, PLANE_C1, PLANE_C2, PLANE_C3, PLANE_THETA, PLANE_STRENGTH = 0, 32, 33, 34, 35, 36
 
 
@@ -61,6 +61,9 @@ SIGNATURES = {
     "cvs_phase_weights": (C.c_int, [C.c_void_p, _PP, _PP, C.c_float, C.c_int, C.c_float]),
     "cvs_find": (C.c_int, [C.c_void_p, _PP, _PP, _PP, _PP, _PP]),
     "cvs_pipeline": (C.c_int, [C.c_void_p, _PP, C.POINTER(_PP)]),
+    "cvs_pipeline_batch": (C.c_int, [C.c_void_p, _PP, C.c_int, _PP]),
+    "cvs_select_frame": (C.c_int, [C.c_void_p, C.c_int]),
+    "cvs_num_frames": (C.c_int, [C.c_void_p, _IP]),
     "cvs_pyr_down": (C.c_int, [C.c_void_p, _PP, _PP]),
     "cvs_normalize_u8": (C.c_int, [C.c_void_p, _PP, C.c_void_p, C.c_size_t, C.c_int]),
     "cvs_convert_u8": (C.c_int, [C.c_void_p, _PP, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_int]),

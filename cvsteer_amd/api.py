@@ -324,6 +324,29 @@ class SteerableFiltersG2(SteerableFilters):
         self._check(lib().cvs_pipeline(self._h, C.byref(pi), arr), "cvs_pipeline")
         return tuple(outs)
 
+    def pipeline_batch(self, frames, out=None):
+        """pipeline() for n same-size frames in one launch.  frames: [n, H, W] tensor/array (or a list
+        of planes); returns / fills out [n, 8, H, W].  select_frame(i) then picks whose state the
+        getters and steer() use."""
+        planes = [_as_input(f) for f in frames]
+        n = len(planes)
+        self._like = planes[0]
+        shape = tuple(planes[0].shape)
+        if out is None:
+            if _is_torch(planes[0]):
+                out = torch.empty((n, 8) + shape, dtype=torch.float32, device=planes[0].device)
+            else:
+                out = np.empty((n, 8) + shape, np.float32)
+        self._bind_stream(planes[0], out[0][0])
+        imgs = (Plane * n)(*[_plane(p) for p in planes])
+        outs = (Plane * (n * 8))(*[_plane(out[i][k]) for i in range(n) for k in range(8)])
+        self._check(lib().cvs_pipeline_batch(self._h, imgs, n, outs), "cvs_pipeline_batch")
+        self._batch_keepalive = (planes, out)
+        return out
+
+    def select_frame(self, i):
+        self._check(lib().cvs_select_frame(self._h, int(i)), "cvs_select_frame")
+
     def _to_u8(self, plane, gain):
         self._bind_stream(plane)
         pp = _plane(plane)

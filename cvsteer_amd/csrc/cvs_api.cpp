@@ -32,11 +32,17 @@ struct cvs_context {
     float* state = nullptr;
     size_t state_elems = 0;
     bool have_basis = false, have_orient = false;
+    // batched state: num_frames blocks of (nb+5) planes; cur_frame selects the block all state
+    // accessors and steer calls address
+    int num_frames = 1, cur_frame = 0;
+    size_t frame_stride = 0;
+    BatchFrame* frame_tab = nullptr;
+    int frame_tab_cap = 0;
     // staging arena for host planes and scratch (bump allocated per call)
     float* arena = nullptr;
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1, branch_free = 0, plane_pad = 0, xcd_map = 0;
     std::string err;
 };
 
@@ -180,13 +186,16 @@ int begin(cvs_handle h, Call& c, std::initializer_list<const cvs_plane*> planes,
     return CVS_OK;
 }
 
-float* state_plane(cvs_handle h, int idx) { return h->state + (size_t)idx * h->plane_stride; }
+float* state_plane(cvs_handle h, int idx)
+{
+    return h->state + (size_t)h->cur_frame * h->frame_stride + (size_t)idx * h->plane_stride;
+}
 
-int ensure_state(cvs_handle h, int rows, int cols)
+int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
 {
     const size_t pitch = round_up((size_t)cols, 64);
-    const size_t stride = round_up(pitch * rows, 64);
-    const size_t elems = stride * (h->nb + 5);
+    const size_t stride = round_up(pitch * rows, 64) + (size_t)h->plane_pad;
+    const size_t elems = stride * (h->nb + 5) * (size_t)nframes;
     if (elems > h->state_elems) {
         if (h->state) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -201,6 +210,9 @@ int ensure_state(cvs_handle h, int rows, int cols)
     h->cols = cols;
     h->pitch = pitch;
     h->plane_stride = stride;
+    h->frame_stride = stride * (h->nb + 5);
+    h->num_frames = nframes;
+    if (h->cur_frame >= nframes) h->cur_frame = 0;
     return CVS_OK;
 }
 
@@ -235,7 +247,7 @@ int use_nt_stores(cvs_handle h, size_t npix)
 }
 
 int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, float theta, const cvs_plane* g,
-             const cvs_plane* hq, const cvs_plane* const* pipe_outs = nullptr)
+             const cvs_plane* hq, const cvs_plane* const* pipe_outs = nullptr, int nframes = 1, int frame = 0)
 {
     if (!h) return CVS_E_BADARG;
     int rc = check_plane(h, image, "image");
@@ -262,7 +274,8 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     rc = begin(h, c, {image, steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7]}, scratch);
     if (rc) return rc;
     h->have_basis = h->have_orient = false;
-    if ((rc = ensure_state(h, image->rows, image->cols))) return rc;
+    if ((rc = ensure_state(h, image->rows, image->cols, nframes))) return rc;
+    h->cur_frame = frame;
 
     BasisArgs a{};
     PlaneRef in;
@@ -271,7 +284,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.in_pitch = in.pitch;
     a.rows = image->rows;
     a.cols = image->cols;
-    a.basis = h->state;
+    a.basis = state_plane(h, 0);
     a.pitch = h->pitch;
     a.plane_stride = h->plane_stride;
     a.orient = (flags & CVS_SETUP_ORIENT) ? state_plane(h, h->nb) : nullptr;
@@ -279,6 +292,8 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.strip_rows = default_strip_rows(h, a.rows, a.cols);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     a.g4_split = h->g4_split;
+    a.branch_free = h->branch_free;
+    a.xcd_map = h->xcd_map;
     if (steer) {
         PlaneRef rg, rh;
         if ((rc = out_ref(c, g, rg)) || (rc = out_ref(c, hq, rh))) return rc;
@@ -431,6 +446,7 @@ int cvs_destroy(cvs_handle h)
     if (h->state) (void)hipFree(h->state);
     if (h->arena) (void)hipFree(h->arena);
     if (h->minmax) (void)hipFree(h->minmax);
+    if (h->frame_tab) (void)hipFree(h->frame_tab);
     delete h;
     return CVS_OK;
 }
@@ -468,6 +484,19 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "g4 split");
             h->g4_split = value;
             return CVS_OK;
+        case CVS_OPT_PLANE_PAD:
+            if (value < 0 || value > (1 << 24) || value % 64) return fail(h, CVS_E_BADARG, "plane pad");
+            h->plane_pad = value;
+            h->state_elems = h->state_elems;  // takes effect at the next setup
+            return CVS_OK;
+        case CVS_OPT_XCD_MAP:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "xcd map");
+            h->xcd_map = value;
+            return CVS_OK;
+        case CVS_OPT_BRANCH_FREE:
+            if (value < -1 || value > 1) return fail(h, CVS_E_BADARG, "branch free");
+            h->branch_free = value;
+            return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -481,6 +510,9 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_FIND_ON: *value = h->find_on; return CVS_OK;
         case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
+        case CVS_OPT_BRANCH_FREE: *value = h->branch_free; return CVS_OK;
+        case CVS_OPT_PLANE_PAD: *value = h->plane_pad; return CVS_OK;
+        case CVS_OPT_XCD_MAP: *value = h->xcd_map; return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -703,6 +735,102 @@ int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const ou
     }
     // one launch: filter bank, orientation and the whole caller sequence in the kernel's epilogue
     return do_setup(h, image, CVS_SETUP_FULL, false, 0.f, nullptr, nullptr, outs);
+}
+
+int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_plane* outs)
+{
+    if (!h || !images || n < 1) return CVS_E_BADARG;
+    if (h->kind != CVS_KIND_G2) return fail(h, CVS_E_UNSUPPORTED, "the caller pipeline exists for G2 only");
+    int rc;
+    const int rows = images[0].rows, cols = images[0].cols;
+    bool all_dev = true;
+    size_t max_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((rc = check_plane(h, &images[i], "image")) || (rc = check_same(h, &images[i], rows, cols))) return rc;
+        all_dev = all_dev && images[i].mem == CVS_MEM_DEVICE;
+        max_bytes = std::max(max_bytes, (size_t)rows * images[i].step);
+        for (int k = 0; outs && k < 8; ++k) {
+            const cvs_plane* o = &outs[(size_t)i * 8 + k];
+            if (!o->data) continue;
+            if ((rc = check_plane(h, o, "out")) || (rc = check_same(h, o, rows, cols))) return rc;
+            all_dev = all_dev && o->mem == CVS_MEM_DEVICE;
+            max_bytes = std::max(max_bytes, (size_t)rows * o->step);
+        }
+    }
+    const size_t pitch = round_up((size_t)cols, 64);
+    const bool fast = all_dev && !basis_may_need_scratch(h->kind, h->width, h->taps, rows, cols, std::max(pitch, max_bytes / sizeof(float) / rows));
+    if (!fast) {
+        // host planes, tiny images or non-default taps: frame by frame through the single-image path
+        for (int i = 0; i < n; ++i) {
+            const cvs_plane* po[8];
+            for (int k = 0; k < 8; ++k) po[k] = (outs && outs[(size_t)i * 8 + k].data) ? &outs[(size_t)i * 8 + k] : nullptr;
+            if ((rc = do_setup(h, &images[i], CVS_SETUP_FULL, false, 0.f, nullptr, nullptr, po, n, i))) return rc;
+        }
+        h->cur_frame = 0;
+        return CVS_OK;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->have_basis = h->have_orient = false;
+    if ((rc = ensure_state(h, rows, cols, n))) return rc;
+    h->cur_frame = 0;
+    if (n > h->frame_tab_cap) {
+        if (h->frame_tab) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipFree(h->frame_tab));
+            h->frame_tab = nullptr;
+            h->frame_tab_cap = 0;
+        }
+        HIP_TRY(h, hipMalloc(&h->frame_tab, (size_t)n * sizeof(BatchFrame)));
+        h->frame_tab_cap = n;
+    }
+    std::vector<BatchFrame> tab(n);
+    for (int i = 0; i < n; ++i) {
+        tab[i].in = images[i].data;
+        tab[i].in_pitch = images[i].step / sizeof(float);
+        for (int k = 0; k < 8; ++k) {
+            const cvs_plane* o = outs ? &outs[(size_t)i * 8 + k] : nullptr;
+            tab[i].out[k] = (o && o->data) ? PlaneRef{o->data, o->step / sizeof(float)} : PlaneRef{nullptr, 0};
+        }
+    }
+    // pageable source: the runtime stages it before returning, so `tab` may go out of scope
+    HIP_TRY(h, hipMemcpyAsync(h->frame_tab, tab.data(), (size_t)n * sizeof(BatchFrame), hipMemcpyHostToDevice, h->stream));
+    BasisArgs a{};
+    a.rows = rows;
+    a.cols = cols;
+    a.in_pitch = pitch;
+    a.basis = h->state;
+    a.pitch = h->pitch;
+    a.plane_stride = h->plane_stride;
+    a.orient = h->state + (size_t)h->nb * h->plane_stride;
+    a.atan_mode = h->atan_mode;
+    a.strip_rows = default_strip_rows(h, rows, cols);
+    a.nt_stores = use_nt_stores(h, (size_t)rows * cols * n);
+    a.pipe = 1;
+    a.find_on_e = h->find_on;
+    a.frames = h->frame_tab;
+    a.g4_split = h->g4_split;
+    a.branch_free = 0;
+    a.xcd_map = h->xcd_map;
+    a.batch = n;
+    a.frame_stride = h->frame_stride;
+    HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream));
+    h->have_basis = h->have_orient = true;
+    return CVS_OK;
+}
+
+int cvs_select_frame(cvs_handle h, int frame)
+{
+    if (!h) return CVS_E_BADARG;
+    if (frame < 0 || frame >= h->num_frames) return fail(h, CVS_E_BADARG, "frame index");
+    h->cur_frame = frame;
+    return CVS_OK;
+}
+
+int cvs_num_frames(cvs_handle h, int* n)
+{
+    if (!h || !n) return CVS_E_BADARG;
+    *n = h->have_basis ? h->num_frames : 0;
+    return CVS_OK;
 }
 
 int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst)

@@ -16,6 +16,13 @@ struct PlaneRef {
     size_t pitch;   // elements
 };
 
+// per-frame pointers of a batched launch (device-resident table, one entry per frame = blockIdx.z)
+struct BatchFrame {
+    const float* in;
+    size_t in_pitch;
+    PlaneRef out[8];   // g2,h2,e,mag,phase,edges,dark,bright (any may be {nullptr,0})
+};
+
 // One launch of the fused basis kernel ("K1").  All pitches/strides are in ELEMENTS.
 struct BasisArgs {
     const float* in;      // image, device
@@ -34,10 +41,18 @@ struct BasisArgs {
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 1 = run the G4 bank as two launches (G half, H half)
+    int branch_free;      // 1 = G2 row loop without the store branch (more stores in flight)
+    int xcd_map;          // 1 = 1-D grid, row bands pinned to XCDs (see k_basis)
+    int grid_x, grid_y;   // filled by the launcher
     // fused caller pipeline (needs orient): g2,h2,e,mag,phase,edges,dark,bright at theta_dom
     int pipe;             // 1 = run the pipeline epilogue
     int find_on_e;        // 1 = find*(e, phase), 0 = find*(magnitude, phase)
     PlaneRef pipe_out[8]; // any entry may be {nullptr, 0}
+    // batched launch: n frames of identical geometry, frame z takes in/out from frames[z] and its
+    // state planes at basis + z*frame_stride (orient likewise)
+    const BatchFrame* frames;  // device pointer, or nullptr = single image
+    int batch;
+    size_t frame_stride;       // elements between the state blocks of consecutive frames
 };
 
 // taps[i] = the handle's i-th tap vector (member order), 2*width+1 floats each

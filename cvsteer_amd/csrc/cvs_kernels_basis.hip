@@ -132,7 +132,7 @@ __device__ __forceinline__ void bst(rsrc_t r, unsigned lane_off, unsigned row_of
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_off, row_off, STREAM ? 2 : 0);  // aux 2 = nt
 }
 
-template <class B, int FLAGS, bool STREAM>
+template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool BF = false>
 __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B> t)
 {
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
@@ -141,9 +141,21 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int x0 = (blockIdx.x * 4 + wv) * 64;
+    // workgroup -> (column block bx, row band by).  With xcd_map the grid is 1-D and consecutive ids,
+    // which the dispatcher deals round-robin over the 8 XCDs, are spread so that every row band is
+    // filtered by ONE XCD walking along x: the DRAM pages / TLB entries of a band's output rows are
+    // then touched from a single XCD (placement is an observed behaviour -- speed only, never
+    // correctness).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd_map) {
+        const int id = blockIdx.x, t = id >> 3;
+        bx = t % a.grid_x;
+        by = (t / a.grid_x) * 8 + (id & 7);
+        if (by >= a.grid_y) return;
+    }
+    const int x0 = (bx * 4 + wv) * 64;
     if (x0 >= a.cols) return;  // wave-uniform; waves of a workgroup never rendezvous
-    const int y0 = blockIdx.y * a.strip_rows;
+    const int y0 = by * a.strip_rows;
     const int yend = min(y0 + a.strip_rows, a.rows);
     const int x = x0 + lane;
     const bool xin = x < a.cols;
@@ -156,13 +168,29 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
     const unsigned xb = xin ? (unsigned)x * 4u : kLaneOff;
     const unsigned xmb = (unsigned)xm * 4u;
     const unsigned xhb = is_halo ? (unsigned)xh * 4u : kLaneOff;
-    const int hslot = lane < W ? lane : 64 + lane;  // left halo -> [0,W), right -> [64+W, 64+2W)
+    // left halo -> [0,W), right -> [64+W, 64+2W); lanes that carry no halo value write into the
+    // 4 pad words behind the line, so the staging code has no exec-mask branch
+    const int hslot = lane < W ? lane : (is_halo ? 64 + lane : LW + (lane & 3));
     float* line = lds[wv];
+    // per-frame pointers: kernel arguments, or (batched launch) entry blockIdx.z of the frame table
+    const float* in_p = a.in;
+    size_t in_pitch = a.in_pitch;
+    float* basis_p = a.basis;
+    float* orient_p = a.orient;
+    const PlaneRef* pipe_out = a.pipe_out;
+    if constexpr (BATCH) {
+        const BatchFrame* fr = a.frames + blockIdx.z;
+        in_p = fr->in;
+        in_pitch = fr->in_pitch;
+        basis_p += (size_t)blockIdx.z * a.frame_stride;
+        orient_p += (size_t)blockIdx.z * a.frame_stride;
+        pipe_out = fr->out;
+    }
     // buffer resources (wave-uniform): input plane, state planes
     const size_t plane_bytes = (size_t)a.rows * a.pitch * sizeof(float);
     const unsigned pitch_b = (unsigned)(a.pitch * sizeof(float));
-    const rsrc_t r_in = plane_rsrc(a.in, (size_t)a.rows * a.in_pitch * sizeof(float));
-    const unsigned in_pitch_b = (unsigned)(a.in_pitch * sizeof(float));
+    const rsrc_t r_in = plane_rsrc(in_p, (size_t)a.rows * in_pitch * sizeof(float));
+    const unsigned in_pitch_b = (unsigned)(in_pitch * sizeof(float));
 
     float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
     float pre[NT], preh[NT];  // prefetched input rows (main lane value, halo-lane value)
@@ -195,7 +223,7 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
             }
             // ---- row pass: stage the line, read the 2W+1 neighbours ----
             line[W + lane] = v;
-            if (is_halo) line[hslot] = vh;
+            line[hslot] = vh;
             wave_lds_fence();
             float s[NT];
 #pragma unroll
@@ -224,8 +252,16 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
             }
 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----
+            // Rows outside [y0, yend) (the first 2W rows of a strip prime the window; the last group may
+            // overshoot) run the same straight-line code with their stores switched off through the
+            // lane offset: no branch, so the compiler sees a fixed 2-loads + NB-stores pattern per row
+            // and lets several rows of stores stay in flight instead of draining them at each wait.
             const int yout = y0 + g * NT + j - 2 * W;
-            if (yout >= y0 && yout < yend) {  // wave-uniform
+            const bool row_ok = yout >= y0 && yout < yend;  // wave-uniform
+            // (BF template flag; chosen per variant by the launcher from measurements: it pays where the
+            // epilogue is light, and costs where skipped rows would run a heavy epilogue for nothing.)
+            const unsigned xbr = (BF && !row_ok) ? kLaneOff : xb;
+            if (BF || row_ok) {
                 float b[NB];
 #pragma unroll
                 for (int p = 0; p < NB; ++p) {
@@ -247,17 +283,18 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
                     b[p] = acc;
                 }
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
-                const unsigned orow = (unsigned)yout * pitch_b;
+                const unsigned yo = row_ok ? (unsigned)yout : 0u;
+                const unsigned orow = yo * pitch_b;
 #pragma unroll
                 for (int p = 0; p < NB; ++p)
-                    bst<STREAM>(plane_rsrc(a.basis + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xb, orow, b[p]);
+                    bst<STREAM>(plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orow, b[p]);
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
                     float c1, c2, c3, th, st;
                     g2_orientation(b, a.atan_mode, c1, c2, c3, th, st);
                     const float ov[5] = {c1, c2, c3, th, st};
 #pragma unroll
                     for (int k = 0; k < 5; ++k)
-                        bst<STREAM>(plane_rsrc(a.orient + (size_t)k * a.plane_stride, plane_bytes), xb, orow, ov[k]);
+                        bst<STREAM>(plane_rsrc(orient_p + (size_t)k * a.plane_stride, plane_bytes), xbr, orow, ov[k]);
                     if constexpr ((FLAGS & F_PIPE) != 0) {
                         // the callers' sequence (test/test.cpp:86-90) on values still in registers:
                         // steer at theta_dom, energy, magnitude/phase, the three feature maps
@@ -274,32 +311,32 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
                         q[7] = __fmul_rn(en, phase_lambda<true>(q[4], kPiF, true));
 #pragma unroll
                         for (int k = 0; k < 8; ++k)
-                            if (a.pipe_out[k].p)
-                                bst<STREAM>(plane_rsrc(a.pipe_out[k].p, (size_t)a.rows * a.pipe_out[k].pitch * sizeof(float)), xb,
-                                            (unsigned)yout * (unsigned)(a.pipe_out[k].pitch * sizeof(float)), q[k]);
+                            if (pipe_out[k].p)
+                                bst<STREAM>(plane_rsrc(pipe_out[k].p, (size_t)a.rows * pipe_out[k].pitch * sizeof(float)), xbr,
+                                            yo * (unsigned)(pipe_out[k].pitch * sizeof(float)), q[k]);
                     }
                 }
                 if constexpr ((FLAGS & F_STEER) != 0) {
                     const rsrc_t rg = plane_rsrc(a.steer_g, (size_t)a.rows * a.steer_g_pitch * sizeof(float));
                     const rsrc_t rh = plane_rsrc(a.steer_h, (size_t)a.rows * a.steer_h_pitch * sizeof(float));
-                    const unsigned og = (unsigned)yout * (unsigned)(a.steer_g_pitch * sizeof(float));
-                    const unsigned oh = (unsigned)yout * (unsigned)(a.steer_h_pitch * sizeof(float));
+                    const unsigned og = yo * (unsigned)(a.steer_g_pitch * sizeof(float));
+                    const unsigned oh = yo * (unsigned)(a.steer_h_pitch * sizeof(float));
                     if constexpr (B::HALF == 0) {
                         float gq, hq;
                         if constexpr (B::KIND == 2) g2_steer_weights(b, a.steer_w, gq, hq);
                         else g4_steer_weights(b, a.steer_w, gq, hq);
-                        bst<STREAM>(rg, xb, og, gq);
-                        bst<STREAM>(rh, xb, oh, hq);
+                        bst<STREAM>(rg, xbr, og, gq);
+                        bst<STREAM>(rh, xbr, oh, hq);
                     } else if constexpr (B::HALF == 1) {  // G4.cpp:120, summed left to right
                         float gq = __fadd_rn(__fmul_rn(a.steer_w[0], b[0]), __fmul_rn(a.steer_w[1], b[1]));
 #pragma unroll
                         for (int p = 2; p < 5; ++p) gq = __fadd_rn(gq, __fmul_rn(a.steer_w[p], b[p]));
-                        bst<STREAM>(rg, xb, og, gq);
+                        bst<STREAM>(rg, xbr, og, gq);
                     } else {  // G4.cpp:121
                         float hq = __fadd_rn(__fmul_rn(a.steer_w[5], b[0]), __fmul_rn(a.steer_w[6], b[1]));
 #pragma unroll
                         for (int p = 2; p < 6; ++p) hq = __fadd_rn(hq, __fmul_rn(a.steer_w[5 + p], b[p]));
-                        bst<STREAM>(rh, xb, oh, hq);
+                        bst<STREAM>(rh, xbr, oh, hq);
                     }
                 }
             }
@@ -389,19 +426,45 @@ bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], 
 }
 
 template <class B>
-static hipError_t launch_fast(const BasisArgs& a, const Folded<B>& f, hipStream_t s)
+static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStream_t s)
 {
+    BasisArgs a = a_in;
     const int strips_x = (a.cols + 63) / 64;
     dim3 grid((strips_x + 3) / 4, (a.rows + a.strip_rows - 1) / a.strip_rows);
+    a.grid_x = grid.x;
+    a.grid_y = grid.y;
+    if (a.xcd_map) grid = dim3(a.grid_x * ((a.grid_y + 7) / 8) * 8, 1);
     dim3 block(256);
     const bool orient = a.orient != nullptr && B::KIND == 2;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
+    if (a.frames) {  // batched caller pipeline: one launch, grid.z = frames (G2 only)
+        if constexpr (B::KIND == 2 && B::HALF == 0) {
+            grid.z = a.batch;
+            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, F_ORIENT | F_PIPE, true, true>), grid, block, 0, s, a, f);
+            else hipLaunchKernelGGL((k_basis<B, F_ORIENT | F_PIPE, false, true>), grid, block, 0, s, a, f);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     const bool pipe = orient && a.pipe;
     const int flags = pipe ? (F_ORIENT | F_PIPE) : ((orient ? F_ORIENT : 0) | (steer ? F_STEER : 0));
-#define CVS_LAUNCH(FL)                                                                         \
-    do {                                                                                       \
-        if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true>), grid, block, 0, s, a, f);  \
-        else hipLaunchKernelGGL((k_basis<B, FL, false>), grid, block, 0, s, a, f);             \
+    // interleaved A/B on MI355X (tools/ab.py): the branch-free loop is neutral for the basis / steer
+    // variants (74.0 vs 73.6 %, 71.0 vs 71.2 %) and loses where skipped rows run a heavy epilogue for
+    // nothing (pipeline 65 -> 47 %), so it stays an experiment switch, off by default
+    const int bf = a.branch_free > 0;
+    (void)bf;
+#define CVS_LAUNCH(FL)                                                                                        \
+    do {                                                                                                      \
+        if constexpr (B::KIND == 2) {                                                                         \
+            if (bf) {                                                                                         \
+                if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, false, true>), grid, block, 0, s, a, f);   \
+                else hipLaunchKernelGGL((k_basis<B, FL, false, false, true>), grid, block, 0, s, a, f);              \
+                break;                                                                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+        if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true>), grid, block, 0, s, a, f);                 \
+        else hipLaunchKernelGGL((k_basis<B, FL, false>), grid, block, 0, s, a, f);                            \
     } while (0)
     if constexpr (B::KIND == 2) {
         switch (flags) {
@@ -482,6 +545,11 @@ static bool fast_geometry_ok(const BasisArgs& a, int width)
 hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
                         float* scratch, hipStream_t s)
 {
+    if (a.frames) {  // batched launch: the API layer has already checked geometry and taps
+        Folded<BankG2> f;
+        if (kind != 2 || width != BankG2::W || !fold_taps<BankG2>(taps, f)) return hipErrorInvalidValue;
+        return launch_fast<BankG2>(a, f, s);
+    }
     if (!fast_geometry_ok(a, width)) return launch_generic(kind, width, taps, a, scratch, s);
     if (kind == 2 && width == BankG2::W) {
         Folded<BankG2> f;

@@ -62,6 +62,9 @@ enum {
     CVS_OPT_STRIP_ROWS = 2,  /* rows per wave strip of the basis kernel (tuning; 0 = default) */
     CVS_OPT_FIND_ON = 3,     /* cvs_pipeline: 0 = find*(magnitude, phase) as the reference's callers do
                                 (test/test.cpp:88-90), 1 = find*(e, phase) */
+    CVS_OPT_XCD_MAP = 8,     /* basis kernel: 1 = pin row bands to XCDs through the block-id map (tuning) */
+    CVS_OPT_PLANE_PAD = 7,   /* extra f32 elements (multiple of 64) between consecutive state planes (tuning) */
+    CVS_OPT_BRANCH_FREE = 6, /* G2 row loop without the store branch: 0 = off (default), 1 = on (tuning) */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 1 = G half and H half as two launches (default), 0 = one 11-plane launch */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
                                 256 MiB Infinity Cache), 1 = plain, 2 = always nontemporal (tuning) */
@@ -163,6 +166,17 @@ int cvs_find(cvs_handle h, const cvs_plane* e, const cvs_plane* phase,
  * setup(FULL) -> steer(theta_dom, g2,h2,e,mag,phase) -> find*(mag|e, phase).
  * outs[8] = {g2, h2, e, magnitude, phase, edges, dark, bright}; any entry may be NULL. */
 int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const outs[8]);
+
+/* The batch axis (example/steer.cpp:69-124,169: one independent pipeline per file): cvs_pipeline for
+ * n images of identical size in ONE kernel launch (grid.z = frame).  outs is a flat array of n*8
+ * planes, frame-major, order {g2,h2,e,magnitude,phase,edges,dark,bright}; an entry with data == NULL
+ * is not written (outs == NULL: state only).  The state of every frame is kept; cvs_select_frame
+ * picks the frame that cvs_state_plane / cvs_read_state / cvs_steer_* address (default 0).
+ * Host planes, images too small for the fused kernel or non-default taps are processed frame by
+ * frame with the same results. */
+int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_plane* outs);
+int cvs_select_frame(cvs_handle h, int frame);
+int cvs_num_frames(cvs_handle h, int* n);
 
 /* One Gaussian-pyramid level (BASELINE config 3; absent from the reference): cv::pyrDown
  * semantics -- 5-tap [1 4 6 4 1]/16 separable blur, BORDER_REFLECT_101, every second pixel.

@@ -461,3 +461,48 @@ def test_cli_driver_matches_reference_goldens(ora, golden_dir, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     u8 = np.load(str(out / "fish_edges.npy"))
     assert u8.dtype == np.uint8 and u8.max() == 255
+
+
+def test_pipeline_batch_equals_per_frame(cv):
+    import torch
+    frames = torch.from_numpy(np.stack([smooth_image(120, 200) + 0.1 * rand_image(120, 200, seed=s) for s in range(5)])).cuda()
+    eng = cv.SteerableFiltersG2(None)
+    out = eng.pipeline_batch(frames)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (5, 8, 120, 200)
+    for i in range(5):
+        single = cv.SteerableFiltersG2(None)
+        ref = single.pipeline(frames[i])
+        for k in range(8):
+            assert torch.equal(out[i, k], ref[k]), (i, k)
+        # every frame's state is kept and addressable
+        eng.select_frame(i)
+        assert torch.equal(eng.getDominantOrientationAngle(), single.getDominantOrientationAngle())
+        assert torch.equal(eng.basis(4), single.basis(4))
+        g, h = eng.steer(0.3)
+        g1, h1 = single.steer(0.3)
+        assert torch.equal(g, g1) and torch.equal(h, h1)
+    with pytest.raises(cv.CvsError):
+        eng.select_frame(5)
+    # a later single-image setup drops back to one frame
+    eng.setup(frames[0])
+    with pytest.raises(cv.CvsError):
+        eng.select_frame(1)
+
+
+def test_pipeline_batch_fallback_paths(cv):
+    # host planes (staged frame by frame) and frames too small for the fused kernel: same results
+    host = np.stack([rand_image(40, 64, seed=s) for s in range(3)])
+    eng = cv.SteerableFiltersG2(None)
+    out = eng.pipeline_batch(host)
+    for i in range(3):
+        ref = cv.SteerableFiltersG2(None).pipeline(host[i])
+        for k in range(8):
+            assert np.array_equal(out[i, k], ref[k])
+    import torch
+    tiny = torch.rand((4, 9, 70), device="cuda")
+    out = cv.SteerableFiltersG2(None).pipeline_batch(tiny)
+    for i in range(4):
+        ref = cv.SteerableFiltersG2(None).pipeline(tiny[i])
+        for k in range(8):
+            assert torch.equal(out[i, k], ref[k])

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""tools/ab.py -- interleaved A/B rounds in ONE process (cdna guide rule 24): option values x legs."""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cvsteer_amd as cv
+from cvsteer_amd import _lib as L
+
+def timeit(fn, steps=20):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
+
+def main():
+    opt = int(sys.argv[1]) if len(sys.argv) > 1 else L.OPT_BRANCH_FREE
+    values = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
+    n = 4096
+    img = torch.rand((n, n), device="cuda")
+    g, h = torch.empty_like(img), torch.empty_like(img)
+    outs = [torch.empty_like(img) for _ in range(8)]
+    hs = {}
+    for v in values:
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(opt, v)
+        hs[v] = f
+    legs = {
+        "M1 basis": (lambda f: f.setup(img, flags=cv.SETUP_BASIS), 32),
+        "M2 +steer": (lambda f: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h)), 40),
+        "M4 full": (lambda f: f.setup(img, flags=cv.SETUP_FULL), 52),
+        "M5 pipeline": (lambda f: f.pipeline(img, out=outs), 84),
+    }
+    for name, (fn, bpp) in legs.items():
+        res = {v: [] for v in values}
+        for v in values:
+            for _ in range(5): fn(hs[v])
+        torch.cuda.synchronize()
+        for r in range(10):
+            for v in values:
+                res[v].append(timeit(lambda: fn(hs[v])))
+        line = "%-12s" % name
+        for v in values:
+            med, mn = statistics.median(res[v]), min(res[v])
+            line += " | opt=%2d med %.4f ms (%5.1f%%) min %.4f" % (v, med, bpp * n * n / med / 1e6 / 80, mn)
+        print(line, flush=True)
+
+if __name__ == "__main__":
+    main()
