@@ -15,7 +15,12 @@ def short(n):
     return n.replace("void ", "")
 
 # 1. kernel stats of `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu`
-stats = glob.glob(os.path.join(G, "prof_stats", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: keep only the most recent run's file"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+stats = newest(os.path.join(G, "prof_stats", "*", "*_kernel_stats.csv"))
 if stats:
     rows = [r for r in csv.DictReader(open(stats[0])) if "cvs::" in r["Name"]]
     with open(os.path.join(P, "%s_kernel_stats.csv" % rnd), "w") as f:
@@ -26,11 +31,19 @@ if stats:
     line = [l for l in open(os.path.join(G, "prof_stats.log")) if l.startswith("{")]
     if line:
         open(os.path.join(P, "%s_bench_under_rocprof.json" % rnd), "w").write(line[-1])
+allst = newest(os.path.join(G, "prof_stats_all", "*", "*_kernel_stats.csv"))
+if allst:
+    rows = [r for r in csv.DictReader(open(allst[0])) if "cvs::" in r["Name"]]
+    with open(os.path.join(P, "%s_kernel_stats_all_legs.csv" % rnd), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 # 2. PMC passes (separate runs, counters only): FETCH_SIZE / WRITE_SIZE per kernel, in KB
 def pmc(tag, sub):
     agg = collections.defaultdict(list)
-    for fn in glob.glob(os.path.join(G, sub % tag, "*", "*_counter_collection.csv")):
+    for fn in newest(os.path.join(G, sub % tag, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(fn)):
             if r["Counter_Name"] == tag:
                 agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
@@ -58,7 +71,7 @@ for k in sorted(write):
                              "WRITE_SIZE_bytes": write[k], "hbm_bytes_per_launch": f2 + write[k]}
 json.dump(summary, open(os.path.join(P, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 
-key = "cvs::k_basis<cvs::BankG2, 2, true>"  # F_STEER, streaming stores: the headline kernel
+key = "cvs::k_basis<cvs::BankG2, 2, true, false, false>"  # F_STEER, streaming stores: the headline kernel
 if key in summary["kernels"]:
     t = summary["kernels"][key]
     json.dump({"k_basis_g2_steer_4096": {"hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
@@ -68,7 +81,7 @@ if key in summary["kernels"]:
               open(os.path.join(P, "traffic.json"), "w"), indent=1)
 # 3. SQ issue/occupancy counters (own pass)
 sq = collections.defaultdict(lambda: collections.defaultdict(list))
-for fn in glob.glob(os.path.join(G, "pmc_SQ", "*", "*_counter_collection.csv")):
+for fn in newest(os.path.join(G, "pmc_SQ", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(fn)):
         k = short(r["Kernel_Name"])
         if "cvs::" in k:
