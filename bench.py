@@ -191,6 +191,25 @@ def main():
         extra["C4_32x1080p_pipeline_batch"] = {"Mpix/s": round(fp / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms / nfr, 5),
                                                "GB/s": round(84 * fp / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(84 * fp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                "launches_per_batch": 1}
+        # BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image (pyrDown is this
+        # build's own component -- the reference has no pyramid code)
+        big = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
+        fp3 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+        lv = fp3.pyramid(big, 5)
+        ppix = sum(l.shape[0] * l.shape[1] for l in lv)
+        hp = [cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank) for _ in lv]
+
+        def pyr_filter():
+            for hnd, l in zip(hp, lv):
+                hnd.setup(l, flags=cv.SETUP_BASIS)
+
+        c3 = max(3, args.steps // 10)
+        w_, e_ = _time_steps(torch, pyr_filter, c3, 2, barrier)
+        w2_, e2_ = _time_steps(torch, lambda: fp3.pyramid(big, 5), c3, 2, barrier)
+        extra["C3_pyramid_8192_5_levels"] = {"filter_Mpix/s": round(ppix / (e_ / c3 * 1e-3) / 1e6, 1), "filter_ms": round(e_ / c3, 4),
+                                            "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix}
+        del big, lv, hp, fp3
         # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in
         # and out (64 MiB up, 9 x 64 MiB down through hipMemcpy2D, pageable memory)
         import numpy as np

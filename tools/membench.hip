@@ -212,6 +212,18 @@ int main()
         }
         CK(hipFree(big));
     }
+    {   // rotating inputs: 8 distinct 64 MiB images so the input read cannot stay in the Infinity Cache
+        float* ins; CK(hipMalloc(&ins, plane * 4 * 8));
+        CK(hipMemset(ins, 0, plane * 4 * 8));
+        for (int sr : {8, 16, 32, 64}) {
+            char nm[80]; int it = 0;
+            snprintf(nm, 80, "P2rot strip dword NT sr=%d (8 rotating inputs)", sr);
+            rep(nm, timeit([&] { p2_strip<true><<<dim3(N / 256, (N + sr - 1) / sr), 256>>>(ins + (size_t)((it++) & 7) * plane, out, sr, plane); }, 24), bytes8);
+            snprintf(nm, 80, "P3rot strip float4 NT sr=%d (8 rotating inputs)", sr);
+            rep(nm, timeit([&] { p3_strip_vec<4, true><<<dim3(N / 1024, (N + sr - 1) / sr), 256>>>(ins + (size_t)((it++) & 7) * plane, out, sr, plane); }, 24), bytes8);
+        }
+        CK(hipFree(ins));
+    }
     for (int sr : {16, 64, 256}) {
         char nm[64];
         snprintf(nm, 64, "P4 vertical-block dword sr=%d", sr); rep(nm, timeit([&] { p4_vert<<<dim3(N / 64, (N + 4 * sr - 1) / (4 * sr)), 256>>>(in, out, sr, plane); }), bytes8);
