@@ -259,6 +259,14 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         if ((rc = check_plane(h, g, "g")) || (rc = check_plane(h, hq, "hq"))) return rc;
         if ((rc = check_same(h, g, image->rows, image->cols)) || (rc = check_same(h, hq, image->rows, image->cols))) return rc;
     }
+    // the kernel reads rows ahead of the rows it writes: an output that aliases the input would be
+    // clobbered mid-flight (the reference's sepFilter2D copies in that case; here it is an error)
+    {
+        const cvs_plane* outs_chk[10] = {steer ? g : nullptr, steer ? hq : nullptr};
+        for (int k = 0; k < 8; ++k) outs_chk[2 + k] = pipe_outs ? pipe_outs[k] : nullptr;
+        for (const cvs_plane* o : outs_chk)
+            if (o && o->data == image->data) return fail(h, CVS_E_BADARG, "an output plane aliases the input image");
+    }
     const size_t pitch = round_up((size_t)image->cols, 64);
     size_t max_pitch = std::max(pitch, image->step / sizeof(float));
     if (steer) max_pitch = std::max(max_pitch, std::max(g->step, hq->step) / sizeof(float));
@@ -619,7 +627,7 @@ int cvs_steer_point(cvs_handle h, int x, int y, float theta, float out[5])
     float v[10];
     const int n = h->have_orient ? 10 : 7;
     // one strided gather: element (y, x) of n consecutive state planes
-    HIP_TRY(h, hipMemcpy2DAsync(v, sizeof(float), h->state + (size_t)y * h->pitch + x, h->plane_stride * sizeof(float),
+    HIP_TRY(h, hipMemcpy2DAsync(v, sizeof(float), state_plane(h, 0) + (size_t)y * h->pitch + x, h->plane_stride * sizeof(float),
                                 sizeof(float), n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     float w[7];

@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
                 float acc = t.od[r][W - 1] * dif[W];
 #pragma unroll
                 for (int i = W - 1; i >= 1; --i) acc = fmaf(t.od[r][i - 1], dif[i], acc);
-                win[NE + r][j] = acc;
+                // the centre tap of an odd kernel is +0.0: the CPU row filter still multiplies it in, which
+                // matters only for non-finite pixels (0 * Inf = NaN) -- keep that footprint identical
+                win[NE + r][j] = fmaf(0.0f, s[W], acc);
             }
 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----

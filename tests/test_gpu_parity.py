@@ -506,3 +506,50 @@ def test_pipeline_batch_fallback_paths(cv):
         ref = cv.SteerableFiltersG2(None).pipeline(tiny[i])
         for k in range(8):
             assert torch.equal(out[i, k], ref[k])
+
+
+def test_generic_width_full_surface(cv, ora):
+    """non-default taps take the two-pass generic kernels for every entry point: same results as stepwise"""
+    img = smooth_image(60, 90) + 0.1 * rand_image(60, 90, seed=91)
+    f = cv.SteerableFiltersG2(img, 3, 0.9)
+    g0, h0, e0, m0, p0 = f.steer(None, full=True)
+    ed, dk, br = f.find(m0, p0)
+    fused = cv.SteerableFiltersG2(None, 3, 0.9).pipeline(img)
+    for a, b in zip((g0, h0, e0, m0, p0, ed, dk, br), fused):
+        assert np.array_equal(a, b)
+    b = np.stack([f.basis(p) for p in range(7)])
+    assert np.abs(b - ora.basis(2, img, 3, 0.9, f64=True)).max() <= TOL
+    g1, h1 = cv.SteerableFiltersG2(None, 3, 0.9).setup_steer(img, 0.3)
+    g2, h2 = f.steer(0.3)
+    assert np.array_equal(g1, g2) and np.array_equal(h1, h2)
+
+
+def test_point_steer_follows_selected_frame_and_alias_is_rejected(cv):
+    import torch
+    frames = torch.rand((3, 40, 70), device="cuda")
+    eng = cv.SteerableFiltersG2(None)
+    eng.pipeline_batch(frames)
+    for i in range(3):
+        eng.select_frame(i)
+        single = cv.SteerableFiltersG2(frames[i])
+        assert eng.steer_point((5, 7), 0.4, full=True) == single.steer_point((5, 7), 0.4, full=True)
+    x = torch.rand((64, 64), device="cuda")
+    with pytest.raises(cv.CvsError) as ei:
+        cv.SteerableFiltersG2(None).setup_steer(x, 0.3, out=(x, torch.empty_like(x)))
+    assert ei.value.status == -1
+
+
+def test_non_finite_inputs_propagate_like_the_reference(cv, ora):
+    """NaN / Inf pixels: basis planes carry them exactly where the 9x9 support touches them; phase is patched to 0"""
+    img = rand_image(48, 64, seed=5)
+    img[20, 30] = np.nan
+    img[5, 5] = np.inf
+    f = cv.SteerableFiltersG2(img)
+    got = f.basis(1)
+    want = ora.basis(2, img, 4, 0.67)[1]
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    ok = np.isfinite(want)
+    assert np.abs(got[ok] - want[ok]).max() <= TOL
+    g2, h2, e, m, p = f.steer(0.3, full=True)
+    assert np.isfinite(p).all()          # patchNaNs (G2.cpp:111)
+    assert not np.isfinite(m[20, 30])
