@@ -3,8 +3,8 @@
 // Thin by design: argument checks, device-state ownership, host<->device staging when a
 // caller hands over host planes, and kernel dispatch.  All arithmetic on the hot path is in
 // the HIP kernels (cvs_kernels_basis.hip, cvs_kernels_point.hip); the only host arithmetic is
-// what the reference also does on the host: tap generation and scalar steering weights
-// (cvs_taps.cpp) and the single-pixel steer (G2.cpp:115-134).  No CPU fallback exists.
+// what the reference also does on the host before it touches an image: tap generation and the
+// scalar steering weights of a given theta (cvs_taps.cpp).  No CPU fallback exists.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -42,6 +42,7 @@ struct cvs_context {
     float* arena = nullptr;
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
+    float* point_out = nullptr;
     int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1, branch_free = 0, plane_pad = 0, xcd_map = 0;
     std::string err;
 };
@@ -455,6 +456,7 @@ int cvs_destroy(cvs_handle h)
     if (h->arena) (void)hipFree(h->arena);
     if (h->minmax) (void)hipFree(h->minmax);
     if (h->frame_tab) (void)hipFree(h->frame_tab);
+    if (h->point_out) (void)hipFree(h->point_out);
     delete h;
     return CVS_OK;
 }
@@ -624,27 +626,17 @@ int cvs_steer_point(cvs_handle h, int x, int y, float theta, float out[5])
     if (rc) return rc;
     if (x < 0 || y < 0 || x >= h->cols || y >= h->rows) return fail(h, CVS_E_BADARG, "point outside the image");
     HIP_TRY(h, hipSetDevice(h->device));
-    float v[10];
-    const int n = h->have_orient ? 10 : 7;
-    // one strided gather: element (y, x) of n consecutive state planes
-    HIP_TRY(h, hipMemcpy2DAsync(v, sizeof(float), state_plane(h, 0) + (size_t)y * h->pitch + x, h->plane_stride * sizeof(float),
-                                sizeof(float), n, hipMemcpyDeviceToHost, h->stream));
+    // the scalar weights are host math in the reference too (G2.cpp:118-120); the pixel arithmetic
+    // runs on the device, next to the state it reads
+    PointArgs a{};
+    host_steer_weights(CVS_KIND_G2, theta, a.w);
+    a.c2t = (float)std::cos((double)theta * 2.0);  // G2.cpp:132: std::cos(theta * 2.0), double argument
+    a.s2t = (float)std::sin((double)theta * 2.0);
+    if (!h->point_out) HIP_TRY(h, hipMalloc(&h->point_out, 8 * sizeof(float)));
+    HIP_TRY(h, launch_steer_point(state_plane(h, 0), h->plane_stride, (size_t)y * h->pitch + x, h->have_orient ? 1 : 0, a,
+                                  h->point_out, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out, h->point_out, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    float w[7];
-    host_steer_weights(CVS_KIND_G2, theta, w);
-    // G2.cpp:121-122 (float expression, left to right)
-    const float g2 = w[0] * v[0] + w[1] * v[1] + w[2] * v[2];
-    const float h2 = w[3] * v[3] + w[4] * v[4] + w[5] * v[5] + w[6] * v[6];
-    out[0] = g2;
-    out[1] = h2;
-    if (h->have_orient) {  // G2.cpp:132-133
-        const float c2t = (float)std::cos((double)theta * 2.0), s2t = (float)std::sin((double)theta * 2.0);
-        out[2] = v[7] + (c2t * v[8]) + (s2t * v[9]);
-    } else {
-        out[2] = std::numeric_limits<float>::quiet_NaN();
-    }
-    out[3] = std::sqrt(h2 * h2 + g2 * g2);  // G2.cpp:129
-    out[4] = std::atan2(h2, g2);            // G2.cpp:128: libm atan2, no wrap
     return CVS_OK;
 }
 

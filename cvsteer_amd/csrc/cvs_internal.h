@@ -94,6 +94,9 @@ struct PointArgs {
 };
 
 hipError_t launch_point(PointOp op, const PointArgs& a, hipStream_t s);
+// single-pixel steer (G2.cpp:115-134): uses a.w, a.c2t, a.s2t; writes {g2,h2,e,mag,phase} to out5 (device)
+hipError_t launch_steer_point(const float* state, size_t plane_stride, size_t offset, int have_orient, const PointArgs& a,
+                              float* out5, hipStream_t s);
 
 // per-image min/max + 8-bit quantise (cv::normalize NORM_MINMAX -> CV_8UC1)
 hipError_t launch_minmax(const float* src, size_t pitch, int rows, int cols, float* minmax2, hipStream_t s);

@@ -247,6 +247,35 @@ __global__ __launch_bounds__(256) void k_quantize_u8(const float* src, size_t pi
 }
 
 // ---------------------------------------------------------------------------------------
+// steer(const cv::Point& p, theta, g2, h2, e, magnitude, phase)  (G2.cpp:115-134): one pixel.
+// One lane gathers the 7 (+3) state values at (y, x) and evaluates the reference's scalar
+// expression: float sums left to right, libm-style atan2 (no wrap, no NaN patch) and sqrt.
+// ---------------------------------------------------------------------------------------
+__global__ void k_steer_point(const float* state, size_t plane_stride, size_t offset, int have_orient,
+                              PointArgs a, float* out5)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float v[10];
+    for (int i = 0; i < 10; ++i) v[i] = (i < 7 || have_orient) ? state[(size_t)i * plane_stride + offset] : 0.f;
+    const float g2 = __fadd_rn(__fadd_rn(__fmul_rn(a.w[0], v[0]), __fmul_rn(a.w[1], v[1])), __fmul_rn(a.w[2], v[2]));
+    float h2 = __fadd_rn(__fmul_rn(a.w[3], v[3]), __fmul_rn(a.w[4], v[4]));
+    h2 = __fadd_rn(h2, __fmul_rn(a.w[5], v[5]));
+    h2 = __fadd_rn(h2, __fmul_rn(a.w[6], v[6]));
+    out5[0] = g2;
+    out5[1] = h2;
+    out5[2] = have_orient ? __fadd_rn(__fadd_rn(v[7], __fmul_rn(a.c2t, v[8])), __fmul_rn(a.s2t, v[9])) : __int_as_float(0x7fc00000);
+    out5[3] = __fsqrt_rn(__fadd_rn(__fmul_rn(h2, h2), __fmul_rn(g2, g2)));
+    out5[4] = atan2f(h2, g2);
+}
+
+hipError_t launch_steer_point(const float* state, size_t plane_stride, size_t offset, int have_orient, const PointArgs& a,
+                              float* out5, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_steer_point, dim3(1), dim3(64), 0, s, state, plane_stride, offset, have_orient, a, out5);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // Gaussian pyramid level (BASELINE config 3; the reference has no pyramid code): cv::pyrDown
 // semantics -- [1 4 6 4 1]/16 separable blur, REFLECT_101, keep every second pixel, output
 // ((rows+1)/2) x ((cols+1)/2).  One thread makes one output pixel from its 5x5 neighbourhood;
