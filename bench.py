@@ -191,6 +191,14 @@ def main():
         extra["C4_32x1080p_pipeline_batch"] = {"Mpix/s": round(fp / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms / nfr, 5),
                                                "GB/s": round(84 * fp / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(84 * fp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                "launches_per_batch": 1}
+        ff.set_persist(False)
+        fo3 = torch.empty((nfr, 3, 1080, 1920), device=dev)
+        w_, e_ = _time_steps(torch, lambda: ff.pipeline_batch(frames, out=fo3, outputs=(5, 6, 7)), csteps, 2, barrier)
+        ms = e_ / csteps
+        extra["C4_32x1080p_feature_maps_only"] = {"Mpix/s": round(fp / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms / nfr, 5),
+                                                   "B/pix": 16, "GB/s": round(16 * fp / (ms * 1e-3) / 1e9, 1),
+                                                   "note": "edges + dark + bright only, no state persisted (what example/steer.cpp keeps)"}
+        del fout, fo3, frames, ff
         # BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image (pyrDown is this
         # build's own component -- the reference has no pyramid code)
         big = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)

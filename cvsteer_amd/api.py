@@ -324,25 +324,35 @@ class SteerableFiltersG2(SteerableFilters):
         self._check(lib().cvs_pipeline(self._h, C.byref(pi), arr), "cvs_pipeline")
         return tuple(outs)
 
-    def pipeline_batch(self, frames, out=None):
+    def pipeline_batch(self, frames, out=None, outputs=None):
         """pipeline() for n same-size frames in one launch.  frames: [n, H, W] tensor/array (or a list
-        of planes); returns / fills out [n, 8, H, W].  select_frame(i) then picks whose state the
-        getters and steer() use."""
+        of planes).  outputs: indices into (g2, h2, e, magnitude, phase, edges, dark, bright) to
+        produce (default all 8); returns / fills out [n, len(outputs), H, W].  select_frame(i) then
+        picks whose state the getters and steer() use (unless set_persist(False))."""
         planes = [_as_input(f) for f in frames]
         n = len(planes)
+        sel = list(range(8)) if outputs is None else [int(k) for k in outputs]
         self._like = planes[0]
         shape = tuple(planes[0].shape)
         if out is None:
             if _is_torch(planes[0]):
-                out = torch.empty((n, 8) + shape, dtype=torch.float32, device=planes[0].device)
+                out = torch.empty((n, len(sel)) + shape, dtype=torch.float32, device=planes[0].device)
             else:
-                out = np.empty((n, 8) + shape, np.float32)
+                out = np.empty((n, len(sel)) + shape, np.float32)
         self._bind_stream(planes[0], out[0][0])
         imgs = (Plane * n)(*[_plane(p) for p in planes])
-        outs = (Plane * (n * 8))(*[_plane(out[i][k]) for i in range(n) for k in range(8)])
+        outs = (Plane * (n * 8))()  # zero-initialised: data == NULL means "not requested"
+        for i in range(n):
+            for j, k in enumerate(sel):
+                outs[i * 8 + k] = _plane(out[i][j])
         self._check(lib().cvs_pipeline_batch(self._h, imgs, n, outs), "cvs_pipeline_batch")
         self._batch_keepalive = (planes, out)
         return out
+
+    def set_persist(self, on):
+        """pipeline()/pipeline_batch(): keep the basis + orientation planes (default, like the reference
+        object) or write the requested outputs only"""
+        self.set_option(L.OPT_PERSIST_STATE, 1 if on else 0)
 
     def select_frame(self, i):
         self._check(lib().cvs_select_frame(self._h, int(i)), "cvs_select_frame")

@@ -43,7 +43,7 @@ struct cvs_context {
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
     float* point_out = nullptr;
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1, branch_free = 0, plane_pad = 0, xcd_map = 0;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1, plane_pad = 0, xcd_map = 0, persist = 1;
     std::string err;
 };
 
@@ -301,7 +301,6 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.strip_rows = default_strip_rows(h, a.rows, a.cols);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     a.g4_split = h->g4_split;
-    a.branch_free = h->branch_free;
     a.xcd_map = h->xcd_map;
     if (steer) {
         PlaneRef rg, rh;
@@ -314,14 +313,16 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     }
     if (pipe_outs) {
         a.pipe = 1;
+        a.no_state = h->persist ? 0 : 1;
         a.find_on_e = h->find_on;
         for (int k = 0; k < 8; ++k)
             if ((rc = out_ref(c, po[k], a.pipe_out[k]))) return rc;
     }
     float* scr = scratch ? arena_take(h, scratch) : nullptr;
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
-    h->have_basis = true;
-    h->have_orient = (flags & CVS_SETUP_ORIENT) != 0;
+    // a pipeline run with CVS_OPT_PERSIST_STATE = 0 wrote its outputs only: no state to address afterwards
+    h->have_basis = !(pipe_outs && !h->persist);
+    h->have_orient = h->have_basis && (flags & CVS_SETUP_ORIENT) != 0;
     return finish(c);
 }
 
@@ -499,13 +500,13 @@ int cvs_set_option(cvs_handle h, int option, int value)
             h->plane_pad = value;
             h->state_elems = h->state_elems;  // takes effect at the next setup
             return CVS_OK;
+        case CVS_OPT_PERSIST_STATE:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "persist");
+            h->persist = value;
+            return CVS_OK;
         case CVS_OPT_XCD_MAP:
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "xcd map");
             h->xcd_map = value;
-            return CVS_OK;
-        case CVS_OPT_BRANCH_FREE:
-            if (value < -1 || value > 1) return fail(h, CVS_E_BADARG, "branch free");
-            h->branch_free = value;
             return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
@@ -520,9 +521,9 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_FIND_ON: *value = h->find_on; return CVS_OK;
         case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
-        case CVS_OPT_BRANCH_FREE: *value = h->branch_free; return CVS_OK;
         case CVS_OPT_PLANE_PAD: *value = h->plane_pad; return CVS_OK;
         case CVS_OPT_XCD_MAP: *value = h->xcd_map; return CVS_OK;
+        case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -806,15 +807,15 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.strip_rows = default_strip_rows(h, rows, cols);
     a.nt_stores = use_nt_stores(h, (size_t)rows * cols * n);
     a.pipe = 1;
+    a.no_state = h->persist ? 0 : 1;
     a.find_on_e = h->find_on;
     a.frames = h->frame_tab;
     a.g4_split = h->g4_split;
-    a.branch_free = 0;
     a.xcd_map = h->xcd_map;
     a.batch = n;
     a.frame_stride = h->frame_stride;
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream));
-    h->have_basis = h->have_orient = true;
+    h->have_basis = h->have_orient = h->persist != 0;
     return CVS_OK;
 }
 

@@ -118,8 +118,9 @@ __device__ __forceinline__ float phase_lambda(float phase, float phi, bool signu
 }
 
 // G2.cpp:70-99: products, C1..C3, cartToPolar, wrap, *0.5.  b = {g2a,g2b,g2c,h2a,h2b,h2c,h2d}.
+// need_c1 = false skips C1 (only the oriented energy e uses it); callers that store C1 pass true
 __device__ inline void g2_orientation(const float b[7], int mode, float& c1, float& c2, float& c3,
-                                      float& theta, float& strength)
+                                      float& theta, float& strength, bool need_c1 = true)
 {
     const float A = b[0], B = b[1], C = b[2], HA = b[3], HB = b[4], HC = b[5], HD = b[6];
     const float g2aa = __fmul_rn(A, A), g2ab = __fmul_rn(A, B), g2ac = __fmul_rn(A, C);
@@ -128,11 +129,14 @@ __device__ inline void g2_orientation(const float b[7], int mode, float& c1, flo
     const float h2bb = __fmul_rn(HB, HB), h2bc = __fmul_rn(HB, HC), h2bd = __fmul_rn(HB, HD);
     const float h2cc = __fmul_rn(HC, HC), h2cd = __fmul_rn(HC, HD), h2dd = __fmul_rn(HD, HD);
     // every MatExpr node of G2.cpp:93-95 rounds to f32; scalars distribute over (a +/- b)
-    float v1 = __fadd_rn(__fmul_rn(0.5f, g2bb), __fmul_rn(0.25f, g2ac));
-    v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.375f, g2aa), __fmul_rn(0.375f, g2cc)));
-    v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.3125f, h2aa), __fmul_rn(0.3125f, h2dd)));
-    v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.5625f, h2bb), __fmul_rn(0.5625f, h2cc)));
-    v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.375f, h2ac), __fmul_rn(0.375f, h2bd)));
+    float v1 = 0.f;
+    if (need_c1) {
+        v1 = __fadd_rn(__fmul_rn(0.5f, g2bb), __fmul_rn(0.25f, g2ac));
+        v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.375f, g2aa), __fmul_rn(0.375f, g2cc)));
+        v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.3125f, h2aa), __fmul_rn(0.3125f, h2dd)));
+        v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.5625f, h2bb), __fmul_rn(0.5625f, h2cc)));
+        v1 = __fadd_rn(v1, __fadd_rn(__fmul_rn(0.375f, h2ac), __fmul_rn(0.375f, h2bd)));
+    }
     float v2 = __fsub_rn(__fmul_rn(0.5f, g2aa), __fmul_rn(0.5f, g2cc));
     v2 = __fadd_rn(v2, __fsub_rn(__fmul_rn(0.46875f, h2aa), __fmul_rn(0.46875f, h2dd)));
     v2 = __fadd_rn(v2, __fsub_rn(__fmul_rn(0.28125f, h2bb), __fmul_rn(0.28125f, h2cc)));

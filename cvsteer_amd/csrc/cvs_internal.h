@@ -41,11 +41,11 @@ struct BasisArgs {
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 1 = run the G4 bank as two launches (G half, H half)
-    int branch_free;      // 1 = G2 row loop without the store branch (more stores in flight)
     int xcd_map;          // 1 = 1-D grid, row bands pinned to XCDs (see k_basis)
     int grid_x, grid_y;   // filled by the launcher
     // fused caller pipeline (needs orient): g2,h2,e,mag,phase,edges,dark,bright at theta_dom
     int pipe;             // 1 = run the pipeline epilogue
+    int no_state;         // pipeline only: 1 = do not persist basis / orientation planes (outputs only)
     int find_on_e;        // 1 = find*(e, phase), 0 = find*(magnitude, phase)
     PlaneRef pipe_out[8]; // any entry may be {nullptr, 0}
     // batched launch: n frames of identical geometry, frame z takes in/out from frames[z] and its

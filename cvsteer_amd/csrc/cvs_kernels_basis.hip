@@ -85,7 +85,7 @@ struct Folded {
     float od[B::NO][B::W];
 };
 
-enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4 };  // F_PIPE implies F_ORIENT
+enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8 };  // F_PIPE implies F_ORIENT; F_NOSTATE: outputs only
 
 // LDS hand-off inside ONE wave: DS ops of a wave execute in issue order, so only the compiler
 // must be kept from moving them across this point.
@@ -132,7 +132,17 @@ __device__ __forceinline__ void bst(rsrc_t r, unsigned lane_off, unsigned row_of
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_off, row_off, STREAM ? 2 : 0);  // aux 2 = nt
 }
 
-template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool BF = false>
+// a 64-bit value that is the same in every lane, moved to SGPRs (the compiler cannot prove that a
+// value loaded from the per-frame table is wave-uniform; without this every use becomes a VGPR
+// address + a readfirstlane "waterfall" loop around each buffer instruction)
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool ONE = false>
 __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B> t)
 {
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
@@ -177,19 +187,33 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
     size_t in_pitch = a.in_pitch;
     float* basis_p = a.basis;
     float* orient_p = a.orient;
-    const PlaneRef* pipe_out = a.pipe_out;
+    PlaneRef pipe_out[8];
     if constexpr (BATCH) {
         const BatchFrame* fr = a.frames + blockIdx.z;
-        in_p = fr->in;
-        in_pitch = fr->in_pitch;
+        in_p = reinterpret_cast<const float*>(uniform64(reinterpret_cast<unsigned long long>(fr->in)));
+        in_pitch = uniform64(fr->in_pitch);
         basis_p += (size_t)blockIdx.z * a.frame_stride;
         orient_p += (size_t)blockIdx.z * a.frame_stride;
-        pipe_out = fr->out;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            pipe_out[k].p = reinterpret_cast<float*>(uniform64(reinterpret_cast<unsigned long long>(fr->out[k].p)));
+            pipe_out[k].pitch = uniform64(fr->out[k].pitch);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pipe_out[k] = a.pipe_out[k];
     }
     // buffer resources (wave-uniform): input plane, state planes
     const size_t plane_bytes = (size_t)a.rows * a.pitch * sizeof(float);
     const unsigned pitch_b = (unsigned)(a.pitch * sizeof(float));
     const rsrc_t r_in = plane_rsrc(in_p, (size_t)a.rows * in_pitch * sizeof(float));
+    // ONE: the frame's whole state block (basis + orientation planes, one allocation) is a single
+    // resource and the plane is part of the scalar offset -- 4 SGPRs instead of 4 per plane, which is
+    // what keeps the 20-plane pipeline variant from spilling SGPRs.  Needs the block to be < 2 GiB;
+    // larger images use one resource per plane.
+    constexpr int NBTOT = B::KIND == 2 ? 7 : 11;
+    const rsrc_t r_state = plane_rsrc(basis_p, (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float));
+    const unsigned pstride_b = (unsigned)(a.plane_stride * sizeof(float));
     const unsigned in_pitch_b = (unsigned)(in_pitch * sizeof(float));
 
     float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
@@ -254,16 +278,10 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
             }
 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----
-            // Rows outside [y0, yend) (the first 2W rows of a strip prime the window; the last group may
-            // overshoot) run the same straight-line code with their stores switched off through the
-            // lane offset: no branch, so the compiler sees a fixed 2-loads + NB-stores pattern per row
-            // and lets several rows of stores stay in flight instead of draining them at each wait.
             const int yout = y0 + g * NT + j - 2 * W;
             const bool row_ok = yout >= y0 && yout < yend;  // wave-uniform
-            // (BF template flag; chosen per variant by the launcher from measurements: it pays where the
-            // epilogue is light, and costs where skipped rows would run a heavy epilogue for nothing.)
-            const unsigned xbr = (BF && !row_ok) ? kLaneOff : xb;
-            if (BF || row_ok) {
+            const unsigned xbr = xb;
+            if (row_ok) {
                 float b[NB];
 #pragma unroll
                 for (int p = 0; p < NB; ++p) {
@@ -287,25 +305,36 @@ __global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
                 const unsigned yo = row_ok ? (unsigned)yout : 0u;
                 const unsigned orow = yo * pitch_b;
+                if constexpr ((FLAGS & F_NOSTATE) == 0) {
 #pragma unroll
-                for (int p = 0; p < NB; ++p)
-                    bst<STREAM>(plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orow, b[p]);
+                    for (int p = 0; p < NB; ++p)
+                        if constexpr (ONE) bst<STREAM>(r_state, xbr, orow + (unsigned)(B::PLANE0 + p) * pstride_b, b[p]);
+                        else bst<STREAM>(plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orow, b[p]);
+                }
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
+                    // stateless pipeline: the oriented energy (and with it C1) is evaluated only when asked for
+                    const bool need_e = (FLAGS & F_NOSTATE) == 0 || pipe_out[2].p != nullptr || a.find_on_e != 0;  // wave-uniform
                     float c1, c2, c3, th, st;
-                    g2_orientation(b, a.atan_mode, c1, c2, c3, th, st);
-                    const float ov[5] = {c1, c2, c3, th, st};
+                    g2_orientation(b, a.atan_mode, c1, c2, c3, th, st, need_e);
+                    if constexpr ((FLAGS & F_NOSTATE) == 0) {
+                        const float ov[5] = {c1, c2, c3, th, st};
 #pragma unroll
-                    for (int k = 0; k < 5; ++k)
-                        bst<STREAM>(plane_rsrc(orient_p + (size_t)k * a.plane_stride, plane_bytes), xbr, orow, ov[k]);
+                        for (int k = 0; k < 5; ++k)
+                            if constexpr (ONE) bst<STREAM>(r_state, xbr, orow + (unsigned)(NBTOT + k) * pstride_b, ov[k]);
+                            else bst<STREAM>(plane_rsrc(orient_p + (size_t)k * a.plane_stride, plane_bytes), xbr, orow, ov[k]);
+                    }
                     if constexpr ((FLAGS & F_PIPE) != 0) {
                         // the callers' sequence (test/test.cpp:86-90) on values still in registers:
                         // steer at theta_dom, energy, magnitude/phase, the three feature maps
                         float q[8];
                         // theta_dom in (-pi/2, pi/2]: the bounded cos/sin path, no library call
                         g2_steer_angle<true>(b, th, q[0], q[1]);
-                        float s2, cc2;
-                        sincos_small(__fmul_rn(th, 2.0f), s2, cc2);
-                        q[2] = __fadd_rn(__fadd_rn(c1, __fmul_rn(c2, cc2)), __fmul_rn(c3, s2));
+                        q[2] = 0.f;
+                        if (need_e) {
+                            float s2, cc2;
+                            sincos_small(__fmul_rn(th, 2.0f), s2, cc2);
+                            q[2] = __fadd_rn(__fadd_rn(c1, __fmul_rn(c2, cc2)), __fmul_rn(c3, s2));
+                        }
                         mag_phase(q[0], q[1], a.atan_mode, q[3], q[4]);
                         const float en = a.find_on_e ? q[2] : q[3];
                         q[5] = __fmul_rn(en, phase_lambda<true>(q[4], kHalfPiF, false));
@@ -439,11 +468,24 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     dim3 block(256);
     const bool orient = a.orient != nullptr && B::KIND == 2;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
+    constexpr int NBTOT = B::KIND == 2 ? 7 : 11;
+    const bool one = (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;
+#define CVS_LAUNCH_B(FL, BATCHED)                                                                             \
+    do {                                                                                                      \
+        if (one) {                                                                                            \
+            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, true>), grid, block, 0, s, a, f);   \
+            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, true>), grid, block, 0, s, a, f);              \
+        } else {                                                                                              \
+            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, false>), grid, block, 0, s, a, f);  \
+            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, false>), grid, block, 0, s, a, f);             \
+        }                                                                                                     \
+    } while (0)
+#define CVS_LAUNCH(FL) CVS_LAUNCH_B(FL, false)
     if (a.frames) {  // batched caller pipeline: one launch, grid.z = frames (G2 only)
         if constexpr (B::KIND == 2 && B::HALF == 0) {
             grid.z = a.batch;
-            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, F_ORIENT | F_PIPE, true, true>), grid, block, 0, s, a, f);
-            else hipLaunchKernelGGL((k_basis<B, F_ORIENT | F_PIPE, false, true>), grid, block, 0, s, a, f);
+            if (a.no_state) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE, true);
+            else CVS_LAUNCH_B(F_ORIENT | F_PIPE, true);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
@@ -451,35 +493,22 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     }
     const bool pipe = orient && a.pipe;
     const int flags = pipe ? (F_ORIENT | F_PIPE) : ((orient ? F_ORIENT : 0) | (steer ? F_STEER : 0));
-    // interleaved A/B on MI355X (tools/ab.py): the branch-free loop is neutral for the basis / steer
-    // variants (74.0 vs 73.6 %, 71.0 vs 71.2 %) and loses where skipped rows run a heavy epilogue for
-    // nothing (pipeline 65 -> 47 %), so it stays an experiment switch, off by default
-    const int bf = a.branch_free > 0;
-    (void)bf;
-#define CVS_LAUNCH(FL)                                                                                        \
-    do {                                                                                                      \
-        if constexpr (B::KIND == 2) {                                                                         \
-            if (bf) {                                                                                         \
-                if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, false, true>), grid, block, 0, s, a, f);   \
-                else hipLaunchKernelGGL((k_basis<B, FL, false, false, true>), grid, block, 0, s, a, f);              \
-                break;                                                                                        \
-            }                                                                                                 \
-        }                                                                                                     \
-        if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true>), grid, block, 0, s, a, f);                 \
-        else hipLaunchKernelGGL((k_basis<B, FL, false>), grid, block, 0, s, a, f);                            \
-    } while (0)
     if constexpr (B::KIND == 2) {
         switch (flags) {
             case 0: CVS_LAUNCH(0); break;
             case F_ORIENT: CVS_LAUNCH(F_ORIENT); break;
             case F_STEER: CVS_LAUNCH(F_STEER); break;
             case F_ORIENT | F_STEER: CVS_LAUNCH(F_ORIENT | F_STEER); break;
-            default: CVS_LAUNCH(F_ORIENT | F_PIPE); break;
+            default:
+                if (a.no_state) CVS_LAUNCH(F_ORIENT | F_PIPE | F_NOSTATE);
+                else CVS_LAUNCH(F_ORIENT | F_PIPE);
+                break;
         }
     } else {
         if (steer) CVS_LAUNCH(F_STEER);
         else CVS_LAUNCH(0);
     }
+#undef CVS_LAUNCH_B
 #undef CVS_LAUNCH
     return hipGetLastError();
 }

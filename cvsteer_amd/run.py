@@ -63,7 +63,8 @@ def process_file(engine, path, outdir, gain, ext=".png"):
     gray = read_gray(path)
     dev = torch.device("cuda", engine.device)
     img = torch.from_numpy(np.ascontiguousarray(gray)).to(dev).to(torch.float32)  # u8 crosses PCIe as u8
-    outs = engine.pipeline(img)  # g2, h2, e, magnitude, phase, edges, dark, bright -- one launch
+    # one launch; only the three feature maps leave the kernel (set_persist(False): no state planes)
+    outs = engine.pipeline(img, out=[None] * 5 + [torch.empty_like(img) for _ in range(3)])
     base = os.path.splitext(os.path.basename(path))[0]
     written = []
     for plane, suffix in zip(outs[5:], ("_edges", "_lines_dark", "_lines_bright")):
@@ -97,6 +98,7 @@ def main(argv=None):
     if args.output:
         os.makedirs(args.output, exist_ok=True)
     engine = SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+    engine.set_persist(False)  # the driver never revisits an image's basis planes
     failed = 0
     for path in files[lo:hi]:
         try:

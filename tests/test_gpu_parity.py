@@ -553,3 +553,24 @@ def test_non_finite_inputs_propagate_like_the_reference(cv, ora):
     g2, h2, e, m, p = f.steer(0.3, full=True)
     assert np.isfinite(p).all()          # patchNaNs (G2.cpp:111)
     assert not np.isfinite(m[20, 30])
+
+
+def test_stateless_pipeline_outputs_only(cv):
+    """CVS_OPT_PERSIST_STATE = 0: same requested outputs, no state planes afterwards"""
+    import torch
+    frames = torch.from_numpy(np.stack([smooth_image(90, 150) + 0.1 * rand_image(90, 150, seed=s) for s in range(4)])).cuda()
+    ref = cv.SteerableFiltersG2(None).pipeline_batch(frames)
+    eng = cv.SteerableFiltersG2(None)
+    eng.set_persist(False)
+    got = eng.pipeline_batch(frames, outputs=(5, 6, 7))
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (4, 3, 90, 150)
+    assert torch.equal(got, ref[:, 5:8])
+    with pytest.raises(cv.CvsError) as ei:
+        eng.getDominantOrientationAngle()
+    assert ei.value.status == -5
+    single = eng.pipeline(frames[2], out=[None] * 5 + [torch.empty_like(frames[2]) for _ in range(3)])
+    assert single[0] is None and torch.equal(single[7], ref[2, 7])
+    eng.set_persist(True)
+    eng.pipeline(frames[1])
+    assert torch.equal(eng.getDominantOrientationAngle(), cv.SteerableFiltersG2(frames[1]).getDominantOrientationAngle())
