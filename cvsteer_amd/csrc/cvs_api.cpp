@@ -43,7 +43,7 @@ struct cvs_context {
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
     float* point_out = nullptr;
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1, plane_pad = 0, xcd_map = 0, persist = 1;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1, xcd_map = 0, persist = 1;
     std::string err;
 };
 
@@ -195,7 +195,7 @@ float* state_plane(cvs_handle h, int idx)
 int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
 {
     const size_t pitch = round_up((size_t)cols, 64);
-    const size_t stride = round_up(pitch * rows, 64) + (size_t)h->plane_pad;
+    const size_t stride = round_up(pitch * rows, 64);
     const size_t elems = stride * (h->nb + 5) * (size_t)nframes;
     if (elems > h->state_elems) {
         if (h->state) {
@@ -495,11 +495,6 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "g4 split");
             h->g4_split = value;
             return CVS_OK;
-        case CVS_OPT_PLANE_PAD:
-            if (value < 0 || value > (1 << 24) || value % 64) return fail(h, CVS_E_BADARG, "plane pad");
-            h->plane_pad = value;
-            h->state_elems = h->state_elems;  // takes effect at the next setup
-            return CVS_OK;
         case CVS_OPT_PERSIST_STATE:
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "persist");
             h->persist = value;
@@ -521,7 +516,6 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_FIND_ON: *value = h->find_on; return CVS_OK;
         case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
-        case CVS_OPT_PLANE_PAD: *value = h->plane_pad; return CVS_OK;
         case CVS_OPT_XCD_MAP: *value = h->xcd_map; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
     }
