@@ -31,7 +31,7 @@ namespace cvs {
 // ---------------------------------------------------------------------------------------
 struct BankG2 {  // SteerableFiltersG2.cpp:62-68
     static constexpr int KIND = 2, W = 4, NE = 3, NO = 3, NB = 7;
-    static constexpr int MIN_WAVES = 4;  // waves per SIMD the register allocator must leave room for
+    static constexpr int MIN_WAVES = 1;  // waves per SIMD the register allocator must leave room for (1 = unconstrained)
     // even: E0=G21 E1=G22(=H22) E2=H24 ; odd: O0=G23 O1=H21 O2=H23 (ids 3,4,5)
     __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 3, 1, 4, 2, 5, 1}; return t[p]; }
     __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 3, 0, 1, 5, 2, 4}; return t[p]; }
@@ -43,7 +43,7 @@ struct BankG2 {  // SteerableFiltersG2.cpp:62-68
 
 struct BankG4 {  // SteerableFiltersG4.cpp:69-80
     static constexpr int KIND = 4, W = 6, NE = 5, NO = 5, NB = 11;
-    static constexpr int MIN_WAVES = 2;
+    static constexpr int MIN_WAVES = 1;
     // even: E0=G41 E1=G42(=H42) E2=G45 E3=H43 E4=H46 ; odd: O0=G43 O1=G44 O2=H41 O3=H44 O4=H45 (ids 5..9)
     __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 5, 2, 6, 1, 7, 3, 9, 4, 8, 1}; return t[p]; }
     __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 6, 2, 5, 0, 1, 8, 4, 9, 3, 7}; return t[p]; }
@@ -58,6 +58,7 @@ struct BankG4 {  // SteerableFiltersG4.cpp:69-80
 // windows; the image is read twice (the second read is an L2 / Infinity-Cache hit).
 struct BankG4G {  // planes g4a..g4e, SteerableFiltersG4.cpp:69-73
     static constexpr int KIND = 4, W = 6, NE = 3, NO = 2, NB = 5;
+    static constexpr int MIN_WAVES = 1;  // forcing 4 waves/SIMD (128 VGPRs) costs scratch spills and ~4 points (measured)
     // even: E0=G41 E1=G42 E2=G45 ; odd: O0=G43 O1=G44 (ids 3,4)
     __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 3, 2, 4, 1}; return t[p]; }
     __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 4, 2, 3, 0}; return t[p]; }
@@ -69,6 +70,7 @@ struct BankG4G {  // planes g4a..g4e, SteerableFiltersG4.cpp:69-73
 
 struct BankG4H {  // planes h4a..h4f, SteerableFiltersG4.cpp:75-80
     static constexpr int KIND = 4, W = 6, NE = 3, NO = 3, NB = 6;
+    static constexpr int MIN_WAVES = 1;  // forcing 4 waves/SIMD (128 VGPRs) costs scratch spills and ~4 points (measured)
     // even: E0=H42 E1=H43 E2=H46 ; odd: O0=H41 O1=H44 O2=H45 (ids 3,4,5)
     __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {3, 1, 5, 2, 4, 0}; return t[p]; }
     __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {0, 4, 2, 5, 1, 3}; return t[p]; }
@@ -143,7 +145,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 }
 
 template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool ONE = false>
-__global__ __launch_bounds__(256) void k_basis(const BasisArgs a, const Folded<B> t)
+__global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
     constexpr int LW = 64 + 2 * W;
