@@ -59,7 +59,18 @@ def steer_weights(kind, theta):
 
 
 def _plane(a):
-    """cvs_plane view of a 2-D float32 numpy array or torch CUDA tensor (no copy)."""
+    """cvs_plane view of a 2-D float32 numpy array or torch CUDA tensor (no copy); 8-bit arrays /
+    tensors are accepted for input images (CVS_DEPTH_U8)."""
+    if _is_torch(a) and a.dtype == torch.uint8:
+        if a.dim() != 2 or (a.numel() and a.shape[1] > 1 and a.stride(1) != 1):
+            raise ValueError("8-bit image must be 2-D with unit column stride")
+        mem = (L.MEM_DEVICE if a.is_cuda else L.MEM_HOST) | L.DEPTH_U8
+        return Plane(a.data_ptr(), a.shape[0], a.shape[1], a.stride(0) if a.shape[0] > 1 else a.shape[1], mem)
+    if isinstance(a, np.ndarray) and a.dtype == np.uint8:
+        if a.ndim != 2 or (a.size and a.shape[1] > 1 and a.strides[1] != 1):
+            raise ValueError("8-bit image must be 2-D with unit column stride")
+        return Plane(a.ctypes.data, a.shape[0], a.shape[1], a.strides[0] if (a.shape[0] > 1 and a.size) else a.shape[1],
+                     L.MEM_HOST | L.DEPTH_U8)
     if _is_torch(a):
         if a.dtype != torch.float32 or a.dim() != 2 or (a.numel() and a.shape[1] > 1 and a.stride(1) != 1):
             raise ValueError("torch plane must be 2-D float32 with unit column stride")
@@ -76,9 +87,9 @@ def _plane(a):
 def _as_input(a):
     """the reference converts any Mat to Mat1f unscaled (Mat1f(const Mat&)); do the same on the host side"""
     if _is_torch(a):
-        return a if a.dtype == torch.float32 else a.to(torch.float32)
+        return a if a.dtype in (torch.float32, torch.uint8) else a.to(torch.float32)
     a = np.asarray(a)
-    return a if a.dtype == np.float32 else a.astype(np.float32)
+    return a if a.dtype in (np.float32, np.uint8) else a.astype(np.float32)
 
 
 class SteerableFilters:

@@ -69,13 +69,21 @@ int fail_hip(cvs_handle h, hipError_t e, const char* where)
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
-int check_plane(cvs_handle h, const cvs_plane* p, const char* name)
+bool is_u8(const cvs_plane* p) { return (p->mem & CVS_DEPTH_U8) != 0; }
+int mem_of(const cvs_plane* p) { return p->mem & 0xff; }
+
+int check_plane(cvs_handle h, const cvs_plane* p, const char* name, bool allow_u8 = false)
 {
     if (!p) return fail(h, CVS_E_BADARG, name);
     if (p->rows <= 0 || p->cols <= 0) return fail(h, CVS_E_SIZE, "empty plane");
     if (!p->data) return fail(h, CVS_E_BADARG, name);
-    if (p->step < (size_t)p->cols * sizeof(float) || p->step % sizeof(float)) return fail(h, CVS_E_SIZE, "bad step");
-    if (p->mem != CVS_MEM_HOST && p->mem != CVS_MEM_DEVICE) return fail(h, CVS_E_BADARG, "bad mem kind");
+    if ((p->mem & ~(0xff | CVS_DEPTH_U8)) || (is_u8(p) && !allow_u8)) return fail(h, CVS_E_BADARG, "bad mem / depth flags");
+    if (mem_of(p) != CVS_MEM_HOST && mem_of(p) != CVS_MEM_DEVICE) return fail(h, CVS_E_BADARG, "bad mem kind");
+    if (is_u8(p)) {
+        if (p->step < (size_t)p->cols) return fail(h, CVS_E_SIZE, "bad step");
+    } else if (p->step < (size_t)p->cols * sizeof(float) || p->step % sizeof(float)) {
+        return fail(h, CVS_E_SIZE, "bad step");
+    }
     return CVS_OK;
 }
 
@@ -122,13 +130,34 @@ float* arena_take(cvs_handle h, size_t elems)
 
 size_t staged_elems(const cvs_plane* p)
 {
-    return (p && p->mem == CVS_MEM_HOST) ? round_up(round_up((size_t)p->cols, 64) * p->rows, 64) : 0;
+    if (!p) return 0;
+    const size_t plane = round_up(round_up((size_t)p->cols, 64) * p->rows, 64);
+    if (is_u8(p))  // f32 plane on the device, plus the byte image itself when it comes from the host
+        return plane + (mem_of(p) == CVS_MEM_HOST ? round_up(round_up((size_t)p->cols, 256) * p->rows / 4 + 64, 64) : 0);
+    return mem_of(p) == CVS_MEM_HOST ? plane : 0;
 }
 
 // resolve an input plane to a device pointer (uploading host data)
 int in_ref(Call& c, const cvs_plane* p, PlaneRef& r)
 {
     cvs_handle h = c.h;
+    if (is_u8(p)) {  // 8-bit image: bytes cross PCIe, widening happens on the device
+        const size_t pitch = round_up((size_t)p->cols, 64);
+        float* d = arena_take(h, pitch * p->rows);
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(p->data);
+        size_t sstep = p->step;
+        if (mem_of(p) == CVS_MEM_HOST) {
+            const size_t bpitch = round_up((size_t)p->cols, 256);
+            uint8_t* b = reinterpret_cast<uint8_t*>(arena_take(h, round_up(bpitch * p->rows / 4 + 64, 64)));
+            HIP_TRY(h, hipMemcpy2DAsync(b, bpitch, p->data, p->step, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, h->stream));
+            c.touched_host = true;
+            src = b;
+            sstep = bpitch;
+        }
+        HIP_TRY(h, launch_u8_to_f32(src, sstep, p->rows, p->cols, d, pitch, h->stream));
+        r = {d, pitch};
+        return CVS_OK;
+    }
     if (p->mem == CVS_MEM_DEVICE) {
         r = {p->data, p->step / sizeof(float)};
         return CVS_OK;
@@ -251,7 +280,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
              const cvs_plane* hq, const cvs_plane* const* pipe_outs = nullptr, int nframes = 1, int frame = 0)
 {
     if (!h) return CVS_E_BADARG;
-    int rc = check_plane(h, image, "image");
+    int rc = check_plane(h, image, "image", true);
     if (rc) return rc;
     if (!(flags & CVS_SETUP_BASIS)) flags |= CVS_SETUP_BASIS;
     if ((flags & CVS_SETUP_ORIENT) && h->kind != CVS_KIND_G2)
@@ -269,7 +298,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
             if (o && o->data == image->data) return fail(h, CVS_E_BADARG, "an output plane aliases the input image");
     }
     const size_t pitch = round_up((size_t)image->cols, 64);
-    size_t max_pitch = std::max(pitch, image->step / sizeof(float));
+    size_t max_pitch = std::max(pitch, is_u8(image) ? pitch : image->step / sizeof(float));
     if (steer) max_pitch = std::max(max_pitch, std::max(g->step, hq->step) / sizeof(float));
     if (pipe_outs)
         for (int k = 0; k < 8; ++k)
@@ -722,7 +751,7 @@ int cvs_pipeline(cvs_handle h, const cvs_plane* image, const cvs_plane* const ou
 {
     if (!h || !outs) return CVS_E_BADARG;
     if (h->kind != CVS_KIND_G2) return fail(h, CVS_E_UNSUPPORTED, "the caller pipeline exists for G2 only");
-    int rc = check_plane(h, image, "image");
+    int rc = check_plane(h, image, "image", true);
     if (rc) return rc;
     for (int o = 0; o < 8; ++o) {
         if (!outs[o]) continue;
@@ -741,9 +770,9 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     bool all_dev = true;
     size_t max_bytes = 0;
     for (int i = 0; i < n; ++i) {
-        if ((rc = check_plane(h, &images[i], "image")) || (rc = check_same(h, &images[i], rows, cols))) return rc;
-        all_dev = all_dev && images[i].mem == CVS_MEM_DEVICE;
-        max_bytes = std::max(max_bytes, (size_t)rows * images[i].step);
+        if ((rc = check_plane(h, &images[i], "image", true)) || (rc = check_same(h, &images[i], rows, cols))) return rc;
+        all_dev = all_dev && images[i].mem == CVS_MEM_DEVICE;  // f32 on the device; 8-bit / host frames go frame by frame
+        if (!is_u8(&images[i])) max_bytes = std::max(max_bytes, (size_t)rows * images[i].step);
         for (int k = 0; outs && k < 8; ++k) {
             const cvs_plane* o = &outs[(size_t)i * 8 + k];
             if (!o->data) continue;

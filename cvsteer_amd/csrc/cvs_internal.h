@@ -105,6 +105,7 @@ hipError_t launch_quantize_u8(const float* src, size_t pitch, int rows, int cols
 
 hipError_t launch_convert_u8(const float* src, size_t pitch, int rows, int cols, float alpha, float beta, uint8_t* dst,
                              size_t dst_step, hipStream_t s);
+hipError_t launch_u8_to_f32(const uint8_t* src, size_t sstep, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 
 // host-side tap math (cvs_taps.cpp, no HIP)

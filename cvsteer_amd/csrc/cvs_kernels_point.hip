@@ -330,6 +330,22 @@ hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, 
     return hipGetLastError();
 }
 
+// cv::Mat1f(const cv::Mat&) on an 8-bit image (test/test.cpp:85): widen to f32, unscaled
+__global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* src, size_t sstep, int rows, int cols, float* dst, size_t dpitch)
+{
+    for (int row = blockIdx.y; row < rows; row += gridDim.y)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x)
+            dst[(size_t)row * dpitch + c] = (float)src[(size_t)row * sstep + c];
+}
+
+hipError_t launch_u8_to_f32(const uint8_t* src, size_t sstep, int rows, int cols, float* dst, size_t dpitch, hipStream_t s)
+{
+    int gx = (cols + 255) / 256; if (gx > 16) gx = 16;
+    int gy = rows > 256 ? 256 : rows;
+    hipLaunchKernelGGL(k_u8_to_f32, dim3(gx, gy), dim3(256), 0, s, src, sstep, rows, cols, dst, dpitch);
+    return hipGetLastError();
+}
+
 // Mat::convertTo(dst, CV_8UC1, alpha, beta) (example/steer.cpp:94-96): saturate_cast<uchar>(v*alpha + beta)
 __global__ __launch_bounds__(256) void k_convert_u8(const float* src, size_t pitch, int rows, int cols, float alpha, float beta,
                                                      uint8_t* dst, size_t dst_step)

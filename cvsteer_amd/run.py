@@ -62,9 +62,13 @@ def process_file(engine, path, outdir, gain, ext=".png"):
     import torch
     gray = read_gray(path)
     dev = torch.device("cuda", engine.device)
-    img = torch.from_numpy(np.ascontiguousarray(gray)).to(dev).to(torch.float32)  # u8 crosses PCIe as u8
+    img = torch.from_numpy(np.ascontiguousarray(gray))
+    if img.dtype != torch.uint8:
+        img = img.to(torch.float32)
+    img = img.to(dev)  # 8-bit images cross PCIe as bytes and are widened by the engine (CVS_DEPTH_U8)
     # one launch; only the three feature maps leave the kernel (set_persist(False): no state planes)
-    outs = engine.pipeline(img, out=[None] * 5 + [torch.empty_like(img) for _ in range(3)])
+    feat = [torch.empty(tuple(img.shape), dtype=torch.float32, device=dev) for _ in range(3)]
+    outs = engine.pipeline(img, out=[None] * 5 + feat)
     base = os.path.splitext(os.path.basename(path))[0]
     written = []
     for plane, suffix in zip(outs[5:], ("_edges", "_lines_dark", "_lines_bright")):

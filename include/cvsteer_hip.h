@@ -48,6 +48,11 @@ enum {
 
 enum { CVS_KIND_G2 = 2, CVS_KIND_G4 = 4 };
 enum { CVS_MEM_HOST = 0, CVS_MEM_DEVICE = 1 };
+/* OR-ed into cvs_plane.mem of an INPUT IMAGE (cvs_setup / cvs_setup_steer / cvs_pipeline[_batch]): `data` points
+ * at 8-bit samples (`step` >= cols bytes).  The reference's callers hand 8-bit images to the constructor and let
+ * cv::Mat1f(const Mat&) widen them unscaled (test/test.cpp:73,85; example/steer.cpp:73-86); here the 8-bit data
+ * crosses PCIe as bytes and is widened on the device. */
+enum { CVS_DEPTH_U8 = 0x100 };
 
 /* cvs_setup flags */
 enum {

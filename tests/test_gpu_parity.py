@@ -574,3 +574,26 @@ def test_stateless_pipeline_outputs_only(cv):
     eng.set_persist(True)
     eng.pipeline(frames[1])
     assert torch.equal(eng.getDominantOrientationAngle(), cv.SteerableFiltersG2(frames[1]).getDominantOrientationAngle())
+
+
+def test_8bit_input_images(cv, ora, fish, golden_dir):
+    """CVS_DEPTH_U8: 8-bit images are widened on the device, unscaled, like cv::Mat1f(const Mat&) (test.cpp:85)"""
+    import torch
+    u8 = np.load(os.path.join(golden_dir, "fish_u8.npy"))
+    ref = cv.SteerableFiltersG2(fish).pipeline(fish)
+    for img in (u8, torch.from_numpy(u8).cuda(), u8[3:150, 10:200]):
+        f = cv.SteerableFiltersG2(None)
+        got = f.pipeline(img)
+        want = ref if img.shape == u8.shape else cv.SteerableFiltersG2(None).pipeline(np.ascontiguousarray(fish[3:150, 10:200]))
+        for a, b in zip(got, want):
+            a = a.cpu().numpy() if hasattr(a, "cpu") else a
+            assert a.dtype == np.float32 and np.array_equal(a, b)
+    f = cv.SteerableFiltersG2(u8)                    # constructor path, as test.cpp:85 does
+    assert np.array_equal(f.basis(0), cv.SteerableFiltersG2(fish).basis(0))
+    g1, h1 = cv.SteerableFiltersG4(u8).steer(0.3)
+    g2, h2 = cv.SteerableFiltersG4(fish).steer(0.3)
+    assert np.array_equal(g1, g2) and np.array_equal(h1, h2)
+    out = cv.SteerableFiltersG2(None).pipeline_batch(np.stack([u8, u8[::-1].copy()]))
+    assert np.array_equal(out[0, 5], ref[5])
+    with pytest.raises(cv.CvsError):                 # 8-bit planes are inputs only
+        f.computeMagnitudeAndPhase(u8, u8)
