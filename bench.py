@@ -179,6 +179,20 @@ def main():
         f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)
         leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"])
         leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"])
+        # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed
+        # start-up cost of a launch (every wave primes its 8-row window before its first store) amortises
+        big2 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
+        fb = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+        gb, hb = torch.empty_like(big2), torch.empty_like(big2)
+        bsteps = max(5, args.steps // 4)
+        for nm, fn, bpp in (("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32),
+                            ("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40)):
+            w_, e_ = _time_steps(torch, fn, bsteps, 3, barrier)
+            ms = e_ / bsteps
+            extra[nm] = {"Mpix/s": round(4 * npix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5),
+                         "GB/s": round(bpp * 4 * npix / (ms * 1e-3) / 1e9, 1),
+                         "frac_hbm": round(bpp * 4 * npix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": bpp}
+        del big2, fb, gb, hb
         # BASELINE config 4 frame shape: 1080 x 1920 frames resident in HBM, full pipeline per frame
         nfr = 32
         frames = torch.rand((nfr, 1080, 1920), generator=gen, device=dev, dtype=torch.float32)

@@ -17,9 +17,13 @@ def timeit(fn, steps=30, warm=5):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    img = torch.rand((n, n), device="cuda")
+    m = int(sys.argv[2]) if len(sys.argv) > 2 else n     # rows x cols = n x m
+    kinds = sys.argv[3].split(",") if len(sys.argv) > 3 else ["G2", "G4"]
+    img = torch.rand((n, m), device="cuda")
     g, h = torch.empty_like(img), torch.empty_like(img)
     for kind, cls, bpp in (("G2", cv.SteerableFiltersG2, 32), ("G4", cv.SteerableFiltersG4, 48)):
+        if kind not in kinds:
+            continue
         f = cls(None)
         nt_, halo = (9, 8) if kind == "G2" else (13, 12)
         for pol, split in ((1, 1), (2, 1), (2, 0)) if kind == "G4" else ((1, 1), (2, 1)):
@@ -31,8 +35,8 @@ def main():
                 ms = timeit(lambda: f.setup(img, flags=cv.SETUP_BASIS))
                 ms2 = timeit(lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h)))
                 print("%s split=%d policy=%s strip_rows=%3d  basis %.4f ms %7.0f Mpix/s %6.0f GB/s (%.1f%%) | +steer %.4f ms %7.0f Mpix/s %6.0f GB/s" % (
-                    kind, split, "plain" if pol == 1 else "nt", sr, ms, n*n/ms/1e3, bpp*n*n/ms/1e6, bpp*n*n/ms/1e6/80,
-                    ms2, n*n/ms2/1e3, (bpp+8)*n*n/ms2/1e6), flush=True)
+                    kind, split, "plain" if pol == 1 else "nt", sr, ms, n*m/ms/1e3, bpp*n*m/ms/1e6, bpp*n*m/ms/1e6/80,
+                    ms2, n*m/ms2/1e3, (bpp+8)*n*m/ms2/1e6), flush=True)
 
 if __name__ == "__main__":
     main()
