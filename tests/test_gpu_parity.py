@@ -597,3 +597,27 @@ def test_8bit_input_images(cv, ora, fish, golden_dir):
     assert np.array_equal(out[0, 5], ref[5])
     with pytest.raises(cv.CvsError):                 # 8-bit planes are inputs only
         f.computeMagnitudeAndPhase(u8, u8)
+
+
+def test_random_shapes_fuzz(cv, ora):
+    """seeded shape fuzz across the fast / generic path boundaries (rows around 3W+1, cols around W+1 and
+    around multiples of 64, strip boundaries): basis planes and the fused pipeline vs the oracle"""
+    rng = np.random.default_rng(2024)
+    shapes = [(13, 5), (12, 70), (14, 64), (19, 65), (27, 63), (28, 128), (20, 129), (38, 191), (57, 257)]
+    shapes += [(int(rng.integers(1, 140)), int(rng.integers(1, 330))) for _ in range(16)]
+    for rows, cols in shapes:
+        img = rng.random((rows, cols), dtype=np.float32)
+        f2 = cv.SteerableFiltersG2(img)
+        got = np.stack([f2.basis(p) for p in range(7)])
+        assert np.abs(got - ora.basis(2, img, 4, 0.67, f64=True)).max() <= TOL, (rows, cols)
+        f4 = cv.SteerableFiltersG4(img)
+        got4 = np.stack([f4.basis(p) for p in range(11)])
+        assert np.abs(got4 - ora.basis(4, img, 6, 0.5, f64=True)).max() <= TOL, (rows, cols)
+        # fused pipeline == stepwise on the same handle state
+        outs = cv.SteerableFiltersG2(None).pipeline(img)
+        step = f2.steer(None, full=True)
+        for a, b in zip(outs[:5], step):
+            assert np.array_equal(a, b), (rows, cols)
+        g4, h4 = cv.SteerableFiltersG4(None).setup_steer(img, -0.7)
+        og, oh = ora.g4_steer_scalar(got4, -0.7)
+        assert np.abs(g4 - og).max() <= 1e-6 and np.abs(h4 - oh).max() <= 1e-6, (rows, cols)
