@@ -43,7 +43,7 @@ struct cvs_context {
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
     float* point_out = nullptr;
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 1, xcd_map = 0, persist = 1;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, xcd_map = 0, persist = 1;
     std::string err;
 };
 
@@ -250,15 +250,14 @@ int default_strip_rows(cvs_handle h, int rows, int cols)
 {
     if (h->strip_rows > 0) return h->strip_rows;
     // strips whose (rows + 2W) is a multiple of the 2W+1-row unroll waste no loop iterations.
-    // Measured on MI355X at 4096x4096 (tools/tune.py, streaming stores): the 7-plane G2 kernel is
-    // fastest with short strips (10-19 rows: ~14k waves keep every CU's store queues busy and the
-    // extra halo rows are L2 hits); the register-heavy 11-plane G4 kernel (2 waves/SIMD) prefers
-    // long strips (~131 rows) that amortise its 12 halo rows of row-pass work.
+    // Measured on MI355X at 4096x4096 (tools/ab.py, tools/ab_g4.py; streaming stores): short strips
+    // win -- 19 rows for the 7-plane G2 kernel (~14k waves keep every CU's store queues busy, the
+    // extra halo rows are cache hits), 27 rows for the G4 half banks run in one launch.
     const int nt = 2 * h->width + 1, halo = 2 * h->width;
     const long strips_x = (cols + 63) / 64;
     const double ideal = (double)rows * (double)strips_x / 2048.0;
     long k = std::lround((ideal + halo) / nt);
-    const long kmax = h->kind == CVS_KIND_G2 ? 3 : 11;
+    const long kmax = 3;
     if (k < 2) k = 2;
     if (k > kmax) k = kmax;
     return (int)(k * nt - halo);
@@ -521,7 +520,7 @@ int cvs_set_option(cvs_handle h, int option, int value)
             h->store_policy = value;
             return CVS_OK;
         case CVS_OPT_G4_SPLIT:
-            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "g4 split");
+            if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "g4 split");
             h->g4_split = value;
             return CVS_OK;
         case CVS_OPT_PERSIST_STATE:

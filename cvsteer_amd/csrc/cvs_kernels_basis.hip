@@ -144,12 +144,13 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool ONE = false>
-__global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
+// the kernel body: one wave filters one strip.  `line` = this wave's LDS line (64 + 2W + 4 floats),
+// `zframe` = frame index of a batched launch.
+template <class B, int FLAGS, bool STREAM, bool BATCH, bool ONE>
+__device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe)
 {
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
     constexpr int LW = 64 + 2 * W;
-    __shared__ float lds[4][LW + 4];
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -183,7 +184,6 @@ __global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis(const BasisArgs a, 
     // left halo -> [0,W), right -> [64+W, 64+2W); lanes that carry no halo value write into the
     // 4 pad words behind the line, so the staging code has no exec-mask branch
     const int hslot = lane < W ? lane : (is_halo ? 64 + lane : LW + (lane & 3));
-    float* line = lds[wv];
     // per-frame pointers: kernel arguments, or (batched launch) entry blockIdx.z of the frame table
     const float* in_p = a.in;
     size_t in_pitch = a.in_pitch;
@@ -191,11 +191,11 @@ __global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis(const BasisArgs a, 
     float* orient_p = a.orient;
     PlaneRef pipe_out[8];
     if constexpr (BATCH) {
-        const BatchFrame* fr = a.frames + blockIdx.z;
+        const BatchFrame* fr = a.frames + zframe;
         in_p = reinterpret_cast<const float*>(uniform64(reinterpret_cast<unsigned long long>(fr->in)));
         in_pitch = uniform64(fr->in_pitch);
-        basis_p += (size_t)blockIdx.z * a.frame_stride;
-        orient_p += (size_t)blockIdx.z * a.frame_stride;
+        basis_p += (size_t)zframe * a.frame_stride;
+        orient_p += (size_t)zframe * a.frame_stride;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             pipe_out[k].p = reinterpret_cast<float*>(uniform64(reinterpret_cast<unsigned long long>(fr->out[k].p)));
@@ -377,6 +377,24 @@ __global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis(const BasisArgs a, 
     }
 }
 
+template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool ONE = false>
+__global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
+{
+    __shared__ float lds[4][64 + 2 * B::W + 4];
+    basis_body<B, FLAGS, STREAM, BATCH, ONE>(a, t, lds[threadIdx.x >> 6], blockIdx.z);
+}
+
+// G4+H4 in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
+// one launch start-up / tail and read the same image rows at about the same time (L2 hits), while each
+// keeps its half-size register window.
+template <int FLAGS, bool STREAM, bool ONE>
+__global__ __launch_bounds__(256) void k_basis_g4pair(const BasisArgs a, const Folded<BankG4G> tg, const Folded<BankG4H> th)
+{
+    __shared__ float lds[4][64 + 2 * BankG4G::W + 4];
+    if (blockIdx.z == 0) basis_body<BankG4G, FLAGS, STREAM, false, ONE>(a, tg, lds[threadIdx.x >> 6], 0);
+    else basis_body<BankG4H, FLAGS, STREAM, false, ONE>(a, th, lds[threadIdx.x >> 6], 0);
+}
+
 // ---------------------------------------------------------------------------------------
 // generic-width fallback (any width <= kMaxWidth, any taps): two plain passes through a
 // scratch plane, one basis plane at a time.  Same summation order as the CPU reference's
@@ -515,6 +533,28 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     return hipGetLastError();
 }
 
+static hipError_t launch_g4pair(const BasisArgs& a_in, const Folded<BankG4G>& fg, const Folded<BankG4H>& fh, hipStream_t s)
+{
+    BasisArgs a = a_in;
+    const int strips_x = (a.cols + 63) / 64;
+    dim3 grid((strips_x + 3) / 4, (a.rows + a.strip_rows - 1) / a.strip_rows, 2), block(256);
+    a.grid_x = grid.x;
+    a.grid_y = grid.y;
+    a.xcd_map = 0;
+    const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
+    const bool one = (size_t)(11 + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;
+#define CVS_PAIR(FL, ST, ON) hipLaunchKernelGGL((k_basis_g4pair<FL, ST, ON>), grid, block, 0, s, a, fg, fh)
+    if (steer) {
+        if (a.nt_stores) { if (one) CVS_PAIR(F_STEER, true, true); else CVS_PAIR(F_STEER, true, false); }
+        else { if (one) CVS_PAIR(F_STEER, false, true); else CVS_PAIR(F_STEER, false, false); }
+    } else {
+        if (a.nt_stores) { if (one) CVS_PAIR(0, true, true); else CVS_PAIR(0, true, false); }
+        else { if (one) CVS_PAIR(0, false, true); else CVS_PAIR(0, false, false); }
+    }
+#undef CVS_PAIR
+    return hipGetLastError();
+}
+
 static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
                                  float* scratch, hipStream_t s)
 {
@@ -587,6 +627,11 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
     if (kind == 2 && width == BankG2::W) {
         Folded<BankG2> f;
         if (fold_taps<BankG2>(taps, f)) return launch_fast<BankG2>(a, f, s);
+    }
+    if (kind == 4 && width == BankG4::W && a.g4_split == 2) {
+        Folded<BankG4G> fg;
+        Folded<BankG4H> fh;
+        if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh)) return launch_g4pair(a, fg, fh, s);
     }
     if (kind == 4 && width == BankG4::W) {
         if (a.g4_split) {

@@ -70,7 +70,8 @@ enum {
     CVS_OPT_PERSIST_STATE = 9, /* cvs_pipeline / cvs_pipeline_batch: 1 (default) = keep basis + orientation planes like the
                                   reference object does; 0 = write the requested outputs only (no state afterwards) */
     CVS_OPT_XCD_MAP = 8,     /* basis kernel: 1 = pin row bands to XCDs through the block-id map (tuning) */
-    CVS_OPT_G4_SPLIT = 5,    /* G4: 1 = G half and H half as two launches (default), 0 = one 11-plane launch */
+    CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
+                                launch (blockIdx.z picks the half) */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
                                 256 MiB Infinity Cache), 1 = plain, 2 = always nontemporal (tuning) */
 };

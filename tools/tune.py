@@ -26,7 +26,7 @@ def main():
             continue
         f = cls(None)
         nt_, halo = (9, 8) if kind == "G2" else (13, 12)
-        for pol, split in ((1, 1), (2, 1), (2, 0)) if kind == "G4" else ((1, 1), (2, 1)):
+        for pol, split in ((2, 1), (2, 0), (2, 2)) if kind == "G4" else ((1, 1), (2, 1)):
             f.set_option(L.OPT_STORE_POLICY, pol)
             f.set_option(L.OPT_G4_SPLIT, split)
             for k in (2, 3, 4, 6, 8, 11, 15, 22):
