@@ -40,7 +40,7 @@ struct BasisArgs {
     int strip_rows;       // output rows per wave strip
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
-    int g4_split;         // 1 = run the G4 bank as two launches (G half, H half)
+    int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
     int xcd_map;          // 1 = 1-D grid, row bands pinned to XCDs (see k_basis)
     int grid_x, grid_y;   // filled by the launcher
     // fused caller pipeline (needs orient): g2,h2,e,mag,phase,edges,dark,bright at theta_dom

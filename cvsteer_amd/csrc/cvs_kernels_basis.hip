@@ -360,15 +360,15 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         else g4_steer_weights(b, a.steer_w, gq, hq);
                         bst<STREAM>(rg, xbr, og, gq);
                         bst<STREAM>(rh, xbr, oh, hq);
-                    } else if constexpr (B::HALF == 1) {  // G4.cpp:120, summed left to right
+                    } else if constexpr (B::HALF == 1) {  // the G sum of G2.cpp:143 / G4.cpp:120, left to right
                         float gq = __fadd_rn(__fmul_rn(a.steer_w[0], b[0]), __fmul_rn(a.steer_w[1], b[1]));
 #pragma unroll
-                        for (int p = 2; p < 5; ++p) gq = __fadd_rn(gq, __fmul_rn(a.steer_w[p], b[p]));
+                        for (int p = 2; p < NB; ++p) gq = __fadd_rn(gq, __fmul_rn(a.steer_w[p], b[p]));
                         bst<STREAM>(rg, xbr, og, gq);
-                    } else {  // G4.cpp:121
-                        float hq = __fadd_rn(__fmul_rn(a.steer_w[5], b[0]), __fmul_rn(a.steer_w[6], b[1]));
+                    } else {  // the H sum of G2.cpp:144 / G4.cpp:121
+                        float hq = __fadd_rn(__fmul_rn(a.steer_w[B::PLANE0], b[0]), __fmul_rn(a.steer_w[B::PLANE0 + 1], b[1]));
 #pragma unroll
-                        for (int p = 2; p < 6; ++p) hq = __fadd_rn(hq, __fmul_rn(a.steer_w[5 + p], b[p]));
+                        for (int p = 2; p < NB; ++p) hq = __fadd_rn(hq, __fmul_rn(a.steer_w[B::PLANE0 + p], b[p]));
                         bst<STREAM>(rh, xbr, oh, hq);
                     }
                 }
@@ -384,15 +384,15 @@ __global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis(const BasisArgs a, 
     basis_body<B, FLAGS, STREAM, BATCH, ONE>(a, t, lds[threadIdx.x >> 6], blockIdx.z);
 }
 
-// G4+H4 in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
+// G + H half banks in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
 // one launch start-up / tail and read the same image rows at about the same time (L2 hits), while each
 // keeps its half-size register window.
-template <int FLAGS, bool STREAM, bool ONE>
-__global__ __launch_bounds__(256) void k_basis_g4pair(const BasisArgs a, const Folded<BankG4G> tg, const Folded<BankG4H> th)
+template <class BG, class BH, int FLAGS, bool STREAM, bool ONE>
+__global__ __launch_bounds__(256) void k_basis_pair(const BasisArgs a, const Folded<BG> tg, const Folded<BH> th)
 {
-    __shared__ float lds[4][64 + 2 * BankG4G::W + 4];
-    if (blockIdx.z == 0) basis_body<BankG4G, FLAGS, STREAM, false, ONE>(a, tg, lds[threadIdx.x >> 6], 0);
-    else basis_body<BankG4H, FLAGS, STREAM, false, ONE>(a, th, lds[threadIdx.x >> 6], 0);
+    __shared__ float lds[4][64 + 2 * BG::W + 4];
+    if (blockIdx.z == 0) basis_body<BG, FLAGS, STREAM, false, ONE>(a, tg, lds[threadIdx.x >> 6], 0);
+    else basis_body<BH, FLAGS, STREAM, false, ONE>(a, th, lds[threadIdx.x >> 6], 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -533,7 +533,8 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     return hipGetLastError();
 }
 
-static hipError_t launch_g4pair(const BasisArgs& a_in, const Folded<BankG4G>& fg, const Folded<BankG4H>& fh, hipStream_t s)
+template <class BG, class BH>
+static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const Folded<BH>& fh, hipStream_t s)
 {
     BasisArgs a = a_in;
     const int strips_x = (a.cols + 63) / 64;
@@ -542,8 +543,9 @@ static hipError_t launch_g4pair(const BasisArgs& a_in, const Folded<BankG4G>& fg
     a.grid_y = grid.y;
     a.xcd_map = 0;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
-    const bool one = (size_t)(11 + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;
-#define CVS_PAIR(FL, ST, ON) hipLaunchKernelGGL((k_basis_g4pair<FL, ST, ON>), grid, block, 0, s, a, fg, fh)
+    constexpr int NBTOT = BG::KIND == 2 ? 7 : 11;
+    const bool one = (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;
+#define CVS_PAIR(FL, ST, ON) hipLaunchKernelGGL((k_basis_pair<BG, BH, FL, ST, ON>), grid, block, 0, s, a, fg, fh)
     if (steer) {
         if (a.nt_stores) { if (one) CVS_PAIR(F_STEER, true, true); else CVS_PAIR(F_STEER, true, false); }
         else { if (one) CVS_PAIR(F_STEER, false, true); else CVS_PAIR(F_STEER, false, false); }
@@ -631,7 +633,7 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
     if (kind == 4 && width == BankG4::W && a.g4_split == 2) {
         Folded<BankG4G> fg;
         Folded<BankG4H> fh;
-        if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh)) return launch_g4pair(a, fg, fh, s);
+        if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh)) return launch_pair<BankG4G, BankG4H>(a, fg, fh, s);
     }
     if (kind == 4 && width == BankG4::W) {
         if (a.g4_split) {
