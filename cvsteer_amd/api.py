@@ -394,20 +394,46 @@ class SteerableFiltersG2(SteerableFilters):
 
 
 class SteerableFiltersG4(SteerableFilters):
-    """fa::SteerableFiltersG4 (SteerableFiltersG4.h:35-57): setup + steer only."""
+    """fa::SteerableFiltersG4 (SteerableFiltersG4.h:35-57): setup + steer only.
+
+    extensions=True switches on what the reference leaves unfinished (G4.h:55, G4.cpp:88-90): dominant
+    orientation / strength / C1..C3 derived from the G4/H4 steering polynomials, steer(..., full=True)
+    and a working computeMagnitudeAndPhase.  Off by default: then the class behaves exactly like the
+    reference (empty getters, no-op computeMagnitudeAndPhase)."""
 
     KIND = L.KIND_G4
     DEFAULT_WIDTH = 6
     DEFAULT_SPACING = 0.5
     _DEFAULT_FLAGS = SETUP_BASIS
 
+    def __init__(self, image=None, width=None, spacing=None, device=None, setup_flags=None, extensions=False):
+        self.extensions = bool(extensions)
+        super().__init__(None, width, spacing, device, setup_flags)
+        if self.extensions:
+            self.set_option(L.OPT_G4_EXTENSIONS, 1)
+            if setup_flags is None:
+                self._setup_flags = SETUP_FULL
+        if image is not None:
+            self.setup(image)
+
     def getDominantOrientationAngle(self):
-        """never assigned in the reference (G4.h:55): an empty Mat"""
-        return np.empty((0, 0), np.float32)
+        """never assigned in the reference (G4.h:55): an empty Mat -- unless extensions are on"""
+        return self._state(L.PLANE_THETA) if self.extensions else np.empty((0, 0), np.float32)
 
     def getDominantOrientationStrength(self):
-        return np.empty((0, 0), np.float32)
+        return self._state(L.PLANE_STRENGTH) if self.extensions else np.empty((0, 0), np.float32)
+
+    def coefficients(self):
+        if not self.extensions:
+            raise CvsError(L.E_UNSUPPORTED, "coefficients", "G4 orientation is an extension (extensions=True)")
+        return tuple(self._state(w) for w in (L.PLANE_C1, L.PLANE_C2, L.PLANE_C3))
 
     def computeMagnitudeAndPhase(self, g4, h4, magnitude=None, phase=None):
-        """empty body in the reference (G4.cpp:88-90): outputs untouched"""
-        return magnitude, phase
+        """empty body in the reference (G4.cpp:88-90): outputs untouched -- unless extensions are on"""
+        if not self.extensions:
+            return magnitude, phase
+        mag, ph = self._new_like(g4), self._new_like(g4)
+        self._bind_stream(g4, h4, mag, ph)
+        pg, phh, pm, pp = _plane(g4), _plane(h4), _plane(mag), _plane(ph)
+        self._check(lib().cvs_mag_phase(self._h, C.byref(pg), C.byref(phh), C.byref(pm), C.byref(pp)), "cvs_mag_phase")
+        return mag, ph

@@ -43,7 +43,7 @@ struct cvs_context {
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
     float* point_out = nullptr;
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, xcd_map = 0, persist = 1;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, xcd_map = 0, persist = 1, g4_ext = 0;
     std::string err;
 };
 
@@ -282,8 +282,8 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     int rc = check_plane(h, image, "image", true);
     if (rc) return rc;
     if (!(flags & CVS_SETUP_BASIS)) flags |= CVS_SETUP_BASIS;
-    if ((flags & CVS_SETUP_ORIENT) && h->kind != CVS_KIND_G2)
-        return fail(h, CVS_E_UNSUPPORTED, "the reference computes no orientation for G4 (G4.cpp:67-81)");
+    if ((flags & CVS_SETUP_ORIENT) && h->kind != CVS_KIND_G2 && !h->g4_ext)
+        return fail(h, CVS_E_UNSUPPORTED, "the reference computes no orientation for G4 (G4.cpp:67-81); see CVS_OPT_G4_EXTENSIONS");
     if (steer) {
         if ((rc = check_plane(h, g, "g")) || (rc = check_plane(h, hq, "hq"))) return rc;
         if ((rc = check_same(h, g, image->rows, image->cols)) || (rc = check_same(h, hq, image->rows, image->cols))) return rc;
@@ -324,7 +324,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.basis = state_plane(h, 0);
     a.pitch = h->pitch;
     a.plane_stride = h->plane_stride;
-    a.orient = (flags & CVS_SETUP_ORIENT) ? state_plane(h, h->nb) : nullptr;
+    a.orient = ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G2) ? state_plane(h, h->nb) : nullptr;
     a.atan_mode = h->atan_mode;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
@@ -348,6 +348,16 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     }
     float* scr = scratch ? arena_take(h, scratch) : nullptr;
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
+    if ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G4) {  // extension: one per-pixel pass over the 11 planes
+        PointArgs pa{};
+        pa.rows = a.rows;
+        pa.cols = a.cols;
+        pa.atan_mode = h->atan_mode;
+        pa.nt_stores = a.nt_stores;
+        for (int p = 0; p < 11; ++p) pa.in[p] = {state_plane(h, p), h->pitch};
+        for (int i = 0; i < 5; ++i) pa.out[i] = {state_plane(h, h->nb + i), h->pitch};
+        HIP_TRY(h, launch_point(OP_G4_ORIENT, pa, h->stream));
+    }
     // a pipeline run with CVS_OPT_PERSIST_STATE = 0 wrote its outputs only: no state to address afterwards
     h->have_basis = !(pipe_outs && !h->persist);
     h->have_orient = h->have_basis && (flags & CVS_SETUP_ORIENT) != 0;
@@ -378,8 +388,8 @@ int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map
         if (!p) continue;
         if ((rc = check_plane(h, p, "plane")) || (rc = check_same(h, p, h->rows, h->cols))) return rc;
     }
-    if (h->kind == CVS_KIND_G4 && (e || mag || phase))
-        return fail(h, CVS_E_UNSUPPORTED, "G4 has no energy / magnitude / phase in the reference (G4.cpp:88-90)");
+    if (h->kind == CVS_KIND_G4 && (e || mag || phase) && !h->g4_ext)
+        return fail(h, CVS_E_UNSUPPORTED, "G4 has no energy / magnitude / phase in the reference (G4.cpp:88-90); see CVS_OPT_G4_EXTENSIONS");
     if (e && (rc = need_state(h, true))) return rc;
     if (map && !theta_map && (rc = need_state(h, true))) return rc;
 
@@ -391,8 +401,8 @@ int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map
     a.atan_mode = h->atan_mode;
     basis_inputs(h, a);
     const int nb = h->nb;
-    if (h->kind == CVS_KIND_G2 && e) {
-        for (int i = 0; i < 3; ++i) a.in[7 + i] = {state_plane(h, nb + i), h->pitch};
+    if (e) {  // C1..C3 follow the basis planes: in[7..9] (G2) / in[11..13] (G4 extension)
+        for (int i = 0; i < 3; ++i) a.in[nb + i] = {state_plane(h, nb + i), h->pitch};
     }
     if (map) {
         PlaneRef th;
@@ -401,7 +411,7 @@ int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map
         } else {
             th = {state_plane(h, nb + 3), h->pitch};
         }
-        a.in[h->kind == CVS_KIND_G2 ? 10 : 11] = th;
+        a.in[h->kind == CVS_KIND_G2 ? 10 : 14] = th;
     } else {
         host_steer_weights(h->kind, theta, a.w);
         // G2.cpp:162: float c2t(std::cos(theta * 2.0)) -- double argument, narrowed
@@ -409,7 +419,7 @@ int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map
         a.s2t = (float)std::sin((double)theta * 2.0);
     }
     const cvs_plane* outs[5] = {g, hq, e, mag, phase};
-    for (int o = 0; o < (h->kind == CVS_KIND_G2 ? 5 : 2); ++o)
+    for (int o = 0; o < 5; ++o)
         if ((rc = out_ref(c, outs[o], a.out[o]))) return rc;
     PointOp op = h->kind == CVS_KIND_G2 ? (map ? OP_G2_STEER_MAP : OP_G2_STEER_SCALAR)
                                         : (map ? OP_G4_STEER_MAP : OP_G4_STEER_SCALAR);
@@ -523,6 +533,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "g4 split");
             h->g4_split = value;
             return CVS_OK;
+        case CVS_OPT_G4_EXTENSIONS:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "g4 extensions");
+            h->g4_ext = value;
+            return CVS_OK;
         case CVS_OPT_PERSIST_STATE:
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "persist");
             h->persist = value;
@@ -546,6 +560,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
         case CVS_OPT_XCD_MAP: *value = h->xcd_map; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
+        case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }

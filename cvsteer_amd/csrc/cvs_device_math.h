@@ -150,6 +150,50 @@ __device__ inline void g2_orientation(const float b[7], int mode, float& c1, flo
     theta = __fmul_rn(wrap_pi(angle_0_2pi(v3, v2, mode)), 0.5f);
 }
 
+// ---- EXTENSION beyond the reference (opt-in through CVS_OPT_G4_EXTENSIONS) ----
+// The reference never computes G4/H4 orientation (G4.h:55 members unused).  The coefficients follow
+// from its own steering polynomials (G4.cpp:116-119) exactly as G2.cpp:93-95 follow from G2's:
+//   E(theta) = g4(theta)^2 + h4(theta)^2 = C1 + C2 cos 2theta + C3 sin 2theta + [4..10 theta terms],
+// with g4 = sum kg_i(theta) G_i, h4 = sum kh_i(theta) H_i; the table holds the mean, the cos 2theta and
+// the sin 2theta Fourier coefficients of every product kg_i kg_j / kh_i kh_j (tools/gen_g4_orient.py;
+// the same procedure reproduces the reference's G2 constants 0.5, 0.25, 0.375, ...).  All entries are
+// dyadic rationals, exact in f32.  theta = wrap(atan2(C3, C2)) / 2 and strength = |(C2, C3)|, the
+// convention of G2.cpp:97-99.  b = {g4a..g4e, h4a..h4f}.
+struct G4Term { signed char i, j, which; float k; };  // which: 1 -> C1, 2 -> C2, 3 -> C3
+__device__ __constant__ const G4Term kG4Terms[] = {
+    // G part (plane indices 0..4)
+    {0, 0, 1, 35.f / 128}, {0, 0, 2, 7.f / 16}, {0, 1, 3, -7.f / 8}, {0, 2, 1, 15.f / 32}, {0, 2, 2, 3.f / 8},
+    {0, 3, 3, -3.f / 8}, {0, 4, 1, 3.f / 64}, {1, 1, 1, 5.f / 8}, {1, 1, 2, 1.f / 2}, {1, 2, 3, -9.f / 4},
+    {1, 3, 1, 3.f / 4}, {1, 4, 3, -3.f / 8}, {2, 2, 1, 27.f / 32}, {2, 3, 3, -9.f / 4}, {2, 4, 1, 15.f / 32},
+    {2, 4, 2, -3.f / 8}, {3, 3, 1, 5.f / 8}, {3, 3, 2, -1.f / 2}, {3, 4, 3, -7.f / 8}, {4, 4, 1, 35.f / 128},
+    {4, 4, 2, -7.f / 16},
+    // H part (plane indices 5..10)
+    {5, 5, 1, 63.f / 256}, {5, 5, 2, 105.f / 256}, {5, 6, 3, -105.f / 128}, {5, 7, 1, 35.f / 64}, {5, 7, 2, 35.f / 64},
+    {5, 8, 3, -35.f / 64}, {5, 9, 1, 15.f / 128}, {5, 9, 2, 5.f / 128}, {5, 10, 3, -5.f / 128}, {6, 6, 1, 175.f / 256},
+    {6, 6, 2, 175.f / 256}, {6, 7, 3, -175.f / 64}, {6, 8, 1, 75.f / 64}, {6, 8, 2, 25.f / 64}, {6, 9, 3, -125.f / 128},
+    {6, 10, 1, 15.f / 128}, {6, 10, 2, -5.f / 128}, {7, 7, 1, 75.f / 64}, {7, 7, 2, 25.f / 64}, {7, 8, 3, -125.f / 32},
+    {7, 9, 1, 75.f / 64}, {7, 9, 2, -25.f / 64}, {7, 10, 3, -35.f / 64}, {8, 8, 1, 75.f / 64}, {8, 8, 2, -25.f / 64},
+    {8, 9, 3, -175.f / 64}, {8, 10, 1, 35.f / 64}, {8, 10, 2, -35.f / 64}, {9, 9, 1, 175.f / 256}, {9, 9, 2, -175.f / 256},
+    {9, 10, 3, -105.f / 128}, {10, 10, 1, 63.f / 256}, {10, 10, 2, -105.f / 256},
+};
+
+__device__ inline void g4_orientation(const float b[11], int mode, float& c1, float& c2, float& c3,
+                                      float& theta, float& strength)
+{
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    constexpr int n = sizeof(kG4Terms) / sizeof(kG4Terms[0]);
+#pragma unroll
+    for (int t = 0; t < n; ++t) {  // table order, every product and sum rounded to f32
+        const float term = __fmul_rn(kG4Terms[t].k, __fmul_rn(b[kG4Terms[t].i], b[kG4Terms[t].j]));
+        if (kG4Terms[t].which == 1) v1 = __fadd_rn(v1, term);
+        else if (kG4Terms[t].which == 2) v2 = __fadd_rn(v2, term);
+        else v3 = __fadd_rn(v3, term);
+    }
+    c1 = v1; c2 = v2; c3 = v3;
+    strength = __fsqrt_rn(__fadd_rn(__fmul_rn(v2, v2), __fmul_rn(v3, v3)));
+    theta = __fmul_rn(wrap_pi(angle_0_2pi(v3, v2, mode)), 0.5f);
+}
+
 // steer(float theta, ...) G2.cpp:143-144: (ga*A + gb*B) + gc*C, every node rounded
 __device__ inline void g2_steer_weights(const float b[7], const float w[7], float& g, float& h)
 {

@@ -68,13 +68,14 @@ enum PointOp {
     OP_G2_ORIENT = 0,      // in: 7 basis                     out: c1,c2,c3,theta,strength
     OP_G2_STEER_SCALAR,    // in: 7 basis [,c1,c2,c3]          out: g,h[,e,mag,phase]
     OP_G2_STEER_MAP,       // in: 7 basis, theta [,c1,c2,c3]   out: g,h[,e,mag,phase]
-    OP_G4_STEER_SCALAR,    // in: 11 basis                    out: g,h
-    OP_G4_STEER_MAP,       // in: 11 basis, theta             out: g,h
+    OP_G4_STEER_SCALAR,    // in: 11 basis [,c1,c2,c3]         out: g,h[,e,mag,phase: extension]
+    OP_G4_STEER_MAP,       // in: 11 basis [,c1..c3], theta@14 out: g,h[,e,mag,phase: extension]
     OP_MAG_PHASE,          // in: g,h                          out: mag,phase
     OP_PHASE_WEIGHTS,      // in: phase                        out: lambda
     OP_FIND,               // in: e,phase                      out: edges,dark,bright
     OP_G2_PIPELINE,        // in: 7 basis, theta, c1,c2,c3     out: g,h,e,mag,phase,edges,dark,bright
-    OP_WRAP                // in: angle                        out: wrapped angle
+    OP_WRAP,               // in: angle                        out: wrapped angle
+    OP_G4_ORIENT           // in: 11 basis                     out: c1,c2,c3,theta,strength (extension)
 };
 
 constexpr int kMaxIn = 15;

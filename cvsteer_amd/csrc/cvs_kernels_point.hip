@@ -16,6 +16,7 @@
 //   OP_PHASE_WEIGHTS    SteerableFiltersG2.cpp:179-186
 //   OP_FIND             SteerableFiltersG2.cpp:194-212 (three maps in one pass)
 //   OP_WRAP             SteerableFilters.cpp:46-51
+//   OP_G4_ORIENT        (extension, not in the reference) C1..C3 / theta / strength for G4+H4
 //   OP_G2_PIPELINE      test/test.cpp:86-90 / example/steer.cpp:87-90 in one pass
 #include <hip/hip_runtime.h>
 
@@ -28,8 +29,9 @@ template <PointOp OP> struct OpShape;
 template <> struct OpShape<OP_G2_ORIENT> { static constexpr int NIN = 7, NOUT = 5; };
 template <> struct OpShape<OP_G2_STEER_SCALAR> { static constexpr int NIN = 10, NOUT = 5; };  // 7 basis, c1..c3
 template <> struct OpShape<OP_G2_STEER_MAP> { static constexpr int NIN = 11, NOUT = 5; };     // 7 basis, c1..c3, theta
-template <> struct OpShape<OP_G4_STEER_SCALAR> { static constexpr int NIN = 11, NOUT = 2; };
-template <> struct OpShape<OP_G4_STEER_MAP> { static constexpr int NIN = 12, NOUT = 2; };     // 11 basis, theta
+template <> struct OpShape<OP_G4_STEER_SCALAR> { static constexpr int NIN = 14, NOUT = 5; };  // 11 basis, [c1..c3: extension]
+template <> struct OpShape<OP_G4_STEER_MAP> { static constexpr int NIN = 15, NOUT = 5; };     // 11 basis, [c1..c3], theta at 14
+template <> struct OpShape<OP_G4_ORIENT> { static constexpr int NIN = 11, NOUT = 5; };        // extension
 template <> struct OpShape<OP_MAG_PHASE> { static constexpr int NIN = 2, NOUT = 2; };
 template <> struct OpShape<OP_PHASE_WEIGHTS> { static constexpr int NIN = 1, NOUT = 1; };
 template <> struct OpShape<OP_FIND> { static constexpr int NIN = 2, NOUT = 3; };
@@ -57,8 +59,20 @@ __device__ __forceinline__ void point_eval(const float* in, float* out, const Po
         if (need_mp) mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
     } else if constexpr (OP == OP_G4_STEER_SCALAR) {
         g4_steer_weights(in, a.w, out[0], out[1]);
+        // e / magnitude / phase for G4 are an opt-in extension (the reference has none, G4.cpp:88-90)
+        if (need_e) out[2] = __fadd_rn(__fadd_rn(in[11], __fmul_rn(a.c2t, in[12])), __fmul_rn(a.s2t, in[13]));
+        if (need_mp) mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
     } else if constexpr (OP == OP_G4_STEER_MAP) {
-        g4_steer_angle(in, in[11], out[0], out[1]);
+        const float th = in[14];
+        g4_steer_angle(in, th, out[0], out[1]);
+        if (need_e) {
+            float s2, c2;
+            sincos_any(__fmul_rn(th, 2.0f), s2, c2);
+            out[2] = __fadd_rn(__fadd_rn(in[11], __fmul_rn(in[12], c2)), __fmul_rn(in[13], s2));
+        }
+        if (need_mp) mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
+    } else if constexpr (OP == OP_G4_ORIENT) {
+        g4_orientation(in, a.atan_mode, out[0], out[1], out[2], out[3], out[4]);
     } else if constexpr (OP == OP_MAG_PHASE) {
         mag_phase(in[0], in[1], a.atan_mode, out[0], out[1]);
     } else if constexpr (OP == OP_PHASE_WEIGHTS) {
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(256) void k_point(const PointArgs a)
     const int ncv = a.cols / VEC;
     // wave-uniform "is this optional stage requested" flags
     bool need_e = false, need_mp = false;
-    if constexpr (OP == OP_G2_STEER_SCALAR || OP == OP_G2_STEER_MAP) {
+    if constexpr (OP == OP_G2_STEER_SCALAR || OP == OP_G2_STEER_MAP || OP == OP_G4_STEER_SCALAR || OP == OP_G4_STEER_MAP) {
         need_e = a.out[2].p != nullptr;
         need_mp = a.out[3].p != nullptr || a.out[4].p != nullptr;
     }
@@ -189,6 +203,7 @@ hipError_t launch_point(PointOp op, const PointArgs& a, hipStream_t s)
         case OP_FIND: return launch_op<OP_FIND>(a, s);
         case OP_G2_PIPELINE: return launch_op<OP_G2_PIPELINE>(a, s);
         case OP_WRAP: return launch_op<OP_WRAP>(a, s);
+        case OP_G4_ORIENT: return launch_op<OP_G4_ORIENT>(a, s);
     }
     return hipErrorInvalidValue;
 }

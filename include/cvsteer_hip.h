@@ -69,6 +69,9 @@ enum {
                                 (test/test.cpp:88-90), 1 = find*(e, phase) */
     CVS_OPT_PERSIST_STATE = 9, /* cvs_pipeline / cvs_pipeline_batch: 1 (default) = keep basis + orientation planes like the
                                   reference object does; 0 = write the requested outputs only (no state afterwards) */
+    CVS_OPT_G4_EXTENSIONS = 6, /* 0 (default) = G4 exactly as the reference leaves it (no orientation, no e/mag/phase);
+                                  1 = EXTENSION beyond the reference: cvs_setup(G4, CVS_SETUP_FULL) fills C1..C3 / theta /
+                                  strength from the G4/H4 steering polynomials, and cvs_steer_* accept e/mag/phase */
     CVS_OPT_XCD_MAP = 8,     /* basis kernel: 1 = pin row bands to XCDs through the block-id map (tuning) */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
                                 launch (blockIdx.z picks the half) */

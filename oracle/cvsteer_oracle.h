@@ -104,6 +104,10 @@ void ora_find(const float* e, const float* phase, size_t n, float* edges, float*
 void ora_g4_steer_scalar(const float* basis, size_t n, float theta, float* g4, float* h4);
 void ora_g4_steer_map(const float* basis, size_t n, const float* theta, float* g4, float* h4);
 
+/* EXTENSION (not in the reference): G4/H4 oriented-energy coefficients, dominant angle, strength */
+void ora_g4_orientation(const float* basis, size_t n, float* c1, float* c2, float* c3,
+                        float* theta, float* strength, int mode);
+
 /* cv::pyrDown restated (config 3 pyramid; not in the reference, unpinned). dst is ((rows+1)/2) x ((cols+1)/2) dense */
 void ora_pyr_down(const float* src, int rows, int cols, size_t src_step_elems, float* dst);
 

@@ -420,6 +420,88 @@ void ora_g4_steer_map(const float* b, size_t n, const float* theta, float* g4, f
     }
 }
 
+/* EXTENSION beyond the reference (it computes no G4 orientation, G4.h:55): C1..C3 of
+ * E(theta) = g4(theta)^2 + h4(theta)^2 from the steering polynomials of G4.cpp:116-119, derived like
+ * G2.cpp:93-95 (tools/gen_g4_orient.py prints this table and, for G2, the reference's own constants).
+ * Unpinned by any reference data; checked against brute-force projection of E(theta) in the tests. */
+typedef struct { int i, j, which; float k; } ora_g4_term;
+static const ora_g4_term ORA_G4_TERMS[] = {
+    {0, 0, 1, 35.f / 128},
+    {0, 0, 2, 7.f / 16},
+    {0, 1, 3, -7.f / 8},
+    {0, 2, 1, 15.f / 32},
+    {0, 2, 2, 3.f / 8},
+    {0, 3, 3, -3.f / 8},
+    {0, 4, 1, 3.f / 64},
+    {1, 1, 1, 5.f / 8},
+    {1, 1, 2, 1.f / 2},
+    {1, 2, 3, -9.f / 4},
+    {1, 3, 1, 3.f / 4},
+    {1, 4, 3, -3.f / 8},
+    {2, 2, 1, 27.f / 32},
+    {2, 3, 3, -9.f / 4},
+    {2, 4, 1, 15.f / 32},
+    {2, 4, 2, -3.f / 8},
+    {3, 3, 1, 5.f / 8},
+    {3, 3, 2, -1.f / 2},
+    {3, 4, 3, -7.f / 8},
+    {4, 4, 1, 35.f / 128},
+    {4, 4, 2, -7.f / 16},
+    {5, 5, 1, 63.f / 256},
+    {5, 5, 2, 105.f / 256},
+    {5, 6, 3, -105.f / 128},
+    {5, 7, 1, 35.f / 64},
+    {5, 7, 2, 35.f / 64},
+    {5, 8, 3, -35.f / 64},
+    {5, 9, 1, 15.f / 128},
+    {5, 9, 2, 5.f / 128},
+    {5, 10, 3, -5.f / 128},
+    {6, 6, 1, 175.f / 256},
+    {6, 6, 2, 175.f / 256},
+    {6, 7, 3, -175.f / 64},
+    {6, 8, 1, 75.f / 64},
+    {6, 8, 2, 25.f / 64},
+    {6, 9, 3, -125.f / 128},
+    {6, 10, 1, 15.f / 128},
+    {6, 10, 2, -5.f / 128},
+    {7, 7, 1, 75.f / 64},
+    {7, 7, 2, 25.f / 64},
+    {7, 8, 3, -125.f / 32},
+    {7, 9, 1, 75.f / 64},
+    {7, 9, 2, -25.f / 64},
+    {7, 10, 3, -35.f / 64},
+    {8, 8, 1, 75.f / 64},
+    {8, 8, 2, -25.f / 64},
+    {8, 9, 3, -175.f / 64},
+    {8, 10, 1, 35.f / 64},
+    {8, 10, 2, -35.f / 64},
+    {9, 9, 1, 175.f / 256},
+    {9, 9, 2, -175.f / 256},
+    {9, 10, 3, -105.f / 128},
+    {10, 10, 1, 63.f / 256},
+    {10, 10, 2, -105.f / 256},
+};
+
+void ora_g4_orientation(const float* basis, size_t n, float* c1, float* c2, float* c3,
+                        float* theta, float* strength, int mode)
+{
+    const int nt = (int)(sizeof(ORA_G4_TERMS) / sizeof(ORA_G4_TERMS[0]));
+    for (size_t p = 0; p < n; p++) {
+        float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        for (int t = 0; t < nt; t++) {
+            float term = ORA_G4_TERMS[t].k * (basis[(size_t)ORA_G4_TERMS[t].i * n + p] * basis[(size_t)ORA_G4_TERMS[t].j * n + p]);
+            if (ORA_G4_TERMS[t].which == 1) v1 = v1 + term;
+            else if (ORA_G4_TERMS[t].which == 2) v2 = v2 + term;
+            else v3 = v3 + term;
+        }
+        if (c1) c1[p] = v1;
+        if (c2) c2[p] = v2;
+        if (c3) c3[p] = v3;
+        if (strength) strength[p] = sqrtf(v2 * v2 + v3 * v3);
+        if (theta) theta[p] = wrap1(angle_0_2pi(v3, v2, mode)) * 0.5f;
+    }
+}
+
 /* cv::pyrDown(src, dst) with default size ((cols+1)/2, (rows+1)/2) and BORDER_REFLECT_101
  * (BORDER_DEFAULT): 5x5 Gaussian [1 4 6 4 1]/16 (x) [1 4 6 4 1]/16, then every second pixel.
  * NOT part of the reference (it has no pyramid code): restated from the

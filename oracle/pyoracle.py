@@ -197,6 +197,14 @@ def g4_steer_map(b, theta):
     return g, h
 
 
+def g4_orientation(b, mode=ATAN_CV):
+    """EXTENSION (not in the reference).  b: (11,H,W) -> c1,c2,c3,theta,strength"""
+    b = _f32(b)
+    outs = [np.empty(b.shape[1:], np.float32) for _ in range(5)]
+    lib().ora_g4_orientation(_fp(b), C.c_size_t(b[0].size), *[_fp(o) for o in outs], mode)
+    return tuple(outs)
+
+
 def pyr_down(src):
     src = _f32(src)
     rows, cols = src.shape

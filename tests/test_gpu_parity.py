@@ -621,3 +621,34 @@ def test_random_shapes_fuzz(cv, ora):
         g4, h4 = cv.SteerableFiltersG4(None).setup_steer(img, -0.7)
         og, oh = ora.g4_steer_scalar(got4, -0.7)
         assert np.abs(g4 - og).max() <= 1e-6 and np.abs(h4 - oh).max() <= 1e-6, (rows, cols)
+
+
+def test_g4_extension_orientation_and_full_steer(cv, ora):
+    """opt-in extension beyond the reference: G4 C1..C3 / theta / strength, steer(full), mag/phase"""
+    img = smooth_image(70, 110) + 0.05 * rand_image(70, 110, seed=77)
+    f = cv.SteerableFiltersG4(img, extensions=True)
+    b = np.stack([f.basis(p) for p in range(11)])
+    o1, o2, o3, oth, ost = ora.g4_orientation(b)
+    c1, c2, c3 = f.coefficients()
+    scale = max(1.0, np.abs(o1).max())
+    for got, want in ((c1, o1), (c2, o2), (c3, o3), (f.getDominantOrientationStrength(), ost)):
+        assert np.abs(got - want).max() <= 1e-6 * scale
+    ok = ost > 1e-3 * scale
+    assert angle_diff(f.getDominantOrientationAngle(), oth, np.pi)[ok].max() <= TOL
+    g, h, e, m, p = f.steer(0.3, full=True)
+    og, oh = ora.g4_steer_scalar(b, 0.3)
+    assert np.abs(g - og).max() <= 1e-6 and np.abs(h - oh).max() <= 1e-6
+    want_e = o1 + np.float32(np.cos(0.6)) * o2 + np.float32(np.sin(0.6)) * o3
+    assert np.abs(e - want_e).max() <= 1e-5 * scale
+    om, op = ora.mag_phase(og, oh)
+    assert np.abs(m - om).max() <= 1e-5 and angle_diff(p, op, 2 * np.pi)[om > 1e-3].max() <= 2e-5
+    g2, h2, e2, m2, p2 = f.steer(None, full=True)          # at the G4 dominant orientation
+    g3, h3 = f.steer(f.getDominantOrientationAngle())
+    assert np.array_equal(g2, g3) and np.array_equal(h2, h3)
+    mm, pp = f.computeMagnitudeAndPhase(g2, h2)
+    assert np.array_equal(mm, m2) and np.array_equal(pp, p2)
+    # default objects stay exactly like the reference
+    ref = cv.SteerableFiltersG4(img)
+    assert ref.getDominantOrientationAngle().size == 0
+    with pytest.raises(cv.CvsError):
+        ref.steer(0.3, full=True)

@@ -186,3 +186,33 @@ def test_pyr_down_matches_scipy_mirror(ora, shape):
     got = ora.pyr_down(img)
     assert got.shape == ((shape[0] + 1) // 2, (shape[1] + 1) // 2)
     assert np.abs(got - a[::2, ::2]).max() <= 5e-7
+
+
+def test_g4_orientation_extension_is_the_fourier_projection(ora):
+    """EXTENSION (not in the reference): C1 + C2 cos2t + C3 sin2t must be the {1, cos2t, sin2t} projection of
+    the brute-force oriented energy g4(t)^2 + h4(t)^2 -- the same identity the reference's G2 constants obey"""
+    img = rand_image(36, 44, seed=23)
+    b = ora.basis(4, img, 6, 0.5)
+    c1, c2, c3, theta, strength = ora.g4_orientation(b)
+    ths = np.linspace(0, 2 * np.pi, 64, endpoint=False)
+    E = []
+    for t in ths:
+        g, h = ora.g4_steer_scalar(b, float(t))
+        E.append(g.astype(np.float64) ** 2 + h.astype(np.float64) ** 2)
+    E = np.stack(E)
+    scale = max(1.0, np.abs(E).max())
+    assert np.abs(E.mean(0) - c1).max() <= 2e-5 * scale
+    assert np.abs(2 * (E * np.cos(2 * ths)[:, None, None]).mean(0) - c2).max() <= 2e-5 * scale
+    assert np.abs(2 * (E * np.sin(2 * ths)[:, None, None]).mean(0) - c3).max() <= 2e-5 * scale
+    assert np.allclose(strength, np.hypot(c2, c3), rtol=1e-6)
+    # and the same procedure reproduces the reference's G2 constants
+    b2 = ora.basis(2, img, 4, 0.67)
+    k1, k2, k3 = ora.g2_orientation(b2)[:3]
+    E2 = []
+    for t in ths:
+        g, h = ora.g2_steer_scalar(b2, float(t))
+        E2.append(g.astype(np.float64) ** 2 + h.astype(np.float64) ** 2)
+    E2 = np.stack(E2)
+    s2 = max(1.0, np.abs(E2).max())
+    assert np.abs(2 * (E2 * np.cos(2 * ths)[:, None, None]).mean(0) - k2).max() <= 2e-5 * s2
+    assert np.abs(2 * (E2 * np.sin(2 * ths)[:, None, None]).mean(0) - k3).max() <= 2e-5 * s2
