@@ -3,10 +3,10 @@
 //
 // Replaces the 7 (11) cv::sepFilter2D calls of SteerableFiltersG2::setup (reference
 // cvsteer/SteerableFiltersG2.cpp:62-68) / SteerableFiltersG4::setup (SteerableFiltersG4.cpp:69-80)
-// and, in the fused epilogues, G2.cpp:70-99 (C1..C3, theta, strength) and G2.cpp:137-145 /
-// G4.cpp:114-122 (scalar steer).
+// and, in the fused epilogues, G2.cpp:70-99 (C1..C3, theta, strength), G2.cpp:137-145 /
+// G4.cpp:114-122 (scalar steer) and the callers' whole sequence test/test.cpp:86-90 (F_PIPE).
 //
-// Design (HBM-bound: 4 B read + 28/44 B written per pixel, ~95/230 VALU ops per pixel):
+// Design (HBM-bound: 4 B read + 28/44 B written per pixel, ~102/290 VALU instructions per row):
 //  * one WAVE owns a strip 64 columns wide and `strip_rows` tall and marches down it; the four
 //    waves of a workgroup own four adjacent strips and never synchronise with each other.
 //  * per input row the wave issues one coalesced 256-B row load (+ one 2W-lane halo load),
@@ -16,8 +16,15 @@
 //  * the 6 (10) distinct row-filtered values enter a (2W+1)-deep sliding window held in
 //    VGPRs (the row loop is unrolled 2W+1 times so every window slot is a fixed register);
 //    the column pass runs on that window, also in folded symmetric / antisymmetric form.
-//  * the input is read once and every output plane is written once with 256-B row segments.
-//  * loads for the next 2W+1 rows are in flight while the current ones are filtered.
+//  * the input is read once and every output plane is written once with 256-B row segments,
+//    nontemporal once the planes outgrow the Infinity Cache.
+//  * loads for the next 2W+1 rows are in flight while the current ones are filtered (the register
+//    just consumed is refilled at once; the prefetch is branch-free).
+//  * every memory access is a buffer instruction: plane = resource (SGPRs), row = scalar offset,
+//    column = one per-lane byte offset shared by all loads and stores; masked lanes use an
+//    out-of-range offset that the hardware range check drops.
+//  * variants (templates): epilogue flags, streaming stores, batched launch (grid.z = frame),
+//    single state resource; G4 runs as two half banks side by side in one launch (k_basis_pair).
 #include <hip/hip_runtime.h>
 
 #include "cvs_device_math.h"
