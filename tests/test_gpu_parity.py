@@ -652,3 +652,53 @@ def test_g4_extension_orientation_and_full_steer(cv, ora):
     assert ref.getDominantOrientationAngle().size == 0
     with pytest.raises(cv.CvsError):
         ref.steer(0.3, full=True)
+
+
+def test_find_on_energy_option(cv):
+    """CVS_OPT_FIND_ON = 1: the fused pipeline weights the oriented energy e instead of the magnitude
+    (the API's findEdges(e, phase) semantics; the reference's callers happen to pass the magnitude)"""
+    from cvsteer_amd import _lib as L
+    img = smooth_image(80, 120) + 0.1 * rand_image(80, 120, seed=15)
+    f = cv.SteerableFiltersG2(None)
+    f.set_option(L.OPT_FIND_ON, 1)
+    outs = f.pipeline(img)
+    ed, dk, br = f.find(outs[2], outs[4])
+    assert np.array_equal(outs[5], ed) and np.array_equal(outs[6], dk) and np.array_equal(outs[7], br)
+    f.set_option(L.OPT_FIND_ON, 0)
+    outs0 = f.pipeline(img)
+    ed0, _, _ = f.find(outs0[3], outs0[4])
+    assert np.array_equal(outs0[5], ed0) and not np.array_equal(outs0[5], outs[5])
+
+
+def test_large_ragged_image_bands(cv, ora):
+    """a big image whose width is no multiple of 64 and whose height is no multiple of the strip: bands vs oracle"""
+    import torch
+    rows, cols = 3001, 5003
+    x = torch.rand((rows, cols), generator=torch.Generator(device="cuda").manual_seed(7), device="cuda")
+    xh = x.cpu().numpy()
+    for cls, kind, w, s, n, halo in ((cv.SteerableFiltersG2, 2, 4, 0.67, 7, 4), (cv.SteerableFiltersG4, 4, 6, 0.5, 11, 6)):
+        f = cls(x, w, s)
+        for lo, hi in ((0, 40), (1490, 1535), (rows - 41, rows)):
+            band = ora.basis(kind, xh[lo:hi], w, s, f64=True)
+            a = 0 if lo == 0 else halo
+            b = band.shape[1] if hi == rows else band.shape[1] - halo
+            for p in (0, n // 2, n - 1):
+                got = f.basis(p)[lo + a:lo + b].cpu().numpy()
+                assert np.abs(got - band[p][a:b]).max() <= TOL, (kind, lo, p)
+                assert np.abs(got[:, -70:] - band[p][a:b, -70:]).max() <= TOL   # right border columns
+
+
+def test_g4_8192_band(cv, ora):
+    """G4+H4 at 8192x8192 (state block 16 x 256 MiB = 4 GiB: one buffer resource per plane instead of one per block)"""
+    import torch
+    n = 8192
+    x = torch.rand((n, n), generator=torch.Generator(device="cuda").manual_seed(11), device="cuda")
+    f = cv.SteerableFiltersG4(x)
+    lo, hi = 4000, 4040
+    band = ora.basis(4, x[lo:hi].cpu().numpy(), 6, 0.5, f64=True)
+    for p in (0, 5, 10):
+        assert np.abs(f.basis(p)[lo + 6:hi - 6].cpu().numpy() - band[p][6:-6]).max() <= TOL
+    g, h = f.steer(0.3)
+    w = cv.steer_weights(4, 0.3)
+    acc = sum(float(w[p]) * f.basis(p)[lo:hi] for p in range(5))
+    assert float((g[lo:hi] - acc).abs().max()) <= 2e-6
