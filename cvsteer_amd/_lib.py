@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libcvsteer_hip.so")
+_SO = os.environ.get("CVSTEER_HIP_LIB", os.path.join(_HERE, "libcvsteer_hip.so"))  # override: diagnostic twin only
 
 OK, E_BADARG, E_SIZE, E_HIP, E_NOMEM, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 KIND_G2, KIND_G4 = 2, 4

@@ -43,6 +43,7 @@ struct cvs_context {
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
     float* point_out = nullptr;
+    unsigned long long* diag = nullptr;  // diagnostic builds only
     int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, xcd_map = 0, persist = 1, g4_ext = 0;
     std::string err;
 };
@@ -330,6 +331,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     a.g4_split = h->g4_split;
     a.xcd_map = h->xcd_map;
+    a.diag = h->diag;
     if (steer) {
         PlaneRef rg, rh;
         if ((rc = out_ref(c, g, rg)) || (rc = out_ref(c, hq, rh))) return rc;
@@ -855,6 +857,17 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     h->have_basis = h->have_orient = h->persist != 0;
     return CVS_OK;
 }
+
+#ifdef CVS_DIAG_STAMPS
+// diagnostic builds only: per-wave time stamps of the next basis launches go to `buf` (device memory,
+// 4 x 8 bytes per wave); not declared in the public header
+int cvs_diag_set_buffer(cvs_handle h, void* buf)
+{
+    if (!h) return CVS_E_BADARG;
+    h->diag = static_cast<unsigned long long*>(buf);
+    return CVS_OK;
+}
+#endif
 
 int cvs_select_frame(cvs_handle h, int frame)
 {

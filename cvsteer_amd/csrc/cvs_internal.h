@@ -53,6 +53,9 @@ struct BasisArgs {
     const BatchFrame* frames;  // device pointer, or nullptr = single image
     int batch;
     size_t frame_stride;       // elements between the state blocks of consecutive frames
+    // diagnostic builds only (-DCVS_DIAG_STAMPS, tools/k1_timeline.py): per-wave {start, first store, end}
+    // 100 MHz real-time stamps; never read by the product, nullptr in normal builds
+    unsigned long long* diag;
 };
 
 // taps[i] = the handle's i-th tap vector (member order), 2*width+1 floats each

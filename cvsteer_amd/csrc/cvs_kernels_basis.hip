@@ -175,6 +175,11 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     }
     const int x0 = (bx * 4 + wv) * 64;
     if (x0 >= a.cols) return;  // wave-uniform; waves of a workgroup never rendezvous
+#ifdef CVS_DIAG_STAMPS
+    unsigned long long* stamp = a.diag ? a.diag + ((size_t)(by * a.grid_x + bx) * 4 + wv) * 4 : nullptr;
+    bool stamped_first = false;
+    if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int y0 = by * a.strip_rows;
     const int yend = min(y0 + a.strip_rows, a.rows);
     const int x = x0 + lane;
@@ -291,6 +296,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             const bool row_ok = yout >= y0 && yout < yend;  // wave-uniform
             const unsigned xbr = xb;
             if (row_ok) {
+#ifdef CVS_DIAG_STAMPS
+                if (stamp && !stamped_first) { stamped_first = true; if (lane == 0) stamp[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
                 float b[NB];
 #pragma unroll
                 for (int p = 0; p < NB; ++p) {
@@ -382,6 +390,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             }
         }
     }
+#ifdef CVS_DIAG_STAMPS
+    if (stamp && lane == 0) { __builtin_amdgcn_s_waitcnt(0); stamp[2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool ONE = false>
