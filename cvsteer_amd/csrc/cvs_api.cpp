@@ -258,7 +258,9 @@ int default_strip_rows(cvs_handle h, int rows, int cols)
     const long strips_x = (cols + 63) / 64;
     const double ideal = (double)rows * (double)strips_x / 2048.0;
     long k = std::lround((ideal + halo) / nt);
-    const long kmax = 3;
+    // launches of >= 32 Mpix are long enough that the shorter strips' faster drain wins (tools/tune.py 8192:
+    // 80.5 vs 77.8 % at 8192x8192, 81.6 vs 77.7 % at 4096x8192)
+    const long kmax = (h->kind == CVS_KIND_G2 && (size_t)rows * cols >= ((size_t)32 << 20)) ? 2 : 3;
     if (k < 2) k = 2;
     if (k > kmax) k = kmax;
     return (int)(k * nt - halo);
