@@ -10,8 +10,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <new>
 #include <string>
 #include <vector>
@@ -44,7 +48,8 @@ struct cvs_context {
     float* minmax = nullptr;
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, xcd_map = 0, persist = 1, g4_ext = 0;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     std::string err;
 };
 
@@ -278,6 +283,84 @@ int use_nt_stores(cvs_handle h, size_t npix)
     return state_bytes > (size_t)96 << 20;
 }
 
+// process-wide autotune memory: (device, kernel variant, rows, cols, strip rows) -> {times seen, chosen order}.
+// Shared by all handles, because the reference's usage pattern is one short-lived object per image.
+struct TuneEntry {
+    int seen = 0;
+    int order = -1;  // -1 = not tuned yet
+};
+std::mutex g_tune_mutex;
+std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
+
+// Block order autotune.  The basis kernel can walk its strips row-major, in groups of T bands, or
+// column-major; which one the memory system likes depends on how many planes the variant writes and --
+// measurably -- on the box (tools/ab.py: e.g. the 20-plane pipeline 65 -> 80 % column-major on one box,
+// the 12-plane setup 68 -> 82 % with T = 32 on another, the 7-plane pass always best row-major).  All
+// orders produce identical results, so the first launch of a (variant, shape) times the candidates on the
+// caller's stream and keeps the winner; CVS_OPT_BLOCK_ORDER >= 0 pins an order instead.
+int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant)
+{
+    if (h->block_order >= 0) {
+        a.block_order = h->block_order;
+        return CVS_OK;
+    }
+    a.block_order = 0;
+    if (h->kind != CVS_KIND_G2 || !basis_fast_path(h->kind, h->width, h->taps) || (size_t)a.rows * a.cols < ((size_t)1 << 20))
+        return CVS_OK;  // small images and the generic / G4 paths keep the plain grid
+    const auto key = std::make_tuple(h->device, variant, a.rows, a.cols, a.strip_rows);
+    {
+        std::lock_guard<std::mutex> lock(g_tune_mutex);
+        TuneEntry& e = g_tune[key];
+        if (e.order >= 0) {
+            a.block_order = e.order;
+            return CVS_OK;
+        }
+        // a shape seen for the first time runs on the plain grid: one-off images never pay for tuning
+        if (++e.seen < 2) return CVS_OK;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return CVS_OK;
+    if (!h->ev0) {
+        HIP_TRY(h, hipEventCreate(&h->ev0));
+        HIP_TRY(h, hipEventCreate(&h->ev1));
+    }
+    const int bands = (a.rows + a.strip_rows - 1) / a.strip_rows;
+    const int cand[3] = {0, 32, bands};
+    float tmin[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    // one untimed launch first (first touch of fresh allocations, clock ramp), then the candidates
+    // interleaved over several rounds so that drift hits them equally; keep each candidate's fastest run
+    a.block_order = 0;
+    HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
+    for (int round = 0; round < 4; ++round) {
+        for (int ci = 0; ci < 3; ++ci) {
+            a.block_order = cand[ci];
+            HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+            HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
+            HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+            HIP_TRY(h, hipEventSynchronize(h->ev1));
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            if (round > 0 && ms < tmin[ci]) tmin[ci] = ms;  // round 0 warms each candidate's own pattern
+        }
+    }
+    int best_order = 0;
+    float best = tmin[0];
+    for (int ci = 1; ci < 3; ++ci)
+        if (tmin[ci] < best * 0.98f) {  // a challenger must win by 2 % to displace the plain grid / an earlier winner
+            best = tmin[ci];
+            best_order = cand[ci];
+        }
+    if (std::getenv("CVS_TUNE_VERBOSE"))
+        std::fprintf(stderr, "[cvsteer] block order tune variant %d %dx%d: row-major %.4f ms, T=32 %.4f ms, column-major %.4f ms -> %d\n",
+                     variant, a.rows, a.cols, tmin[0], tmin[1], tmin[2], best_order);
+    {
+        std::lock_guard<std::mutex> lock(g_tune_mutex);
+        g_tune[key].order = best_order;
+    }
+    a.block_order = best_order;
+    return CVS_OK;
+}
+
 int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, float theta, const cvs_plane* g,
              const cvs_plane* hq, const cvs_plane* const* pipe_outs = nullptr, int nframes = 1, int frame = 0)
 {
@@ -332,7 +415,6 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.strip_rows = default_strip_rows(h, a.rows, a.cols);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     a.g4_split = h->g4_split;
-    a.xcd_map = h->xcd_map;
     a.diag = h->diag;
     if (steer) {
         PlaneRef rg, rh;
@@ -351,6 +433,11 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
             if ((rc = out_ref(c, po[k], a.pipe_out[k]))) return rc;
     }
     float* scr = scratch ? arena_take(h, scratch) : nullptr;
+    {
+        const bool orient_k = a.orient != nullptr;
+        const int variant = (orient_k ? 1 : 0) | (steer ? 2 : 0) | (a.pipe ? 4 : 0) | (a.no_state ? 8 : 0);
+        if ((rc = tune_block_order(h, a, scr, variant))) return rc;
+    }
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
     if ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G4) {  // extension: one per-pixel pass over the 11 planes
         PointArgs pa{};
@@ -500,6 +587,8 @@ int cvs_destroy(cvs_handle h)
     if (h->minmax) (void)hipFree(h->minmax);
     if (h->frame_tab) (void)hipFree(h->frame_tab);
     if (h->point_out) (void)hipFree(h->point_out);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
     return CVS_OK;
 }
@@ -545,9 +634,9 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "persist");
             h->persist = value;
             return CVS_OK;
-        case CVS_OPT_XCD_MAP:
-            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "xcd map");
-            h->xcd_map = value;
+        case CVS_OPT_BLOCK_ORDER:
+            if (value < -1 || value == 1 || value > 1000000) return fail(h, CVS_E_BADARG, "block order");
+            h->block_order = value;
             return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
@@ -562,7 +651,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_FIND_ON: *value = h->find_on; return CVS_OK;
         case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
-        case CVS_OPT_XCD_MAP: *value = h->xcd_map; return CVS_OK;
+        case CVS_OPT_BLOCK_ORDER: *value = h->block_order; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;
     }
@@ -852,9 +941,9 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.find_on_e = h->find_on;
     a.frames = h->frame_tab;
     a.g4_split = h->g4_split;
-    a.xcd_map = h->xcd_map;
     a.batch = n;
     a.frame_stride = h->frame_stride;
+    if ((rc = tune_block_order(h, a, nullptr, 16 | 1 | 4 | (a.no_state ? 8 : 0)))) return rc;
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream));
     h->have_basis = h->have_orient = h->persist != 0;
     return CVS_OK;

@@ -41,7 +41,7 @@ struct BasisArgs {
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
-    int xcd_map;          // 1 = 1-D grid, row bands pinned to XCDs (see k_basis)
+    int block_order;      // 0 = row-major grid, T >= 2 = groups of T bands walked column by column (see k_basis)
     int grid_x, grid_y;   // filled by the launcher
     // fused caller pipeline (needs orient): g2,h2,e,mag,phase,edges,dark,bright at theta_dom
     int pipe;             // 1 = run the pipeline epilogue

@@ -161,17 +161,19 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    // workgroup -> (column block bx, row band by).  With xcd_map the grid is 1-D and consecutive ids,
-    // which the dispatcher deals round-robin over the 8 XCDs, are spread so that every row band is
-    // filtered by ONE XCD walking along x: the DRAM pages / TLB entries of a band's output rows are
-    // then touched from a single XCD (placement is an observed behaviour -- speed only, never
-    // correctness).
+    // workgroup -> (column block bx, row band by).  block_order = 0: plain row-major grid.  block_order =
+    // T >= 2: 1-D grid, groups of T bands walked column by column, so T vertically adjacent bands are in
+    // flight together (T >= grid_y: column-major).  Which order the memory system prefers depends on the
+    // kernel variant (how many planes it writes) and on the box; the API layer picks it by timing the
+    // candidates once per (variant, shape) -- see autotune in cvs_api.cpp.
     int bx = blockIdx.x, by = blockIdx.y;
-    if (a.xcd_map) {
-        const int id = blockIdx.x, t = id >> 3;
-        bx = t % a.grid_x;
-        by = (t / a.grid_x) * 8 + (id & 7);
-        if (by >= a.grid_y) return;
+    if (a.block_order >= 2) {
+        const int T = min(a.block_order, a.grid_y);
+        const int per = T * a.grid_x, g = blockIdx.x / per, r = blockIdx.x % per;
+        const int tg = min(T, a.grid_y - g * T);  // bands in this (possibly last, shorter) group
+        by = g * T + r % tg;
+        bx = r / tg;
+        if (bx >= a.grid_x) return;
     }
     const int x0 = (bx * 4 + wv) * 64;
     if (x0 >= a.cols) return;  // wave-uniform; waves of a workgroup never rendezvous
@@ -502,7 +504,10 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     dim3 grid((strips_x + 3) / 4, (a.rows + a.strip_rows - 1) / a.strip_rows);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
-    if (a.xcd_map) grid = dim3(a.grid_x * ((a.grid_y + 7) / 8) * 8, 1);
+    if (a.block_order >= 2) {
+        const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
+        grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1);
+    }
     dim3 block(256);
     const bool orient = a.orient != nullptr && B::KIND == 2;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
@@ -559,7 +564,7 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
     dim3 grid((strips_x + 3) / 4, (a.rows + a.strip_rows - 1) / a.strip_rows, 2), block(256);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
-    a.xcd_map = 0;
+    a.block_order = 0;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     constexpr int NBTOT = BG::KIND == 2 ? 7 : 11;
     const bool one = (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;

@@ -72,7 +72,10 @@ enum {
     CVS_OPT_G4_EXTENSIONS = 6, /* 0 (default) = G4 exactly as the reference leaves it (no orientation, no e/mag/phase);
                                   1 = EXTENSION beyond the reference: cvs_setup(G4, CVS_SETUP_FULL) fills C1..C3 / theta /
                                   strength from the G4/H4 steering polynomials, and cvs_steer_* accept e/mag/phase */
-    CVS_OPT_XCD_MAP = 8,     /* basis kernel: 1 = pin row bands to XCDs through the block-id map (tuning) */
+    CVS_OPT_BLOCK_ORDER = 8, /* order in which the basis kernel walks its strips: -1 (default) = timed once per (kernel
+                                variant, image shape) on first use and cached; 0 = row-major; T >= 2 = groups of T row
+                                bands walked column by column (T >= number of bands: column-major).  Results do not
+                                depend on it. */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
                                 launch (blockIdx.z picks the half) */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the

@@ -702,3 +702,25 @@ def test_g4_8192_band(cv, ora):
     w = cv.steer_weights(4, 0.3)
     acc = sum(float(w[p]) * f.basis(p)[lo:hi] for p in range(5))
     assert float((g[lo:hi] - acc).abs().max()) <= 2e-6
+
+
+def test_block_order_never_changes_results(cv):
+    """CVS_OPT_BLOCK_ORDER (row-major / band groups / column-major / autotuned): identical outputs"""
+    import torch
+    from cvsteer_amd import _lib as L
+    img = torch.rand((1100, 1500), device="cuda")     # >= 1 Mpix: eligible for autotune
+    ref = None
+    for order in (0, 2, 7, 32, 100000, -1):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_BLOCK_ORDER, order)
+        outs = []
+        for _ in range(3):                              # the autotuner kicks in on the second call
+            outs = f.pipeline(img)
+        g, h = f.setup_steer(img, 0.3)
+        cur = [o.clone() for o in outs] + [g, h] + [f.basis(p) for p in range(7)]
+        if ref is None:
+            ref = cur
+        for a, b in zip(cur, ref):
+            assert torch.equal(a, b), order
+    with pytest.raises(cv.CvsError):
+        cv.SteerableFiltersG2(None).set_option(L.OPT_BLOCK_ORDER, 1)

@@ -14,7 +14,7 @@ def timeit(fn, steps=20):
     return a.elapsed_time(b) / steps
 
 def main():
-    opt = int(sys.argv[1]) if len(sys.argv) > 1 else L.OPT_XCD_MAP
+    opt = int(sys.argv[1]) if len(sys.argv) > 1 else L.OPT_BLOCK_ORDER
     values = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
     n = 4096
     img = torch.rand((n, n), device="cuda")
