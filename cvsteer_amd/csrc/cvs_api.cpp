@@ -48,6 +48,7 @@ struct cvs_context {
     float* minmax = nullptr;
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
+    const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
     int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     std::string err;
@@ -252,7 +253,7 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
     return CVS_OK;
 }
 
-int default_strip_rows(cvs_handle h, int rows, int cols)
+int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input = false)
 {
     if (h->strip_rows > 0) return h->strip_rows;
     // strips whose (rows + 2W) is a multiple of the 2W+1-row unroll waste no loop iterations.
@@ -265,7 +266,10 @@ int default_strip_rows(cvs_handle h, int rows, int cols)
     long k = std::lround((ideal + halo) / nt);
     // launches of >= 32 Mpix are long enough that the shorter strips' faster drain wins (tools/tune.py 8192:
     // 80.5 vs 77.8 % at 8192x8192, 81.6 vs 77.7 % at 4096x8192)
-    const long kmax = (h->kind == CVS_KIND_G2 && (size_t)rows * cols >= ((size_t)32 << 20)) ? 2 : 3;
+    // ... and so do inputs that are not cache-resident: when consecutive calls bring DIFFERENT images, the
+    // halo rows of vertically adjacent strips only hit in cache if those strips run close in time
+    // (tools/ab_rot.py, 8 rotating 4096x4096 inputs: 10-row strips 66 %, 19-row strips 57 %)
+    const long kmax = (h->kind == CVS_KIND_G2 && (fresh_input || (size_t)rows * cols >= ((size_t)32 << 20))) ? 2 : 3;
     if (k < 2) k = 2;
     if (k > kmax) k = kmax;
     return (int)(k * nt - halo);
@@ -412,7 +416,11 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.plane_stride = h->plane_stride;
     a.orient = ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G2) ? state_plane(h, h->nb) : nullptr;
     a.atan_mode = h->atan_mode;
-    a.strip_rows = default_strip_rows(h, a.rows, a.cols);
+    // a different input pointer than last time = a stream of fresh images (not resident in the Infinity Cache);
+    // the pipeline variants keep the taller strips (tools/shape_sweep.py)
+    const bool fresh = h->last_image != nullptr && h->last_image != (const void*)image->data && !pipe_outs;
+    h->last_image = image->data;
+    a.strip_rows = default_strip_rows(h, a.rows, a.cols, fresh);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     a.g4_split = h->g4_split;
     a.diag = h->diag;
