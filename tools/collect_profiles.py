@@ -71,8 +71,10 @@ for k in sorted(write):
                              "WRITE_SIZE_bytes": write[k], "hbm_bytes_per_launch": f2 + write[k]}
 json.dump(summary, open(os.path.join(P, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 
-key = "cvs::k_basis<cvs::BankG2, 2, true, false, false>"  # F_STEER, streaming stores: the headline kernel
-if key in summary["kernels"]:
+# the headline kernel: G2 bank, F_STEER (2), streaming stores, not batched
+keys = [k for k in summary["kernels"] if k.startswith("cvs::k_basis<cvs::BankG2, 2, true, false")]
+key = keys[0] if keys else None
+if key:
     t = summary["kernels"][key]
     json.dump({"k_basis_g2_steer_4096": {"hbm_bytes_per_launch": round(t["hbm_bytes_per_launch"]),
                                          "read_bytes": round(t["read_bytes_corrected_x2"]), "write_bytes": round(t["WRITE_SIZE_bytes"]),

@@ -4,7 +4,7 @@
 #   pass A  kernel-trace + stats of the HEADLINE loop only (bench.py --no-extra): the dominant
 #           kernel's average duration here is what bench.py's roofline.avg_launch_ms must agree with
 #   pass B  kernel-trace + stats with every secondary leg
-#   pass C  PMC FETCH_SIZE / WRITE_SIZE (own runs, counters only) + the same on tools/membench
+#   pass C  PMC FETCH_SIZE / WRITE_SIZE of the headline loop (own runs, counters only) + the same on tools/membench
 #           kernels of known traffic (calibration)
 #   pass D  SQ issue / occupancy counters (own run)
 set -u
@@ -17,7 +17,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stat
 echo "stats rc=$?" >> $O/prof_stats.log
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_all -- python3 bench.py --steps 50 --warmup 5 --no-cpu > $O/prof_stats_all.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/pmc_$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python3 bench.py --steps 5 --warmup 3 --no-cpu --no-extra > $O/pmc_$C.log 2>&1
   echo "pmc $C rc=$?" >> $O/pmc_$C.log
   timeout 200 rocprofv3 --pmc $C --output-format csv -d $O/pmc_cal_$C -- ./tools/membench > $O/pmc_cal_$C.log 2>&1
 done
