@@ -291,7 +291,8 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // Shared by all handles, because the reference's usage pattern is one short-lived object per image.
 struct TuneEntry {
     int seen = 0;
-    int order = -1;  // -1 = not tuned yet
+    int order = -1;      // -1 = not tuned yet
+    int strip_rows = 0;  // 0 = keep the default
 };
 std::mutex g_tune_mutex;
 std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
@@ -302,7 +303,7 @@ std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
 // the 12-plane setup 68 -> 82 % with T = 32 on another, the 7-plane pass always best row-major).  All
 // orders produce identical results, so the first launch of a (variant, shape) times the candidates on the
 // caller's stream and keeps the winner; CVS_OPT_BLOCK_ORDER >= 0 pins an order instead.
-int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant)
+int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
 {
     if (h->block_order >= 0) {
         a.block_order = h->block_order;
@@ -311,12 +312,14 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant)
     a.block_order = 0;
     if (h->kind != CVS_KIND_G2 || !basis_fast_path(h->kind, h->width, h->taps) || (size_t)a.rows * a.cols < ((size_t)1 << 20))
         return CVS_OK;  // small images and the generic / G4 paths keep the plain grid
-    const auto key = std::make_tuple(h->device, variant, a.rows, a.cols, a.strip_rows);
+    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->strip_rows > 0 ? 512 : 0), a.rows, a.cols,
+                                     h->strip_rows > 0 ? h->strip_rows : 0);
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
         TuneEntry& e = g_tune[key];
         if (e.order >= 0) {
             a.block_order = e.order;
+            if (e.strip_rows > 0) a.strip_rows = e.strip_rows;
             return CVS_OK;
         }
         // a shape seen for the first time runs on the plain grid: one-off images never pay for tuning
@@ -328,16 +331,24 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant)
         HIP_TRY(h, hipEventCreate(&h->ev0));
         HIP_TRY(h, hipEventCreate(&h->ev1));
     }
-    const int bands = (a.rows + a.strip_rows - 1) / a.strip_rows;
-    const int cand[3] = {0, 32, bands};
-    float tmin[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    // candidates: {row-major, groups of 32 bands, column-major} at the chosen strip height, plus -- when the
+    // caller did not pin the strip height and the input is being re-filtered (so the timing is representative)
+    // -- row-major with the shortest strips
+    const int sr0 = a.strip_rows;
+    const int bands = (a.rows + sr0 - 1) / sr0;
+    const int sr_short = 2 * (2 * h->width + 1) - 2 * h->width;
+    struct Cand { int order, strip; };
+    Cand cand[4] = {{0, sr0}, {32, sr0}, {bands, sr0}, {0, sr_short}};
+    const int ncand = (h->strip_rows > 0 || fresh_input || sr_short == sr0) ? 3 : 4;
+    float tmin[4];
+    for (float& t : tmin) t = std::numeric_limits<float>::max();
     // one untimed launch first (first touch of fresh allocations, clock ramp), then the candidates
     // interleaved over several rounds so that drift hits them equally; keep each candidate's fastest run
-    a.block_order = 0;
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
     for (int round = 0; round < 4; ++round) {
-        for (int ci = 0; ci < 3; ++ci) {
-            a.block_order = cand[ci];
+        for (int ci = 0; ci < ncand; ++ci) {
+            a.block_order = cand[ci].order;
+            a.strip_rows = cand[ci].strip;
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
             HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
             HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -347,21 +358,21 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant)
             if (round > 0 && ms < tmin[ci]) tmin[ci] = ms;  // round 0 warms each candidate's own pattern
         }
     }
-    int best_order = 0;
-    float best = tmin[0];
-    for (int ci = 1; ci < 3; ++ci)
-        if (tmin[ci] < best * 0.98f) {  // a challenger must win by 2 % to displace the plain grid / an earlier winner
-            best = tmin[ci];
-            best_order = cand[ci];
-        }
-    if (std::getenv("CVS_TUNE_VERBOSE"))
-        std::fprintf(stderr, "[cvsteer] block order tune variant %d %dx%d: row-major %.4f ms, T=32 %.4f ms, column-major %.4f ms -> %d\n",
-                     variant, a.rows, a.cols, tmin[0], tmin[1], tmin[2], best_order);
+    int best_ci = 0;
+    for (int ci = 1; ci < ncand; ++ci)
+        if (tmin[ci] < tmin[best_ci] * 0.98f) best_ci = ci;  // a challenger must win by 2 % to displace the default
+    if (std::getenv("CVS_TUNE_VERBOSE")) {
+        std::fprintf(stderr, "[cvsteer] tune variant %d %dx%d:", variant, a.rows, a.cols);
+        for (int ci = 0; ci < ncand; ++ci) std::fprintf(stderr, " (order %d, strip %d) %.4f ms", cand[ci].order, cand[ci].strip, tmin[ci]);
+        std::fprintf(stderr, " -> order %d strip %d\n", cand[best_ci].order, cand[best_ci].strip);
+    }
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
-        g_tune[key].order = best_order;
+        g_tune[key].order = cand[best_ci].order;
+        g_tune[key].strip_rows = cand[best_ci].strip;
     }
-    a.block_order = best_order;
+    a.block_order = cand[best_ci].order;
+    a.strip_rows = cand[best_ci].strip;
     return CVS_OK;
 }
 
@@ -444,7 +455,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     {
         const bool orient_k = a.orient != nullptr;
         const int variant = (orient_k ? 1 : 0) | (steer ? 2 : 0) | (a.pipe ? 4 : 0) | (a.no_state ? 8 : 0);
-        if ((rc = tune_block_order(h, a, scr, variant))) return rc;
+        if ((rc = tune_block_order(h, a, scr, variant, fresh))) return rc;
     }
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
     if ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G4) {  // extension: one per-pixel pass over the 11 planes

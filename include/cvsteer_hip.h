@@ -64,7 +64,7 @@ enum {
 /* options for cvs_set_option */
 enum {
     CVS_OPT_ATAN_MODE = 1,   /* 0 = OpenCV-compatible fastAtan2 polynomial (default), 1 = exact atan2f */
-    CVS_OPT_STRIP_ROWS = 2,  /* rows per wave strip of the basis kernel (tuning; 0 = default) */
+    CVS_OPT_STRIP_ROWS = 2,  /* rows per wave strip of the basis kernel (0 = default: chosen by the engine / autotune) */
     CVS_OPT_FIND_ON = 3,     /* cvs_pipeline: 0 = find*(magnitude, phase) as the reference's callers do
                                 (test/test.cpp:88-90), 1 = find*(e, phase) */
     CVS_OPT_PERSIST_STATE = 9, /* cvs_pipeline / cvs_pipeline_batch: 1 (default) = keep basis + orientation planes like the
