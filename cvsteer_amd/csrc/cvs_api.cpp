@@ -310,9 +310,10 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
         return CVS_OK;
     }
     a.block_order = 0;
-    if (h->kind != CVS_KIND_G2 || !basis_fast_path(h->kind, h->width, h->taps) || (size_t)a.rows * a.cols < ((size_t)1 << 20))
-        return CVS_OK;  // small images and the generic / G4 paths keep the plain grid
-    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->strip_rows > 0 ? 512 : 0), a.rows, a.cols,
+    if ((h->kind == CVS_KIND_G4 && h->g4_split != 2) || !basis_fast_path(h->kind, h->width, h->taps) ||
+        (size_t)a.rows * a.cols < ((size_t)1 << 20))
+        return CVS_OK;  // small images, the generic path and the non-default G4 layouts keep the plain grid
+    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->strip_rows > 0 ? 512 : 0) | (h->kind << 12), a.rows, a.cols,
                                      h->strip_rows > 0 ? h->strip_rows : 0);
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);

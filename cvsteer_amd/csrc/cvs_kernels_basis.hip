@@ -564,7 +564,10 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
     dim3 grid((strips_x + 3) / 4, (a.rows + a.strip_rows - 1) / a.strip_rows, 2), block(256);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
-    a.block_order = 0;
+    if (a.block_order >= 2) {  // same 1-D band-interleaved walk as launch_fast; z still picks the half bank
+        const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
+        grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1, 2);
+    }
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     constexpr int NBTOT = BG::KIND == 2 ? 7 : 11;
     const bool one = (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;
