@@ -49,7 +49,7 @@ struct cvs_context {
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0, wpb = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     std::string err;
 };
@@ -293,6 +293,7 @@ struct TuneEntry {
     int seen = 0;
     int order = -1;      // -1 = not tuned yet
     int strip_rows = 0;  // 0 = keep the default
+    int wpb = 4;         // waves per workgroup
 };
 std::mutex g_tune_mutex;
 std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
@@ -305,11 +306,13 @@ std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
 // caller's stream and keeps the winner; CVS_OPT_BLOCK_ORDER >= 0 pins an order instead.
 int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
 {
+    a.wpb = h->wpb > 0 ? h->wpb : 4;
     if (h->block_order >= 0) {
         a.block_order = h->block_order;
         return CVS_OK;
     }
     a.block_order = 0;
+    if (h->wpb > 0) return CVS_OK;  // a pinned workgroup width switches tuning off as well
     if ((h->kind == CVS_KIND_G4 && h->g4_split != 2) || !basis_fast_path(h->kind, h->width, h->taps) ||
         (size_t)a.rows * a.cols < ((size_t)1 << 20))
         return CVS_OK;  // small images, the generic path and the non-default G4 layouts keep the plain grid
@@ -320,6 +323,7 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
         TuneEntry& e = g_tune[key];
         if (e.order >= 0) {
             a.block_order = e.order;
+            a.wpb = e.wpb;
             if (e.strip_rows > 0) a.strip_rows = e.strip_rows;
             return CVS_OK;
         }
@@ -338,18 +342,27 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
     const int sr0 = a.strip_rows;
     const int bands = (a.rows + sr0 - 1) / sr0;
     const int sr_short = 2 * (2 * h->width + 1) - 2 * h->width;
-    struct Cand { int order, strip; };
-    Cand cand[4] = {{0, sr0}, {32, sr0}, {bands, sr0}, {0, sr_short}};
-    const int ncand = (h->strip_rows > 0 || fresh_input || sr_short == sr0) ? 3 : 4;
-    float tmin[4];
+    struct Cand { int order, strip, wpb; };
+    Cand cand[6] = {{0, sr0, 4}, {32, sr0, 4}, {bands, sr0, 4}, {0, sr_short, 4}, {0, sr0, 8}, {32, sr0, 8}};
+    int ncand = 0;
+    Cand list[6];
+    const bool free_strip = !(h->strip_rows > 0 || fresh_input || sr_short == sr0);
+    const bool wide = h->kind == CVS_KIND_G2 && (a.orient != nullptr || a.frames != nullptr);  // 8-wave workgroups exist for these variants
+    for (int ci = 0; ci < 6; ++ci) {
+        if (ci == 3 && !free_strip) continue;
+        if (cand[ci].wpb == 8 && !wide) continue;
+        list[ncand++] = cand[ci];
+    }
+    float tmin[6];
     for (float& t : tmin) t = std::numeric_limits<float>::max();
     // one untimed launch first (first touch of fresh allocations, clock ramp), then the candidates
     // interleaved over several rounds so that drift hits them equally; keep each candidate's fastest run
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
     for (int round = 0; round < 4; ++round) {
         for (int ci = 0; ci < ncand; ++ci) {
-            a.block_order = cand[ci].order;
-            a.strip_rows = cand[ci].strip;
+            a.block_order = list[ci].order;
+            a.strip_rows = list[ci].strip;
+            a.wpb = list[ci].wpb;
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
             HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
             HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -363,17 +376,20 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
     for (int ci = 1; ci < ncand; ++ci)
         if (tmin[ci] < tmin[best_ci] * 0.98f) best_ci = ci;  // a challenger must win by 2 % to displace the default
     if (std::getenv("CVS_TUNE_VERBOSE")) {
-        std::fprintf(stderr, "[cvsteer] tune variant %d %dx%d:", variant, a.rows, a.cols);
-        for (int ci = 0; ci < ncand; ++ci) std::fprintf(stderr, " (order %d, strip %d) %.4f ms", cand[ci].order, cand[ci].strip, tmin[ci]);
-        std::fprintf(stderr, " -> order %d strip %d\n", cand[best_ci].order, cand[best_ci].strip);
+        std::fprintf(stderr, "[cvsteer] tune kind %d variant %d %dx%d:", h->kind, variant, a.rows, a.cols);
+        for (int ci = 0; ci < ncand; ++ci)
+            std::fprintf(stderr, " (order %d, strip %d, wpb %d) %.4f ms", list[ci].order, list[ci].strip, list[ci].wpb, tmin[ci]);
+        std::fprintf(stderr, " -> order %d strip %d wpb %d\n", list[best_ci].order, list[best_ci].strip, list[best_ci].wpb);
     }
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
-        g_tune[key].order = cand[best_ci].order;
-        g_tune[key].strip_rows = cand[best_ci].strip;
+        g_tune[key].order = list[best_ci].order;
+        g_tune[key].strip_rows = list[best_ci].strip;
+        g_tune[key].wpb = list[best_ci].wpb;
     }
-    a.block_order = cand[best_ci].order;
-    a.strip_rows = cand[best_ci].strip;
+    a.block_order = list[best_ci].order;
+    a.strip_rows = list[best_ci].strip;
+    a.wpb = list[best_ci].wpb;
     return CVS_OK;
 }
 
@@ -654,6 +670,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "persist");
             h->persist = value;
             return CVS_OK;
+        case CVS_OPT_WAVES_PER_GROUP:
+            if (value != 0 && value != 4 && value != 8) return fail(h, CVS_E_BADARG, "waves per group");
+            h->wpb = value;
+            return CVS_OK;
         case CVS_OPT_BLOCK_ORDER:
             if (value < -1 || value == 1 || value > 1000000) return fail(h, CVS_E_BADARG, "block order");
             h->block_order = value;
@@ -672,6 +692,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
         case CVS_OPT_BLOCK_ORDER: *value = h->block_order; return CVS_OK;
+        case CVS_OPT_WAVES_PER_GROUP: *value = h->wpb; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;
     }

@@ -153,7 +153,10 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 
 // the kernel body: one wave filters one strip.  `line` = this wave's LDS line (64 + 2W + 4 floats),
 // `zframe` = frame index of a batched launch.
-template <class B, int FLAGS, bool STREAM, bool BATCH, bool ONE>
+// WPB = waves (adjacent 64-column strips of one row band) per workgroup: 4, or 8 for the variants that write
+// many planes (measured: 12-plane setup 67 -> 83 %, 20-plane pipeline 64 -> 77 % with 8; 7/9-plane variants
+// lose 3-6 points) -- the autotuner in cvs_api.cpp decides per (variant, shape, box).
+template <class B, int FLAGS, bool STREAM, bool BATCH, bool ONE, int WPB>
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe)
 {
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
@@ -175,10 +178,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
         bx = r / tg;
         if (bx >= a.grid_x) return;
     }
-    const int x0 = (bx * 4 + wv) * 64;
+    const int x0 = (bx * WPB + wv) * 64;
     if (x0 >= a.cols) return;  // wave-uniform; waves of a workgroup never rendezvous
 #ifdef CVS_DIAG_STAMPS
-    unsigned long long* stamp = a.diag ? a.diag + ((size_t)(by * a.grid_x + bx) * 4 + wv) * 4 : nullptr;
+    unsigned long long* stamp = a.diag ? a.diag + ((size_t)(by * a.grid_x + bx) * WPB + wv) * 4 : nullptr;
     bool stamped_first = false;
     if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -397,11 +400,11 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #endif
 }
 
-template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool ONE = false>
-__global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
+template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool ONE = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
-    __shared__ float lds[4][64 + 2 * B::W + 4];
-    basis_body<B, FLAGS, STREAM, BATCH, ONE>(a, t, lds[threadIdx.x >> 6], blockIdx.z);
+    __shared__ float lds[WPB][64 + 2 * B::W + 4];
+    basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB>(a, t, lds[threadIdx.x >> 6], blockIdx.z);
 }
 
 // G + H half banks in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
@@ -411,8 +414,8 @@ template <class BG, class BH, int FLAGS, bool STREAM, bool ONE>
 __global__ __launch_bounds__(256) void k_basis_pair(const BasisArgs a, const Folded<BG> tg, const Folded<BH> th)
 {
     __shared__ float lds[4][64 + 2 * BG::W + 4];
-    if (blockIdx.z == 0) basis_body<BG, FLAGS, STREAM, false, ONE>(a, tg, lds[threadIdx.x >> 6], 0);
-    else basis_body<BH, FLAGS, STREAM, false, ONE>(a, th, lds[threadIdx.x >> 6], 0);
+    if (blockIdx.z == 0) basis_body<BG, FLAGS, STREAM, false, ONE, 4>(a, tg, lds[threadIdx.x >> 6], 0);
+    else basis_body<BH, FLAGS, STREAM, false, ONE, 4>(a, th, lds[threadIdx.x >> 6], 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -501,27 +504,38 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
 {
     BasisArgs a = a_in;
     const int strips_x = (a.cols + 63) / 64;
-    dim3 grid((strips_x + 3) / 4, (a.rows + a.strip_rows - 1) / a.strip_rows);
+    // 8-wave workgroups exist for the G2 variants with an orientation / pipeline epilogue
+    const bool orient_v = a.orient != nullptr && B::KIND == 2;
+    const int wpb = (a.wpb == 8 && (orient_v || (a.frames && B::KIND == 2))) ? 8 : 4;
+    dim3 grid((strips_x + wpb - 1) / wpb, (a.rows + a.strip_rows - 1) / a.strip_rows);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
     if (a.block_order >= 2) {
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1);
     }
-    dim3 block(256);
-    const bool orient = a.orient != nullptr && B::KIND == 2;
+    dim3 block(64 * wpb);
+    const bool orient = orient_v;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     constexpr int NBTOT = B::KIND == 2 ? 7 : 11;
     const bool one = (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;
-#define CVS_LAUNCH_B(FL, BATCHED)                                                                             \
-    do {                                                                                                      \
-        if (one) {                                                                                            \
-            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, true>), grid, block, 0, s, a, f);   \
-            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, true>), grid, block, 0, s, a, f);              \
-        } else {                                                                                              \
-            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, false>), grid, block, 0, s, a, f);  \
-            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, false>), grid, block, 0, s, a, f);             \
-        }                                                                                                     \
+#define CVS_LAUNCH_W(FL, BATCHED, WP)                                                                              \
+    do {                                                                                                           \
+        if (one) {                                                                                                 \
+            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, true, WP>), grid, block, 0, s, a, f);   \
+            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, true, WP>), grid, block, 0, s, a, f);              \
+        } else {                                                                                                   \
+            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, false, WP>), grid, block, 0, s, a, f);  \
+            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, false, WP>), grid, block, 0, s, a, f);             \
+        }                                                                                                          \
+    } while (0)
+// variants with F_ORIENT come in both workgroup widths (G2 only); the others in the 4-wave form
+#define CVS_LAUNCH_B(FL, BATCHED)                                                     \
+    do {                                                                              \
+        if constexpr (((FL) & F_ORIENT) != 0 && B::KIND == 2) {                       \
+            if (wpb == 8) { CVS_LAUNCH_W(FL, BATCHED, 8); break; }                    \
+        }                                                                             \
+        CVS_LAUNCH_W(FL, BATCHED, 4);                                                 \
     } while (0)
 #define CVS_LAUNCH(FL) CVS_LAUNCH_B(FL, false)
     if (a.frames) {  // batched caller pipeline: one launch, grid.z = frames (G2 only)
@@ -552,6 +566,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
         else CVS_LAUNCH(0);
     }
 #undef CVS_LAUNCH_B
+#undef CVS_LAUNCH_W
 #undef CVS_LAUNCH
     return hipGetLastError();
 }

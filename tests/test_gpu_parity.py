@@ -724,3 +724,31 @@ def test_block_order_never_changes_results(cv):
             assert torch.equal(a, b), order
     with pytest.raises(cv.CvsError):
         cv.SteerableFiltersG2(None).set_option(L.OPT_BLOCK_ORDER, 1)
+
+
+def test_workgroup_width_never_changes_results(cv):
+    """CVS_OPT_WAVES_PER_GROUP (4- or 8-wave workgroups, any block order): identical outputs, ragged widths too"""
+    import torch
+    from cvsteer_amd import _lib as L
+    for shape in ((1100, 1500), (257, 449), (300, 2048 + 64)):
+        img = torch.rand(shape, device="cuda")
+        ref = None
+        for wpb, order in ((4, 0), (8, 0), (8, 5), (8, 100000), (0, -1)):
+            f = cv.SteerableFiltersG2(None)
+            f.set_option(L.OPT_WAVES_PER_GROUP, wpb)
+            f.set_option(L.OPT_BLOCK_ORDER, order)
+            outs = f.pipeline(img)
+            f.setup(img)
+            cur = [o.clone() for o in outs] + [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle().clone()]
+            f.set_persist(False)
+            feat = [torch.empty_like(img) for _ in range(3)]
+            f.pipeline(img, out=[None] * 5 + feat)
+            cur += feat
+            frames = torch.stack([img, img.flip(0)])
+            cur += [o.clone() for o in f.pipeline_batch(frames, outputs=(5, 6, 7))]
+            if ref is None:
+                ref = cur
+            for a, b in zip(cur, ref):
+                assert torch.equal(a, b), (shape, wpb, order)
+    with pytest.raises(cv.CvsError):
+        cv.SteerableFiltersG2(None).set_option(L.OPT_WAVES_PER_GROUP, 3)
