@@ -930,9 +930,12 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
         }
     }
     const size_t pitch = round_up((size_t)cols, 64);
-    const bool fast = all_dev && !basis_may_need_scratch(h->kind, h->width, h->taps, rows, cols, std::max(pitch, max_bytes / sizeof(float) / rows));
+    // one launch over grid.z needs every plane below 2 GiB (huge frames are filtered in row bands, frame by frame)
+    const bool small_planes = std::max(max_bytes, (size_t)rows * pitch * sizeof(float)) <= (size_t)0x7ffffff0;
+    const bool fast = all_dev && small_planes &&
+                      !basis_may_need_scratch(h->kind, h->width, h->taps, rows, cols, std::max(pitch, max_bytes / sizeof(float) / rows));
     if (!fast) {
-        // host planes, tiny images or non-default taps: frame by frame through the single-image path
+        // host planes, tiny or huge images, non-default taps: frame by frame through the single-image path
         for (int i = 0; i < n; ++i) {
             const cvs_plane* po[8];
             for (int k = 0; k < 8; ++k) po[k] = (outs && outs[(size_t)i * 8 + k].data) ? &outs[(size_t)i * 8 + k] : nullptr;

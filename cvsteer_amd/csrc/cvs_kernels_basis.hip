@@ -185,8 +185,13 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     bool stamped_first = false;
     if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int y0 = by * a.strip_rows;
-    const int yend = min(y0 + a.strip_rows, a.rows);
+    // Planes of 2 GiB and more are filtered in row bands, one launch per band: the host shifts every plane
+    // pointer down by row_base rows, so that the 32-bit buffer offsets of the band (halo included) stay
+    // below 2 GiB, and the launch covers output rows [row_lo, row_hi).  Such planes never fit the
+    // single-resource (ONE) form, which therefore keeps the plain arithmetic.
+    const int rbase = ONE ? 0 : a.row_base;
+    const int y0 = (ONE ? 0 : a.row_lo) + by * a.strip_rows;
+    const int yend = min(y0 + a.strip_rows, ONE ? a.rows : a.row_hi);
     const int x = x0 + lane;
     const bool xin = x < a.cols;
     // REFLECT_101 source columns, fixed for the whole strip.  Columns beyond cols+W feed no valid
@@ -223,9 +228,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
         for (int k = 0; k < 8; ++k) pipe_out[k] = a.pipe_out[k];
     }
     // buffer resources (wave-uniform): input plane, state planes
-    const size_t plane_bytes = (size_t)a.rows * a.pitch * sizeof(float);
+    const size_t plane_bytes = (size_t)(a.rows - rbase) * a.pitch * sizeof(float);
     const unsigned pitch_b = (unsigned)(a.pitch * sizeof(float));
-    const rsrc_t r_in = plane_rsrc(in_p, (size_t)a.rows * in_pitch * sizeof(float));
+    const rsrc_t r_in = plane_rsrc(in_p, (size_t)(a.rows - rbase) * in_pitch * sizeof(float));
     // ONE: the frame's whole state block (basis + orientation planes, one allocation) is a single
     // resource and the plane is part of the scalar offset -- 4 SGPRs instead of 4 per plane, which is
     // what keeps the 20-plane pipeline variant from spilling SGPRs.  Needs the block to be < 2 GiB;
@@ -243,7 +248,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const unsigned ro = (unsigned)reflect1(y0 - W + j, a.rows) * in_pitch_b;
+        const unsigned ro = (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b;
         pre[j] = bld(r_in, xmb, ro);
         preh[j] = bld(r_in, xhb, ro);
     }
@@ -260,7 +265,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             // the register just consumed is refilled at once with the same row of the next group:
             // a full group (2W+1 rows) of loads stays in flight with a single set of registers
             {
-                const unsigned ro = (unsigned)reflect1(y0 - W + (g + 1) * NT + j, a.rows) * in_pitch_b;
+                const unsigned ro = (unsigned)(reflect1(y0 - W + (g + 1) * NT + j, a.rows) - rbase) * in_pitch_b;
                 pre[j] = bld(r_in, nxmb, ro);
                 preh[j] = bld(r_in, nxhb, ro);
             }
@@ -325,7 +330,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     b[p] = acc;
                 }
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
-                const unsigned yo = row_ok ? (unsigned)yout : 0u;
+                const unsigned yo = row_ok ? (unsigned)(yout - rbase) : 0u;
                 const unsigned orow = yo * pitch_b;
                 if constexpr ((FLAGS & F_NOSTATE) == 0) {
 #pragma unroll
@@ -365,13 +370,13 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #pragma unroll
                         for (int k = 0; k < 8; ++k)
                             if (pipe_out[k].p)
-                                bst<STREAM>(plane_rsrc(pipe_out[k].p, (size_t)a.rows * pipe_out[k].pitch * sizeof(float)), xbr,
+                                bst<STREAM>(plane_rsrc(pipe_out[k].p, (size_t)(a.rows - rbase) * pipe_out[k].pitch * sizeof(float)), xbr,
                                             yo * (unsigned)(pipe_out[k].pitch * sizeof(float)), q[k]);
                     }
                 }
                 if constexpr ((FLAGS & F_STEER) != 0) {
-                    const rsrc_t rg = plane_rsrc(a.steer_g, (size_t)a.rows * a.steer_g_pitch * sizeof(float));
-                    const rsrc_t rh = plane_rsrc(a.steer_h, (size_t)a.rows * a.steer_h_pitch * sizeof(float));
+                    const rsrc_t rg = plane_rsrc(a.steer_g, (size_t)(a.rows - rbase) * a.steer_g_pitch * sizeof(float));
+                    const rsrc_t rh = plane_rsrc(a.steer_h, (size_t)(a.rows - rbase) * a.steer_h_pitch * sizeof(float));
                     const unsigned og = yo * (unsigned)(a.steer_g_pitch * sizeof(float));
                     const unsigned oh = yo * (unsigned)(a.steer_h_pitch * sizeof(float));
                     if constexpr (B::HALF == 0) {
@@ -496,7 +501,8 @@ bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], 
 {
     if (!basis_fast_path(kind, width, taps)) return true;
     if (rows < 3 * width + 1 || cols < width + 1) return true;
-    return (size_t)rows * max_pitch * sizeof(float) > kMaxPlaneBytes;
+    // huge planes go through the fast kernel in row bands unless not even one strip fits 2 GiB (see band_rows)
+    return kMaxPlaneBytes / (max_pitch * sizeof(float)) < (size_t)(2 * width + 2);
 }
 
 template <class B>
@@ -507,7 +513,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     // 8-wave workgroups exist for the G2 variants with an orientation / pipeline epilogue
     const bool orient_v = a.orient != nullptr && B::KIND == 2;
     const int wpb = (a.wpb == 8 && (orient_v || (a.frames && B::KIND == 2))) ? 8 : 4;
-    dim3 grid((strips_x + wpb - 1) / wpb, (a.rows + a.strip_rows - 1) / a.strip_rows);
+    dim3 grid((strips_x + wpb - 1) / wpb, (a.row_hi - a.row_lo + a.strip_rows - 1) / a.strip_rows);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
     if (a.block_order >= 2) {
@@ -576,7 +582,7 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
 {
     BasisArgs a = a_in;
     const int strips_x = (a.cols + 63) / 64;
-    dim3 grid((strips_x + 3) / 4, (a.rows + a.strip_rows - 1) / a.strip_rows, 2), block(256);
+    dim3 grid((strips_x + 3) / 4, (a.row_hi - a.row_lo + a.strip_rows - 1) / a.strip_rows, 2), block(256);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
     if (a.block_order >= 2) {  // same 1-D band-interleaved walk as launch_fast; z still picks the half bank
@@ -645,17 +651,59 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
     return e;
 }
 
+// widest row pitch (bytes) of any plane the launch touches
+static size_t max_pitch_bytes(const BasisArgs& a)
+{
+    size_t mx = a.in_pitch > a.pitch ? a.in_pitch : a.pitch;
+    if (a.steer_g) { mx = max(mx, a.steer_g_pitch); mx = max(mx, a.steer_h_pitch); }
+    for (int k = 0; k < 8; ++k)
+        if (a.pipe && a.pipe_out[k].p) mx = max(mx, a.pipe_out[k].pitch);
+    return mx * sizeof(float);
+}
+
+// single-step reflection (reflect1) needs a minimum image size; smaller images take the generic path
 static bool fast_geometry_ok(const BasisArgs& a, int width)
 {
-    // single-step reflection (reflect1) and 31-bit plane offsets: see k_basis
-    if (a.rows < 3 * width + 1 || a.cols < width + 1) return false;
-    const size_t in_bytes = (size_t)a.rows * a.in_pitch * sizeof(float);
-    const size_t st_bytes = (size_t)a.rows * a.pitch * sizeof(float);
-    size_t mx = in_bytes > st_bytes ? in_bytes : st_bytes;
-    if (a.steer_g) { mx = max(mx, (size_t)a.rows * a.steer_g_pitch * sizeof(float)); mx = max(mx, (size_t)a.rows * a.steer_h_pitch * sizeof(float)); }
-    for (int k = 0; k < 8; ++k)
-        if (a.pipe && a.pipe_out[k].p) mx = max(mx, (size_t)a.rows * a.pipe_out[k].pitch * sizeof(float));
-    return mx <= kMaxPlaneBytes;
+    return a.rows >= 3 * width + 1 && a.cols >= width + 1;
+}
+
+// Output rows one launch may cover so that every 32-bit buffer offset (band + halo rows, relative to the
+// shifted plane base) stays below 2 GiB: the whole image for ordinary planes, a band for huge ones.
+// 0 = a single strip does not fit (rows of ~100 MiB and more): generic path.
+static int band_rows(const BasisArgs& a, int width)
+{
+    const size_t fit = kMaxPlaneBytes / max_pitch_bytes(a);
+    if (fit >= (size_t)a.rows) return a.rows;
+    if (fit < (size_t)(2 * width + 2)) return 0;
+    const int room = (int)fit - 2 * width;
+    return room >= a.strip_rows ? room / a.strip_rows * a.strip_rows : room;  // very wide rows: one short strip per band
+}
+
+// launch `fn(args)` once per row band, with the plane pointers shifted to the band's first halo row
+template <class F>
+static hipError_t for_each_band(const BasisArgs& a_in, int width, F&& fn)
+{
+    const int per = band_rows(a_in, width);
+    for (int lo = 0; lo < a_in.rows; lo += per) {
+        BasisArgs a = a_in;
+        if (a.strip_rows > per) a.strip_rows = per;
+        a.row_lo = lo;
+        a.row_hi = lo + per < a.rows ? lo + per : a.rows;
+        // the bottom band also reads reflected rows: rows - 2 - k, which lie above row_hi - 1, never below row_base
+        a.row_base = lo > width ? lo - width : 0;
+        if (per >= a.rows) a.row_base = 0;
+        const size_t rb = (size_t)a.row_base;
+        a.in += rb * a.in_pitch;
+        a.basis += rb * a.pitch;
+        if (a.orient) a.orient += rb * a.pitch;
+        if (a.steer_g) a.steer_g += rb * a.steer_g_pitch;
+        if (a.steer_h) a.steer_h += rb * a.steer_h_pitch;
+        for (int k = 0; k < 8; ++k)
+            if (a.pipe_out[k].p) a.pipe_out[k].p += rb * a.pipe_out[k].pitch;
+        const hipError_t e = fn(a);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
@@ -664,29 +712,34 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
     if (a.frames) {  // batched launch: the API layer has already checked geometry and taps
         Folded<BankG2> f;
         if (kind != 2 || width != BankG2::W || !fold_taps<BankG2>(taps, f)) return hipErrorInvalidValue;
-        return launch_fast<BankG2>(a, f, s);
+        BasisArgs b = a;
+        b.row_lo = b.row_base = 0;
+        b.row_hi = b.rows;
+        return launch_fast<BankG2>(b, f, s);
     }
-    if (!fast_geometry_ok(a, width)) return launch_generic(kind, width, taps, a, scratch, s);
+    if (!fast_geometry_ok(a, width) || band_rows(a, width) == 0) return launch_generic(kind, width, taps, a, scratch, s);
     if (kind == 2 && width == BankG2::W) {
         Folded<BankG2> f;
-        if (fold_taps<BankG2>(taps, f)) return launch_fast<BankG2>(a, f, s);
+        if (fold_taps<BankG2>(taps, f)) return for_each_band(a, width, [&](const BasisArgs& b) { return launch_fast<BankG2>(b, f, s); });
     }
     if (kind == 4 && width == BankG4::W && a.g4_split == 2) {
         Folded<BankG4G> fg;
         Folded<BankG4H> fh;
-        if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh)) return launch_pair<BankG4G, BankG4H>(a, fg, fh, s);
+        if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh))
+            return for_each_band(a, width, [&](const BasisArgs& b) { return launch_pair<BankG4G, BankG4H>(b, fg, fh, s); });
     }
     if (kind == 4 && width == BankG4::W) {
         if (a.g4_split) {
             Folded<BankG4G> fg;
             Folded<BankG4H> fh;
-            if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh)) {
-                hipError_t e = launch_fast<BankG4G>(a, fg, s);
-                return e != hipSuccess ? e : launch_fast<BankG4H>(a, fh, s);
-            }
+            if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh))
+                return for_each_band(a, width, [&](const BasisArgs& b) {
+                    hipError_t e = launch_fast<BankG4G>(b, fg, s);
+                    return e != hipSuccess ? e : launch_fast<BankG4H>(b, fh, s);
+                });
         }
         Folded<BankG4> f;
-        if (fold_taps<BankG4>(taps, f)) return launch_fast<BankG4>(a, f, s);
+        if (fold_taps<BankG4>(taps, f)) return for_each_band(a, width, [&](const BasisArgs& b) { return launch_fast<BankG4>(b, f, s); });
     }
     return launch_generic(kind, width, taps, a, scratch, s);
 }

@@ -752,3 +752,59 @@ def test_workgroup_width_never_changes_results(cv):
                 assert torch.equal(a, b), (shape, wpb, order)
     with pytest.raises(cv.CvsError):
         cv.SteerableFiltersG2(None).set_option(L.OPT_WAVES_PER_GROUP, 3)
+
+
+def test_planes_beyond_2gib_row_banded(cv):
+    """Planes of 2 GiB and more (here 30000 x 40000 f32 = 4.8 GB, far end beyond 4 GiB) run through the same
+    kernel in row bands.  Size-independent check: any window of rows, cropped out with enough halo and filtered on
+    its own, gives bit-identical values -- at the image top/bottom (reflection), across the band seams, anywhere."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 120 * 2**30:
+        pytest.skip("needs > 100 GB of device memory")
+    rows, cols, W = 30000, 40000, 4
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.rand((rows, cols), device="cuda", generator=gen)
+    f = cv.SteerableFiltersG2(None)
+    g, h = f.setup_steer(img, 0.3)
+    band = (0x7ffffff0 // (cols * 4) - 2 * W)          # rows one launch can address (before strip rounding)
+    seams = [band // 19 * 19, 2 * (band // 19 * 19)]
+    small = cv.SteerableFiltersG2(None)
+
+    def check(lo, hi, keep_lo, keep_hi):
+        gs, hs = small.setup_steer(img[lo:hi], 0.3)
+        assert torch.equal(gs[keep_lo - lo:keep_hi - lo], g[keep_lo:keep_hi]), (lo, hi)
+        assert torch.equal(hs[keep_lo - lo:keep_hi - lo], h[keep_lo:keep_hi]), (lo, hi)
+        for p in (0, 3, 6):
+            assert torch.equal(small.basis(p)[keep_lo - lo:keep_hi - lo], f.basis(p)[keep_lo:keep_hi]), (lo, hi, p)
+
+    check(0, 120, 0, 120 - W)                                   # top border
+    check(rows - 120, rows, rows - 120 + W, rows)               # bottom border (beyond 4 GiB)
+    for sm in seams:
+        assert 0 < sm < rows
+        check(sm - 60, sm + 60, sm - 60 + W, sm + 60 - W)       # band seams
+    check(17000, 17100, 17000 + W, 17100 - W)
+    del g, h, f
+    # the callers' pipeline without persisted state, and the G4 pair kernel, on a 2.3 GB plane (two bands)
+    rows2 = 14400
+    sub = img[:rows2]
+    f = cv.SteerableFiltersG2(None)
+    f.set_persist(False)
+    feat = [torch.empty_like(sub) for _ in range(3)]
+    f.pipeline(sub, out=[None] * 5 + feat)
+    seam = (0x7ffffff0 // (cols * 4) - 2 * W) // 19 * 19
+    lo, hi = seam - 50, seam + 50
+    feat_s = [torch.empty_like(sub[lo:hi]) for _ in range(3)]
+    small.set_persist(False)
+    small.pipeline(sub[lo:hi], out=[None] * 5 + feat_s)
+    for a, b in zip(feat, feat_s):
+        assert torch.equal(a[lo + W:hi - W], b[W:-W])
+    del feat, f
+    f4 = cv.SteerableFiltersG4(None)
+    g4, h4 = f4.setup_steer(sub, -0.7)
+    s4 = cv.SteerableFiltersG4(None)
+    seam4 = (0x7ffffff0 // (cols * 4) - 12) // 27 * 27
+    lo, hi = seam4 - 60, seam4 + 60
+    g4s, h4s = s4.setup_steer(sub[lo:hi], -0.7)
+    assert torch.equal(g4[lo + 6:hi - 6], g4s[6:-6]) and torch.equal(h4[lo + 6:hi - 6], h4s[6:-6])
+    g4s, h4s = s4.setup_steer(sub[rows2 - 100:], -0.7)
+    assert torch.equal(g4[rows2 - 94:], g4s[6:]) and torch.equal(h4[rows2 - 94:], h4s[6:])
