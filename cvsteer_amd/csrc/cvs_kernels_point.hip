@@ -180,7 +180,7 @@ static hipError_t launch_op(const PointArgs& a, hipStream_t s)
     if (gx > 64) gx = 64;
     int gy = a.rows;
     // workgroups per CU before rows are strided: 16 for the plain weighted sums; the stages with per-pixel
-    // transcendental work hide it better with more, shorter workgroups (tools/ab_point.py: steer-by-map 67 -> 70 %,
+    // transcendental work hide it better with more, shorter workgroups (interleaved A/B: steer-by-map 67 -> 70 %,
     // magnitude/phase 80 -> 84 % of the HBM roofline at 4096^2, scalar steer 71 -> 70 % the other way)
     constexpr bool kHeavy = OP == OP_G2_STEER_MAP || OP == OP_G4_STEER_MAP || OP == OP_MAG_PHASE || OP == OP_FIND;
     const int cap = 256 * (kHeavy ? 64 : 16);
