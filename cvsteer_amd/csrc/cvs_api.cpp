@@ -49,7 +49,7 @@ struct cvs_context {
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0, wpb = 0;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0, wpb = 0, xcd_weights = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     std::string err;
 };
@@ -294,6 +294,7 @@ struct TuneEntry {
     int order = -1;      // -1 = not tuned yet
     int strip_rows = 0;  // 0 = keep the default
     int wpb = 4;         // waves per workgroup
+    int xw = 504;        // order 1: tiles per period for even / odd XCDs, 100 * e + o
 };
 std::mutex g_tune_mutex;
 std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
@@ -301,12 +302,15 @@ std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
 // Block order autotune.  The basis kernel can walk its strips row-major, in groups of T bands, or
 // column-major; which one the memory system likes depends on how many planes the variant writes and --
 // measurably -- on the box (tools/ab.py: e.g. the 20-plane pipeline 65 -> 80 % column-major on one box,
-// the 12-plane setup 68 -> 82 % with T = 32 on another, the 7-plane pass always best row-major).  All
+// the 12-plane setup 68 -> 82 % with T = 32 on another, the 7-plane pass always best row-major; part of that
+// spread follows the physical placement of the state allocation, tools/alloc_modes.py).  All
 // orders produce identical results, so the first launch of a (variant, shape) times the candidates on the
 // caller's stream and keeps the winner; CVS_OPT_BLOCK_ORDER >= 0 pins an order instead.
 int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
 {
     a.wpb = h->wpb > 0 ? h->wpb : 4;
+    a.xcd_even = h->xcd_weights ? h->xcd_weights / 100 : 5;
+    a.xcd_odd = h->xcd_weights ? h->xcd_weights % 100 : 4;
     if (h->block_order >= 0) {
         a.block_order = h->block_order;
         return CVS_OK;
@@ -324,6 +328,7 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
         if (e.order >= 0) {
             a.block_order = e.order;
             a.wpb = e.wpb;
+            if (!h->xcd_weights) { a.xcd_even = e.xw / 100; a.xcd_odd = e.xw % 100; }
             if (e.strip_rows > 0) a.strip_rows = e.strip_rows;
             return CVS_OK;
         }
@@ -342,18 +347,26 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
     const int sr0 = a.strip_rows;
     const int bands = (a.rows + sr0 - 1) / sr0;
     const int sr_short = 2 * (2 * h->width + 1) - 2 * h->width;
-    struct Cand { int order, strip, wpb; };
-    Cand cand[6] = {{0, sr0, 4}, {32, sr0, 4}, {bands, sr0, 4}, {0, sr_short, 4}, {0, sr0, 8}, {32, sr0, 8}};
+    // ... and row-major with more tiles for the even XCDs (5:4, 4:3), which run this kernel faster than the odd ones
+    struct Cand { int order, strip, wpb, xw; };
+    constexpr int kCand = 8;
+    const int xw0 = a.xcd_even * 100 + a.xcd_odd;
+    Cand cand[kCand] = {{0, sr0, 4, xw0}, {32, sr0, 4, xw0}, {bands, sr0, 4, xw0}, {0, sr_short, 4, xw0},
+                        {0, sr0, 8, xw0}, {32, sr0, 8, xw0}, {1, sr0, 4, 504}, {1, sr0, 4, 403}};
     int ncand = 0;
-    Cand list[6];
+    Cand list[kCand];
     const bool free_strip = !(h->strip_rows > 0 || fresh_input || sr_short == sr0);
     const bool wide = h->kind == CVS_KIND_G2 && (a.orient != nullptr || a.frames != nullptr);  // 8-wave workgroups exist for these variants
-    for (int ci = 0; ci < 6; ++ci) {
+    for (int ci = 0; ci < kCand; ++ci) {
         if (ci == 3 && !free_strip) continue;
         if (cand[ci].wpb == 8 && !wide) continue;
+        if (cand[ci].order == 1 && h->xcd_weights) {  // weights pinned by the caller: one weighted candidate
+            if (ci != 6) continue;
+            cand[ci].xw = xw0;
+        }
         list[ncand++] = cand[ci];
     }
-    float tmin[6];
+    float tmin[kCand];
     for (float& t : tmin) t = std::numeric_limits<float>::max();
     // one untimed launch first (first touch of fresh allocations, clock ramp), then the candidates
     // interleaved over several rounds so that drift hits them equally; keep each candidate's fastest run
@@ -363,6 +376,8 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
             a.block_order = list[ci].order;
             a.strip_rows = list[ci].strip;
             a.wpb = list[ci].wpb;
+            a.xcd_even = list[ci].xw / 100;
+            a.xcd_odd = list[ci].xw % 100;
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
             HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
             HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -378,18 +393,21 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
     if (std::getenv("CVS_TUNE_VERBOSE")) {
         std::fprintf(stderr, "[cvsteer] tune kind %d variant %d %dx%d:", h->kind, variant, a.rows, a.cols);
         for (int ci = 0; ci < ncand; ++ci)
-            std::fprintf(stderr, " (order %d, strip %d, wpb %d) %.4f ms", list[ci].order, list[ci].strip, list[ci].wpb, tmin[ci]);
-        std::fprintf(stderr, " -> order %d strip %d wpb %d\n", list[best_ci].order, list[best_ci].strip, list[best_ci].wpb);
+            std::fprintf(stderr, " (order %d, strip %d, wpb %d, xcd %d) %.4f ms", list[ci].order, list[ci].strip, list[ci].wpb, list[ci].xw, tmin[ci]);
+        std::fprintf(stderr, " -> order %d strip %d wpb %d xcd %d\n", list[best_ci].order, list[best_ci].strip, list[best_ci].wpb, list[best_ci].xw);
     }
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
         g_tune[key].order = list[best_ci].order;
         g_tune[key].strip_rows = list[best_ci].strip;
         g_tune[key].wpb = list[best_ci].wpb;
+        g_tune[key].xw = list[best_ci].xw;
     }
     a.block_order = list[best_ci].order;
     a.strip_rows = list[best_ci].strip;
     a.wpb = list[best_ci].wpb;
+    a.xcd_even = list[best_ci].xw / 100;
+    a.xcd_odd = list[best_ci].xw % 100;
     return CVS_OK;
 }
 
@@ -674,8 +692,12 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 4 && value != 8) return fail(h, CVS_E_BADARG, "waves per group");
             h->wpb = value;
             return CVS_OK;
+        case CVS_OPT_XCD_WEIGHTS:
+            if (value != 0 && (value / 100 < 1 || value / 100 > 16 || value % 100 < 1 || value % 100 > 16)) return fail(h, CVS_E_BADARG, "xcd weights");
+            h->xcd_weights = value;
+            return CVS_OK;
         case CVS_OPT_BLOCK_ORDER:
-            if (value < -1 || value == 1 || value > 1000000) return fail(h, CVS_E_BADARG, "block order");
+            if (value < -1 || value > 1000000) return fail(h, CVS_E_BADARG, "block order");
             h->block_order = value;
             return CVS_OK;
     }
@@ -692,6 +714,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
         case CVS_OPT_BLOCK_ORDER: *value = h->block_order; return CVS_OK;
+        case CVS_OPT_XCD_WEIGHTS: *value = h->xcd_weights; return CVS_OK;
         case CVS_OPT_WAVES_PER_GROUP: *value = h->wpb; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;

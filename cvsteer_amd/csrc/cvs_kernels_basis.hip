@@ -170,7 +170,24 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // kernel variant (how many planes it writes) and on the box; the API layer picks it by timing the
     // candidates once per (variant, shape) -- see autotune in cvs_api.cpp.
     int bx = blockIdx.x, by = blockIdx.y;
-    if (a.block_order >= 2) {
+    if (a.block_order == 1) {
+        // XCD-weighted row-major order.  Workgroup b runs on XCD b % 8 (observed on every launch, tools/xcd_map.py;
+        // only speed depends on it), every XCD gets the same number of workgroups, and the XCDs are not equally
+        // fast at this kernel: the odd ones need ~25 % longer per strip (tools/k1_timeline.py), so in the plain
+        // order the even ones idle for the last fifth of the launch.  Here the tiles are dealt in periods of
+        // 4 * (ce + co): an even XCD takes ce tiles per period, an odd one co, and the grid is padded with
+        // workgroups that find no tile and leave at once.  Period layout: cmin rows of the labels 0..7, then
+        // (cmax - cmin) rows of the four labels of the heavier parity.
+        const int ce = a.xcd_even, co = a.xcd_odd, cmin = min(ce, co);
+        const int label = blockIdx.x & 7, r = blockIdx.x >> 3;
+        const int cl = (label & 1) ? co : ce;
+        const int k = r / cl, j = r - k * cl;
+        const int pos = j < cmin ? j * 8 + label : cmin * 8 + (j - cmin) * 4 + (label >> 1);
+        const int tl = k * 4 * (ce + co) + pos;
+        if (tl >= a.grid_x * a.grid_y) return;
+        by = tl / a.grid_x;
+        bx = tl - by * a.grid_x;
+    } else if (a.block_order >= 2) {
         const int T = min(a.block_order, a.grid_y);
         const int per = T * a.grid_x, g = blockIdx.x / per, r = blockIdx.x % per;
         const int tg = min(T, a.grid_y - g * T);  // bands in this (possibly last, shorter) group
@@ -183,7 +200,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #ifdef CVS_DIAG_STAMPS
     unsigned long long* stamp = a.diag ? a.diag + ((size_t)(by * a.grid_x + bx) * WPB + wv) * 4 : nullptr;
     bool stamped_first = false;
-    if (stamp && lane == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
+    if (stamp && lane == 0) {
+        stamp[0] = __builtin_amdgcn_s_memrealtime();
+        stamp[3] = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]: the XCD this wave runs on
+    }
 #endif
     // Planes of 2 GiB and more are filtered in row bands, one launch per band: the host shifts every plane
     // pointer down by row_base rows, so that the 32-bit buffer offsets of the band (halo included) stay
@@ -236,7 +256,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // what keeps the 20-plane pipeline variant from spilling SGPRs.  Needs the block to be < 2 GiB;
     // larger images use one resource per plane.
     constexpr int NBTOT = B::KIND == 2 ? 7 : 11;
-    const rsrc_t r_state = plane_rsrc(basis_p, (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float));
+    const rsrc_t r_state = plane_rsrc(basis_p, ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float));
     const unsigned pstride_b = (unsigned)(a.plane_stride * sizeof(float));
     const unsigned in_pitch_b = (unsigned)(in_pitch * sizeof(float));
 
@@ -505,6 +525,16 @@ bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], 
     return kMaxPlaneBytes / (max_pitch * sizeof(float)) < (size_t)(2 * width + 2);
 }
 
+// grid of the XCD-weighted order (see basis_body): whole periods, 8 labels x cmax workgroups each
+static unsigned weighted_grid(BasisArgs& a)
+{
+    if (a.xcd_even < 1 || a.xcd_even > 16) a.xcd_even = 5;
+    if (a.xcd_odd < 1 || a.xcd_odd > 16) a.xcd_odd = 4;
+    const size_t tiles = (size_t)a.grid_x * a.grid_y, period = 4 * (size_t)(a.xcd_even + a.xcd_odd);
+    const int cmax = a.xcd_even > a.xcd_odd ? a.xcd_even : a.xcd_odd;
+    return (unsigned)(((tiles + period - 1) / period) * 8 * cmax);
+}
+
 template <class B>
 static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStream_t s)
 {
@@ -519,12 +549,14 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     if (a.block_order >= 2) {
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1);
+    } else if (a.block_order == 1) {
+        grid = dim3(weighted_grid(a));
     }
     dim3 block(64 * wpb);
     const bool orient = orient_v;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     constexpr int NBTOT = B::KIND == 2 ? 7 : 11;
-    const bool one = (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;
+    const bool one = ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float) <= kMaxPlaneBytes;
 #define CVS_LAUNCH_W(FL, BATCHED, WP)                                                                              \
     do {                                                                                                           \
         if (one) {                                                                                                 \
@@ -588,10 +620,12 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
     if (a.block_order >= 2) {  // same 1-D band-interleaved walk as launch_fast; z still picks the half bank
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1, 2);
+    } else if (a.block_order == 1) {
+        grid = dim3(weighted_grid(a), 1, 2);
     }
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     constexpr int NBTOT = BG::KIND == 2 ? 7 : 11;
-    const bool one = (size_t)(NBTOT + 5) * a.plane_stride * sizeof(float) <= kMaxPlaneBytes;
+    const bool one = ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float) <= kMaxPlaneBytes;
 #define CVS_PAIR(FL, ST, ON) hipLaunchKernelGGL((k_basis_pair<BG, BH, FL, ST, ON>), grid, block, 0, s, a, fg, fh)
     if (steer) {
         if (a.nt_stores) { if (one) CVS_PAIR(F_STEER, true, true); else CVS_PAIR(F_STEER, true, false); }

@@ -75,9 +75,11 @@ enum {
     CVS_OPT_WAVES_PER_GROUP = 7, /* basis kernel workgroup width: 0 (default) = autotuned, 4 or 8 waves (8 exists for the G2
                                     variants with an orientation / pipeline epilogue; pinning it switches tuning off) */
     CVS_OPT_BLOCK_ORDER = 8, /* order in which the basis kernel walks its strips: -1 (default) = timed once per (kernel
-                                variant, image shape) on first use and cached; 0 = row-major; T >= 2 = groups of T row
-                                bands walked column by column (T >= number of bands: column-major).  Results do not
-                                depend on it. */
+                                variant, image shape) on first use and cached; 0 = row-major; 1 = row-major with more tiles for the
+                                faster XCDs (CVS_OPT_XCD_WEIGHTS); T >= 2 = groups of T row bands walked column by
+                                column (T >= number of bands: column-major).  Results do not depend on it. */
+    CVS_OPT_XCD_WEIGHTS = 10, /* block order 1: 100 * e + o = tiles per period for the even / odd XCDs (1..16 each);
+                                 0 (default) = 5:4, or what the autotuner found (tuning) */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
                                 launch (blockIdx.z picks the half) */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the

@@ -710,7 +710,7 @@ def test_block_order_never_changes_results(cv):
     from cvsteer_amd import _lib as L
     img = torch.rand((1100, 1500), device="cuda")     # >= 1 Mpix: eligible for autotune
     ref = None
-    for order in (0, 2, 7, 32, 100000, -1):
+    for order in (0, 1, 2, 7, 32, 100000, -1):
         f = cv.SteerableFiltersG2(None)
         f.set_option(L.OPT_BLOCK_ORDER, order)
         outs = []
@@ -723,7 +723,7 @@ def test_block_order_never_changes_results(cv):
         for a, b in zip(cur, ref):
             assert torch.equal(a, b), order
     with pytest.raises(cv.CvsError):
-        cv.SteerableFiltersG2(None).set_option(L.OPT_BLOCK_ORDER, 1)
+        cv.SteerableFiltersG2(None).set_option(L.OPT_BLOCK_ORDER, -2)
 
 
 def test_workgroup_width_never_changes_results(cv):
@@ -733,7 +733,7 @@ def test_workgroup_width_never_changes_results(cv):
     for shape in ((1100, 1500), (257, 449), (300, 2048 + 64)):
         img = torch.rand(shape, device="cuda")
         ref = None
-        for wpb, order in ((4, 0), (8, 0), (8, 5), (8, 100000), (0, -1)):
+        for wpb, order in ((4, 0), (8, 0), (4, 1), (8, 1), (8, 5), (8, 100000), (0, -1)):
             f = cv.SteerableFiltersG2(None)
             f.set_option(L.OPT_WAVES_PER_GROUP, wpb)
             f.set_option(L.OPT_BLOCK_ORDER, order)

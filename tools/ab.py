@@ -14,16 +14,24 @@ def timeit(fn, steps=20):
     return a.elapsed_time(b) / steps
 
 def main():
-    opt = int(sys.argv[1]) if len(sys.argv) > 1 else L.OPT_BLOCK_ORDER
-    values = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
-    n = 4096
+    # either: ab.py OPT v1,v2,...      (one option, several values)
+    # or:     ab.py cfg "8=0" "8=1,10=0" ...   (several option sets, "opt=value,opt=value")
+    n = int(os.environ.get("AB_N", "4096"))
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg":
+        values = sys.argv[2:]
+        cfgs = {v: [tuple(int(x) for x in kv.split("=")) for kv in v.split(",") if kv] for v in values}
+    else:
+        opt = int(sys.argv[1]) if len(sys.argv) > 1 else L.OPT_BLOCK_ORDER
+        values = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
+        cfgs = {v: [(opt, v)] for v in values}
     img = torch.rand((n, n), device="cuda")
     g, h = torch.empty_like(img), torch.empty_like(img)
     outs = [torch.empty_like(img) for _ in range(8)]
     hs = {}
     for v in values:
         f = cv.SteerableFiltersG2(None)
-        f.set_option(opt, v)
+        for o, val in cfgs[v]:
+            f.set_option(o, val)
         hs[v] = f
     legs = {
         "M1 basis": (lambda f: f.setup(img, flags=cv.SETUP_BASIS), 32),
@@ -42,7 +50,7 @@ def main():
         line = "%-12s" % name
         for v in values:
             med, mn = statistics.median(res[v]), min(res[v])
-            line += " | opt=%2d med %.4f ms (%5.1f%%) min %.4f" % (v, med, bpp * n * n / med / 1e6 / 80, mn)
+            line += " | %s med %.4f ms (%5.1f%%) min %.4f" % (v, med, bpp * n * n / med / 1e6 / 80, mn)
         print(line, flush=True)
 
 if __name__ == "__main__":

@@ -12,9 +12,13 @@ from cvsteer_amd import _lib as L
 
 n = 4096
 sr = int(sys.argv[1]) if len(sys.argv) > 1 else 19
+order = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tall = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 img = torch.rand((n, n), device="cuda")
 f = cv.SteerableFiltersG2(None)
 f.set_strip_rows(sr)
+f.set_option(L.OPT_BLOCK_ORDER, order)
+f.set_option(L.OPT_TALL_ROWS, tall)
 lib = cv.lib()
 lib.cvs_diag_set_buffer.argtypes = [C.c_void_p, C.c_void_p]
 bands = (n + sr - 1) // sr
@@ -28,7 +32,10 @@ for flags, name in ((cv.SETUP_BASIS, "M1 basis"), (cv.SETUP_FULL, "M4 full")):
     f.setup(img, flags=flags)
     torch.cuda.synchronize()
     lib.cvs_diag_set_buffer(f._h, None)
-    t = buf.cpu().numpy().astype(np.float64) * 0.01   # 100 MHz ticks -> microseconds
+    raw = buf.cpu().numpy()
+    used = raw[:, 0] != 0                                # dynamic order: tall bands leave some slots unused
+    xcc = raw[used, 3]
+    t = raw[used].astype(np.float64) * 0.01              # 100 MHz ticks -> microseconds
     t0 = t[:, 0].min()
     start, first, end = t[:, 0] - t0, t[:, 1] - t0, t[:, 2] - t0
     total = end.max()
@@ -41,3 +48,16 @@ for flags, name in ((cv.SETUP_BASIS, "M1 basis"), (cv.SETUP_FULL, "M4 full")):
     sto = [(np.minimum(end, edges[i + 1]) - np.maximum(first, edges[i])).clip(0).sum() / (edges[1] - edges[0]) for i in range(20)]
     print("   resident waves per 5%% slice : " + " ".join("%4.0f" % o for o in occ))
     print("   of which past priming       : " + " ".join("%4.0f" % o for o in sto))
+    # workgroup w = by * 16 + bx lands on XCD w % 8 (round-robin dispatch): does every XCD finish at the same time?
+    if order == 1:
+        xcd = xcc                                        # stamped from HW_REG_XCC_ID
+        print("   strips per XCD     : " + " ".join("%5d" % (xcd == k).sum() for k in range(8)))
+    else:
+        xcd = xcc                                        # stamped from HW_REG_XCC_ID
+        print("   strips per XCD     : " + " ".join("%5d" % (xcd == k).sum() for k in range(8)))
+    colblk = (np.arange(nwaves) % 64 // 4)[used]         # 256-column block of the strip
+    life = end - start
+    print("   mean life by column block: " + " ".join("%4.1f" % life[colblk == k].mean() for k in range(16)))
+    print("   per-XCD   last end : " + " ".join("%5.1f" % end[xcd == k].max() for k in range(8)))
+    print("   per-XCD last start : " + " ".join("%5.1f" % start[xcd == k].max() for k in range(8)))
+    print("   per-XCD mean life  : " + " ".join("%5.1f" % (end - start)[xcd == k].mean() for k in range(8)))
