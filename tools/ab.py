@@ -28,8 +28,9 @@ def main():
     g, h = torch.empty_like(img), torch.empty_like(img)
     outs = [torch.empty_like(img) for _ in range(8)]
     hs = {}
+    g4 = os.environ.get("AB_KIND", "2") == "4"
     for v in values:
-        f = cv.SteerableFiltersG2(None)
+        f = cv.SteerableFiltersG4(None) if g4 else cv.SteerableFiltersG2(None)
         for o, val in cfgs[v]:
             f.set_option(o, val)
         hs[v] = f
@@ -39,6 +40,8 @@ def main():
         "M4 full": (lambda f: f.setup(img, flags=cv.SETUP_FULL), 52),
         "M5 pipeline": (lambda f: f.pipeline(img, out=outs), 84),
     }
+    if g4:
+        legs = {"M6 basis": (lambda f: f.setup(img), 48), "M6 +steer": (lambda f: f.setup_steer(img, 0.3, out=(g, h)), 56)}
     for name, (fn, bpp) in legs.items():
         res = {v: [] for v in values}
         for v in values:
