@@ -49,8 +49,10 @@ struct cvs_context {
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0, wpb = 0, xcd_weights = 0;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0, wpb = 0, xcd_weights = 0, placement = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
+    size_t placed_elems = 0;                  // state allocation (by size) the placement search has looked at
+    int same_shape_calls = 0;                 // consecutive basis launches on the current state allocation
     std::string err;
 };
 
@@ -242,6 +244,8 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
         }
         HIP_TRY(h, hipMalloc(&h->state, elems * sizeof(float)));
         h->state_elems = elems;
+        h->same_shape_calls = 0;
+        h->placed_elems = 0;
     }
     h->rows = rows;
     h->cols = cols;
@@ -299,6 +303,73 @@ struct TuneEntry {
 std::mutex g_tune_mutex;
 std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
 
+// Placement search.  The many-plane variants run at one of two speeds (67-71 % or 81-84 % of the roofline at
+// 4096^2) depending on where the state block happens to be allocated -- same kernel, same order, same image;
+// nothing at the API level (padding, offsets, contiguity, allocation size) moves a block from one mode to the
+// other (tools/alloc_modes.py).  What does work is taking another block: a handle that keeps filtering
+// the same shape allocates a few candidate state blocks once, times the launch it is about to make on each,
+// keeps the fastest and frees the rest.  Results do not depend on it; it costs a few tens of milliseconds, so it
+// waits until the handle has filtered the shape a few times, and it needs the spare memory to exist.
+int search_placement(cvs_handle h, BasisArgs& a, float* scr)
+{
+    if (!h->placement || h->placed_elems == h->state_elems || a.no_state) return CVS_OK;
+    if (++h->same_shape_calls < 8) return CVS_OK;
+    h->placed_elems = h->state_elems;
+    const size_t bytes = h->state_elems * sizeof(float);
+    if (bytes < ((size_t)256 << 20)) return CVS_OK;  // the whole state sits in the Infinity Cache: nothing to find
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return CVS_OK;
+    constexpr int kExtra = 8;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (kExtra + 1) * bytes + ((size_t)4 << 30)) return CVS_OK;
+    if (!h->ev0) {
+        HIP_TRY(h, hipEventCreate(&h->ev0));
+        HIP_TRY(h, hipEventCreate(&h->ev1));
+    }
+    float* cand[kExtra + 1] = {h->state};
+    int n = 1;
+    for (; n <= kExtra; ++n)
+        if (hipMalloc(&cand[n], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+    float best[kExtra + 1];
+    float* const home = h->state;
+    const ptrdiff_t basis_off = a.basis - home, orient_off = a.orient ? a.orient - home : 0;
+    int rc = CVS_OK;
+    for (int k = 0; k < n && rc == CVS_OK; ++k) {
+        best[k] = std::numeric_limits<float>::max();
+        a.basis = cand[k] + basis_off;
+        if (a.orient) a.orient = cand[k] + orient_off;
+        for (int r = 0; r < 4; ++r) {  // the first launch on a fresh block pays for its first touch
+            if (hipEventRecord(h->ev0, h->stream) != hipSuccess || launch_basis(h->kind, h->width, h->taps, a, scr, h->stream) != hipSuccess ||
+                hipEventRecord(h->ev1, h->stream) != hipSuccess || hipEventSynchronize(h->ev1) != hipSuccess) {
+                rc = fail(h, CVS_E_HIP, "placement search");
+                break;
+            }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            if (r > 0 && ms < best[k]) best[k] = ms;
+        }
+    }
+    int pick = 0;
+    if (rc == CVS_OK)
+        for (int k = 1; k < n; ++k)
+            if (best[k] < best[pick] && best[k] < best[0] * 0.96f) pick = k;  // moving must be worth 4 %
+    if (std::getenv("CVS_TUNE_VERBOSE")) {
+        std::fprintf(stderr, "[cvsteer] placement %dx%d:", a.rows, a.cols);
+        for (int k = 0; k < n; ++k) std::fprintf(stderr, " %.4f", best[k]);
+        std::fprintf(stderr, " ms -> block %d\n", pick);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    for (int k = 0; k < n; ++k)
+        if (k != pick) (void)hipFree(cand[k]);
+    h->state = cand[pick];
+    a.basis = h->state + basis_off;
+    if (a.orient) a.orient = h->state + orient_off;
+    return rc;
+}
+
 // Block order autotune.  The basis kernel can walk its strips row-major, in groups of T bands, or
 // column-major; which one the memory system likes depends on how many planes the variant writes and --
 // measurably -- on the box (tools/ab.py: e.g. the 20-plane pipeline 65 -> 80 % column-major on one box,
@@ -308,6 +379,7 @@ std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
 // caller's stream and keeps the winner; CVS_OPT_BLOCK_ORDER >= 0 pins an order instead.
 int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
 {
+    if (int rc = search_placement(h, a, scr)) return rc;
     a.wpb = h->wpb > 0 ? h->wpb : 4;
     a.xcd_even = h->xcd_weights ? h->xcd_weights / 100 : 5;
     a.xcd_odd = h->xcd_weights ? h->xcd_weights % 100 : 4;
@@ -627,6 +699,7 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
         delete h;
         return CVS_E_NOMEM;
     }
+    if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::atoi(e) != 0;  // default for new handles (A/B tools switch it off)
     *out = h;
     return CVS_OK;
 }
@@ -692,6 +765,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 4 && value != 8) return fail(h, CVS_E_BADARG, "waves per group");
             h->wpb = value;
             return CVS_OK;
+        case CVS_OPT_PLACEMENT_SEARCH:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "placement search");
+            h->placement = value;
+            return CVS_OK;
         case CVS_OPT_XCD_WEIGHTS:
             if (value != 0 && (value / 100 < 1 || value / 100 > 16 || value % 100 < 1 || value % 100 > 16)) return fail(h, CVS_E_BADARG, "xcd weights");
             h->xcd_weights = value;
@@ -715,6 +792,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
         case CVS_OPT_BLOCK_ORDER: *value = h->block_order; return CVS_OK;
         case CVS_OPT_XCD_WEIGHTS: *value = h->xcd_weights; return CVS_OK;
+        case CVS_OPT_PLACEMENT_SEARCH: *value = h->placement; return CVS_OK;
         case CVS_OPT_WAVES_PER_GROUP: *value = h->wpb; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;

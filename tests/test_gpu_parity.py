@@ -808,3 +808,26 @@ def test_planes_beyond_2gib_row_banded(cv):
     assert torch.equal(g4[lo + 6:hi - 6], g4s[6:-6]) and torch.equal(h4[lo + 6:hi - 6], h4s[6:-6])
     g4s, h4s = s4.setup_steer(sub[rows2 - 100:], -0.7)
     assert torch.equal(g4[rows2 - 94:], g4s[6:]) and torch.equal(h4[rows2 - 94:], h4s[6:])
+
+
+def test_placement_search_keeps_results_and_state(cv):
+    """CVS_OPT_PLACEMENT_SEARCH: after a few launches of one shape the handle may move its state to another
+    allocation; outputs and state must be what a handle without the search produces, before and after"""
+    import torch
+    from cvsteer_amd import _lib as L
+    img = torch.rand((4096, 2560), device="cuda")          # state = 12 x 40 MiB: above the 256 MiB threshold
+    ref = cv.SteerableFiltersG2(None)
+    ref.set_option(L.OPT_PLACEMENT_SEARCH, 0)
+    ref.setup(img)
+    want = [ref.basis(p).clone() for p in range(7)] + [ref.getDominantOrientationAngle().clone()]
+    f = cv.SteerableFiltersG2(None)
+    f.set_option(L.OPT_PLACEMENT_SEARCH, 1)
+    for it in range(12):                                    # the search runs on the 8th launch
+        f.setup(img)
+        if it in (0, 6, 7, 8, 11):
+            got = [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle()]
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), it
+    g, h = f.steer(0.3)                                     # later stages read the (possibly moved) state
+    g0, h0 = ref.steer(0.3)
+    assert torch.equal(g, g0) and torch.equal(h, h0)

@@ -9,6 +9,7 @@ physically contiguous allocations (hipDeviceMallocContiguous: always the slower 
 row-interleaved planes do not move a handle from one mode to the other.  On other boxes no allocation is fast."""
 import ctypes as C, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")  # A/B runs compare like with like
 import torch
 import cvsteer_amd as cv
 from cvsteer_amd import _lib as L

@@ -2,6 +2,7 @@
 """tools/tune.py -- sweep the basis kernel's launch knobs on the GPU box (strip rows x store policy)."""
 import os, sys, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")  # A/B runs compare like with like
 import torch
 import cvsteer_amd as cv
 from cvsteer_amd import _lib as L
