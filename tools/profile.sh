@@ -16,6 +16,7 @@ cd $R
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu --no-extra > $O/prof_stats.log 2>&1
 echo "stats rc=$?" >> $O/prof_stats.log
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_all -- python3 bench.py --steps 50 --warmup 5 --no-cpu > $O/prof_stats_all.log 2>&1
+export CVS_PLACEMENT_SEARCH=0   # counter passes: 8 launches in all, the search (8th launch of a shape) would be one of them
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python3 bench.py --steps 5 --warmup 3 --no-cpu --no-extra > $O/pmc_$C.log 2>&1
   echo "pmc $C rc=$?" >> $O/pmc_$C.log
