@@ -129,6 +129,13 @@ def main():
     def step():
         f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
 
+    # engine initialisation, before the contract's W warm-ups: a handle times its launch orders on the 2nd call with
+    # a shape and may move its state block on the 8th (one-time, tens of milliseconds) -- a
+    # short --warmup must not push that into the timed region
+    INIT_CALLS = 10
+    for _ in range(INIT_CALLS):
+        step()
+    torch.cuda.synchronize()
     wall, ev_ms = _time_steps(torch, step, args.steps, args.warmup, barrier)
     if dist is not None:
         t = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
@@ -153,7 +160,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "G2+H2 7-basis separable pass + scalar steer (theta=0.3), one 4096x4096 f32 image "
                                "per GPU per step, image resident in HBM, bases persisted (BASELINE configs[1])",
-                   "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective"},
+                   "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective", "init_calls": INIT_CALLS},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "cvs::k_basis<BankG2, F_STEER>", "algorithmic_bytes_per_launch": BYTES_PER_PIX["M2"] * npix,
@@ -163,7 +170,10 @@ def main():
     # ---- secondary legs (reported, not the headline) ----
     if not args.no_extra:
         extra = {}
-        ksteps, kwarm = args.steps, max(5, args.warmup // 2)
+        ksteps, kwarm = args.steps, max(10, args.warmup // 2)
+        # a handle tunes its launch order on the 2nd call with a shape and may move its state on the 8th:
+        # every leg warms up long enough for both to happen outside its timed region
+        WARM_NEW = 10
 
         def leg(name, fn, bpp, pix=npix):
             w_, e_ = _time_steps(torch, fn, ksteps, kwarm, barrier)
@@ -201,7 +211,7 @@ def main():
         bsteps = max(5, args.steps // 4)
         for nm, fn, bpp in (("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32),
                             ("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40)):
-            w_, e_ = _time_steps(torch, fn, bsteps, 3, barrier)
+            w_, e_ = _time_steps(torch, fn, bsteps, WARM_NEW, barrier)
             ms = e_ / bsteps
             extra[nm] = {"Mpix/s": round(4 * npix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5),
                          "GB/s": round(bpp * 4 * npix / (ms * 1e-3) / 1e9, 1),
@@ -213,7 +223,7 @@ def main():
         fout = torch.empty((nfr, 8, 1080, 1920), device=dev)
         ff = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
         csteps = max(2, args.steps // 20)
-        w_, e_ = _time_steps(torch, lambda: ff.pipeline_batch(frames, out=fout), csteps, 2, barrier)
+        w_, e_ = _time_steps(torch, lambda: ff.pipeline_batch(frames, out=fout), csteps, WARM_NEW, barrier)
         ms = e_ / csteps
         fp = nfr * 1080 * 1920
         extra["C4_32x1080p_pipeline_batch"] = {"Mpix/s": round(fp / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms / nfr, 5),
@@ -221,7 +231,7 @@ def main():
                                                "launches_per_batch": 1}
         ff.set_persist(False)
         fo3 = torch.empty((nfr, 3, 1080, 1920), device=dev)
-        w_, e_ = _time_steps(torch, lambda: ff.pipeline_batch(frames, out=fo3, outputs=(5, 6, 7)), csteps, 2, barrier)
+        w_, e_ = _time_steps(torch, lambda: ff.pipeline_batch(frames, out=fo3, outputs=(5, 6, 7)), csteps, WARM_NEW, barrier)
         ms = e_ / csteps
         extra["C4_32x1080p_feature_maps_only"] = {"Mpix/s": round(fp / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms / nfr, 5),
                                                    "B/pix": 16, "GB/s": round(16 * fp / (ms * 1e-3) / 1e9, 1),
@@ -240,7 +250,7 @@ def main():
                 hnd.setup(l, flags=cv.SETUP_BASIS)
 
         c3 = max(3, args.steps // 10)
-        w_, e_ = _time_steps(torch, pyr_filter, c3, 2, barrier)
+        w_, e_ = _time_steps(torch, pyr_filter, c3, WARM_NEW, barrier)
         w2_, e2_ = _time_steps(torch, lambda: fp3.pyramid(big, 5), c3, 2, barrier)
         extra["C3_pyramid_8192_5_levels"] = {"filter_Mpix/s": round(ppix / (e_ / c3 * 1e-3) / 1e6, 1), "filter_ms": round(e_ / c3, 4),
                                             "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
