@@ -831,3 +831,38 @@ def test_placement_search_keeps_results_and_state(cv):
     g, h = f.steer(0.3)                                     # later stages read the (possibly moved) state
     g0, h0 = ref.steer(0.3)
     assert torch.equal(g, g0) and torch.equal(h, h0)
+
+
+def test_hip_graph_capture_and_replay(cv):
+    """the engine's launches can be captured into a HIP graph on the caller's stream (no tuning, no allocation, no
+    placement search happens under capture) and replayed on new data in the same buffers"""
+    import torch
+    img = torch.rand((1200, 1600), device="cuda")
+    f = cv.SteerableFiltersG2(None)
+    g, h = torch.empty_like(img), torch.empty_like(img)
+    outs = [torch.empty_like(img) for _ in range(8)]
+
+    def work():
+        f.setup_steer(img, 0.3, out=(g, h))
+        f.pipeline(img, out=outs)
+
+    for _ in range(3):
+        work()                                  # state allocation and order tuning happen here
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        work()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            work()
+    torch.cuda.synchronize()
+    img.copy_(torch.rand((1200, 1600), device="cuda"))      # new frame, same buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [g.clone(), h.clone()] + [o.clone() for o in outs] + [f.basis(p).clone() for p in range(7)]
+    work()
+    torch.cuda.synchronize()
+    want = [g, h] + outs + [f.basis(p) for p in range(7)]
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
