@@ -356,10 +356,16 @@ int search_placement(cvs_handle h, BasisArgs& a, float* scr)
     if (rc == CVS_OK)
         for (int k = 1; k < n; ++k)
             if (best[k] < best[pick] && best[k] < best[0] * 0.96f) pick = k;  // moving must be worth 4 %
+    if (rc == CVS_OK && h->placement == 2 && n > 1) pick = n - 1;  // test mode: always move
     if (std::getenv("CVS_TUNE_VERBOSE")) {
         std::fprintf(stderr, "[cvsteer] placement %dx%d:", a.rows, a.cols);
         for (int k = 0; k < n; ++k) std::fprintf(stderr, " %.4f", best[k]);
         std::fprintf(stderr, " ms -> block %d\n", pick);
+    }
+    // other frames / planes of the old block may hold state this launch does not rewrite: take it along
+    if (pick != 0 && rc == CVS_OK && hipMemcpyAsync(cand[pick], home, bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        pick = 0;
     }
     (void)hipStreamSynchronize(h->stream);
     for (int k = 0; k < n; ++k)
@@ -699,7 +705,7 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
         delete h;
         return CVS_E_NOMEM;
     }
-    if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::atoi(e) != 0;  // default for new handles (A/B tools switch it off)
+    if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::atoi(e) == 2 ? 2 : std::atoi(e) != 0;  // default for new handles (A/B tools switch it off)
     *out = h;
     return CVS_OK;
 }
@@ -766,7 +772,7 @@ int cvs_set_option(cvs_handle h, int option, int value)
             h->wpb = value;
             return CVS_OK;
         case CVS_OPT_PLACEMENT_SEARCH:
-            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "placement search");
+            if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "placement search");
             h->placement = value;
             return CVS_OK;
         case CVS_OPT_XCD_WEIGHTS:

@@ -821,7 +821,7 @@ def test_placement_search_keeps_results_and_state(cv):
     ref.setup(img)
     want = [ref.basis(p).clone() for p in range(7)] + [ref.getDominantOrientationAngle().clone()]
     f = cv.SteerableFiltersG2(None)
-    f.set_option(L.OPT_PLACEMENT_SEARCH, 1)
+    f.set_option(L.OPT_PLACEMENT_SEARCH, 2)                 # 2 = search and always move (1 moves only when it pays)
     for it in range(12):                                    # the search runs on the 8th launch
         f.setup(img)
         if it in (0, 6, 7, 8, 11):
@@ -831,6 +831,19 @@ def test_placement_search_keeps_results_and_state(cv):
     g, h = f.steer(0.3)                                     # later stages read the (possibly moved) state
     g0, h0 = ref.steer(0.3)
     assert torch.equal(g, g0) and torch.equal(h, h0)
+    # frames handled one by one (host planes): the state of the frames before the 8th call must survive a move
+    import numpy as np
+    frames = np.random.default_rng(3).random((10, 1024, 2304), dtype=np.float32)   # 10 x 12 x 9 MiB of state
+    fb = cv.SteerableFiltersG2(None)
+    fb.set_option(L.OPT_PLACEMENT_SEARCH, 2)
+    out = fb.pipeline_batch(frames, outputs=(0,))
+    fr = cv.SteerableFiltersG2(None)
+    fr.set_option(L.OPT_PLACEMENT_SEARCH, 0)
+    for i in (0, 3, 6, 7, 9):
+        fb.select_frame(i)
+        fr.setup(frames[i])
+        assert np.array_equal(fb.basis(2), fr.basis(2)), i
+        assert np.array_equal(fb.getDominantOrientationAngle(), fr.getDominantOrientationAngle()), i
 
 
 def test_hip_graph_capture_and_replay(cv):
