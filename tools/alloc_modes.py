@@ -6,7 +6,8 @@ Measured on MI355X (round 1): on some boxes a few of the allocations run the 9..
 the HBM roofline while the others stay at 67-71 %, for the same kernel, order and image; the 7-plane pass does not
 show it.  Within one big allocation every offset behaves the same; plane-stride padding (256 B .. 192 MiB),
 physically contiguous allocations (hipDeviceMallocContiguous: always the slower mode), power-of-two sizes and
-row-interleaved planes do not move a handle from one mode to the other.  On other boxes no allocation is fast."""
+row-interleaved planes do not move a handle from one mode to the other.  On other boxes no allocation is fast.
+AB_PREALLOC_MB=n occupies the first n MiB of device memory before anything else is allocated."""
 import ctypes as C, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")  # A/B runs compare like with like
@@ -23,6 +24,8 @@ def timeit(fn, steps=10):
 
 n = 4096
 nh = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+pre = int(os.environ.get("AB_PREALLOC_MB", "0"))
+dummy = torch.empty(pre << 20, dtype=torch.uint8, device="cuda") if pre else None   # occupy the first part of device memory
 img = torch.rand((n, n), device="cuda")
 hs, pads = [], []
 for i in range(nh):
