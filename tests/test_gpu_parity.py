@@ -879,3 +879,26 @@ def test_hip_graph_capture_and_replay(cv):
     want = [g, h] + outs + [f.basis(p) for p in range(7)]
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+def test_g4_bank_layouts_never_change_results(cv):
+    """CVS_OPT_G4_SPLIT 0..2 (one 11-plane kernel / two launches / both halves in one launch) x block orders:
+    identical planes and steered outputs, ragged shapes included"""
+    import torch
+    from cvsteer_amd import _lib as L
+    for shape in ((1100, 1500), (301, 449), (64, 257), (2100, 600)):
+        img = torch.rand(shape, device="cuda")
+        ref = None
+        for split in (0, 1, 2):
+            for order in (0, 1, 5, 100000):
+                f = cv.SteerableFiltersG4(None)
+                f.set_option(L.OPT_G4_SPLIT, split)
+                f.set_option(L.OPT_BLOCK_ORDER, order)
+                g, h = f.setup_steer(img, 0.7)
+                cur = [g, h] + [f.basis(p).clone() for p in range(11)]
+                f.setup(img)
+                cur += [f.basis(p).clone() for p in (0, 5, 10)]
+                if ref is None:
+                    ref = cur
+                for a, b in zip(cur, ref):
+                    assert torch.equal(a, b), (shape, split, order)
