@@ -80,9 +80,13 @@ def _cpu_baseline(theta):
     wall = time.perf_counter() - t0
     many = {"value": round(threads * per_thread * 1080 * 1920 / wall / 1e6, 3), "unit": "Mpix/s", "cores": threads,
             "sample": "%d threads x %d x (1080x1920 f32, 7 sepFilter2D + scalar steer), one frame per thread" % (threads, per_thread)}
+    # ... and one image with its rows split over the same number of threads (bands with halo rows)
+    t_mt = min(oracle.time_g2_filter_steer_mt(img, theta, 1, threads) for _ in range(3))
+    banded = {"value": round(ROWS * COLS / t_mt / 1e6, 3), "unit": "Mpix/s", "cores": threads,
+              "sample": "best of 3 x (4096x4096 f32, 7 sepFilter2D + scalar steer), rows split over %d threads" % threads}
     return {
         "value": round(reps * ROWS * COLS / total / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
-        "one_image_per_thread": many,
+        "one_image_per_thread": many, "one_image_row_parallel": banded,
         "sample": "%d x (4096x4096 f32, 7 sepFilter2D + scalar steer), single thread, oracle/ C restatement "
                   "(-O3 -march=native); OpenCV itself is not installed on this image" % reps,
         "host_cpus": os.cpu_count(),

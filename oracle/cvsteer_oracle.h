@@ -59,6 +59,11 @@ int ora_reflect101(int p, int len);
 void ora_sepfilter2d_f32(const float* src, int rows, int cols, size_t src_step_elems,
                          const float* kx, const float* ky, int width, float* dst);
 
+/* rows [y_lo, y_hi) only of the same result (dst is still the whole dense plane): what one thread of the
+ * row-parallel timing leg computes */
+void ora_sepfilter2d_f32_rows(const float* src, int rows, int cols, size_t src_step_elems,
+                              const float* kx, const float* ky, int width, float* dst, int y_lo, int y_hi);
+
 /* same correlation with double accumulation and no intermediate rounding -> double plane.
  * This is the "truth" both the f32 oracle and the GPU are compared against. */
 void ora_sepfilter2d_f64(const float* src, int rows, int cols, size_t src_step_elems,
@@ -114,6 +119,8 @@ void ora_pyr_down(const float* src, int rows, int cols, size_t src_step_elems, f
 /* ---- timing legs for bench.py cpu_baseline (reference call sequence, one thread) ---- */
 /* G2: 7 sepFilter2D + scalar steer (M2).  returns seconds for `reps` repetitions */
 double ora_time_g2_filter_steer(const float* src, int rows, int cols, float theta, int reps);
+/* the same, one image with its rows split over `threads` host threads (bands with halo rows; same values) */
+double ora_time_g2_filter_steer_mt(const float* src, int rows, int cols, float theta, int reps, int threads);
 
 #ifdef __cplusplus
 }

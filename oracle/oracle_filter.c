@@ -42,16 +42,20 @@ static int symmetry(const float* k, int w)
  * [recalled, OpenCV 3.4 filter.cpp] 9/13-tap row kernels take the generic RowFilter
  * (sequential s += k[i]*src[x+i]); (anti)symmetric column kernels take SymmColumnFilter
  * (k0*c + sum k_i*(S[+i] +/- S[-i])); the row buffer is f32. */
-void ora_sepfilter2d_f32(const float* src, int rows, int cols, size_t sstep,
-                         const float* kx, const float* ky, int w, float* dst)
+/* rows [y_lo, y_hi) of the filtered plane: the row pass runs over those rows plus w halo rows either side
+ * (reflected at the image borders), the column pass over the band.  Every output value is computed exactly as by
+ * the whole-image call, which is this with the band = the image. */
+static void sepfilter2d_f32_band(const float* src, int rows, int cols, size_t sstep,
+                                 const float* kx, const float* ky, int w, float* dst, int y_lo, int y_hi)
 {
     int n = 2 * w + 1;
-    float* rowbuf = (float*)malloc((size_t)rows * cols * sizeof(float));
+    int nb = y_hi - y_lo + 2 * w;  /* row-filtered lines kept: source rows y_lo - w .. y_hi + w - 1, reflected */
+    float* rowbuf = (float*)malloc((size_t)nb * cols * sizeof(float));
     int* xi = (int*)malloc((size_t)(cols + 2 * w) * sizeof(int));
     for (int x = -w; x < cols + w; x++) xi[x + w] = ora_reflect101(x, cols);
-    for (int y = 0; y < rows; y++) {
-        const float* s = src + (size_t)y * sstep;
-        float* r = rowbuf + (size_t)y * cols;
+    for (int k = 0; k < nb; k++) {
+        const float* s = src + (size_t)ora_reflect101(y_lo - w + k, rows) * sstep;
+        float* r = rowbuf + (size_t)k * cols;
         for (int x = 0; x < cols; x++) {
             float acc = kx[0] * s[xi[x]];
             for (int i = 1; i < n; i++) acc = acc + kx[i] * s[xi[x + i]];
@@ -59,9 +63,9 @@ void ora_sepfilter2d_f32(const float* src, int rows, int cols, size_t sstep,
         }
     }
     int sy = symmetry(ky, w);
-    for (int y = 0; y < rows; y++) {
+    for (int y = y_lo; y < y_hi; y++) {
         const float* rp[2 * ORA_MAXW + 1];
-        for (int j = -w; j <= w; j++) rp[j + w] = rowbuf + (size_t)ora_reflect101(y + j, rows) * cols;
+        for (int j = -w; j <= w; j++) rp[j + w] = rowbuf + (size_t)(y - y_lo + w + j) * cols;
         float* d = dst + (size_t)y * cols;
         for (int x = 0; x < cols; x++) {
             float acc;
@@ -80,6 +84,18 @@ void ora_sepfilter2d_f32(const float* src, int rows, int cols, size_t sstep,
     }
     free(xi);
     free(rowbuf);
+}
+
+void ora_sepfilter2d_f32(const float* src, int rows, int cols, size_t sstep,
+                         const float* kx, const float* ky, int w, float* dst)
+{
+    sepfilter2d_f32_band(src, rows, cols, sstep, kx, ky, w, dst, 0, rows);
+}
+
+void ora_sepfilter2d_f32_rows(const float* src, int rows, int cols, size_t sstep,
+                              const float* kx, const float* ky, int w, float* dst, int y_lo, int y_hi)
+{
+    sepfilter2d_f32_band(src, rows, cols, sstep, kx, ky, w, dst, y_lo, y_hi);
 }
 
 void ora_sepfilter2d_f64(const float* src, int rows, int cols, size_t sstep,
@@ -552,3 +568,59 @@ double ora_time_g2_filter_steer(const float* src, int rows, int cols, float thet
     free(basis); free(g2); free(h2);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- the same G2 filter + steer sequence with the image rows split over `threads` host threads ---- */
+#include <pthread.h>
+typedef struct {
+    const float* src; int rows, cols; float theta; float* basis; float* g2; float* h2; int y_lo, y_hi;
+    float taps[7][2 * ORA_MAXW + 1];
+} band_job;
+
+static void* band_worker(void* arg)
+{
+    band_job* j = (band_job*)arg;
+    size_t n = (size_t)j->rows * j->cols;
+    for (int p = 0; p < 7; p++) {
+        int a, b;
+        ora_basis_pair(ORA_KIND_G2, p, &a, &b);
+        sepfilter2d_f32_band(j->src, j->rows, j->cols, (size_t)j->cols, j->taps[a], j->taps[b], 4, j->basis + (size_t)p * n, j->y_lo, j->y_hi);
+    }
+    /* steer on the band: planes are dense, so a band is a contiguous range of every plane */
+    size_t off = (size_t)j->y_lo * j->cols, cnt = (size_t)(j->y_hi - j->y_lo) * j->cols;
+    float* bb = (float*)malloc(7 * cnt * sizeof(float));
+    for (int p = 0; p < 7; p++) memcpy(bb + (size_t)p * cnt, j->basis + (size_t)p * n + off, cnt * sizeof(float));
+    ora_g2_steer_scalar(bb, NULL, NULL, NULL, cnt, j->theta, j->g2 + off, j->h2 + off, NULL, NULL, NULL, ORA_ATAN_CV);
+    free(bb);
+    return NULL;
+}
+
+double ora_time_g2_filter_steer_mt(const float* src, int rows, int cols, float theta, int reps, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > rows / 16) threads = rows / 16 > 0 ? rows / 16 : 1;
+    size_t n = (size_t)rows * cols;
+    float* basis = (float*)malloc(7 * n * sizeof(float));
+    float* g2 = (float*)malloc(n * sizeof(float));
+    float* h2 = (float*)malloc(n * sizeof(float));
+    band_job* jobs = (band_job*)malloc((size_t)threads * sizeof(band_job));
+    pthread_t* tid = (pthread_t*)malloc((size_t)threads * sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) {
+        band_job* j = &jobs[t];
+        j->src = src; j->rows = rows; j->cols = cols; j->theta = theta; j->basis = basis; j->g2 = g2; j->h2 = h2;
+        j->y_lo = (int)((long long)rows * t / threads);
+        j->y_hi = (int)((long long)rows * (t + 1) / threads);
+        for (int i = 0; i < 7; i++) ora_make_taps(ORA_KIND_G2, i, 4, 0.67f, j->taps[i]);
+    }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < reps; r++) {
+        for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, band_worker, &jobs[t]);
+        for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    volatile float sink = g2[n / 2] + h2[n / 3];
+    (void)sink;
+    free(tid); free(jobs); free(basis); free(g2); free(h2);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+

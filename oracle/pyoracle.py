@@ -34,6 +34,7 @@ def lib():
         build()
         L = C.CDLL(_SO)
         L.ora_time_g2_filter_steer.restype = C.c_double
+        L.ora_time_g2_filter_steer_mt.restype = C.c_double
         _lib = L
     return _lib
 
@@ -213,9 +214,24 @@ def pyr_down(src):
     return dst
 
 
+def sepfilter2d_f32_rows(src, kx, ky, y_lo, y_hi, dst):
+    """rows [y_lo, y_hi) of sepfilter2d_f32 written into the dense plane dst"""
+    src = _f32(src)
+    kx, ky = _f32(kx), _f32(ky)
+    lib().ora_sepfilter2d_f32_rows(_fp(src), src.shape[0], src.shape[1], C.c_size_t(src.shape[1]), _fp(kx), _fp(ky),
+                                   (kx.size - 1) // 2, _fp(dst), int(y_lo), int(y_hi))
+    return dst
+
+
 def time_g2_filter_steer(src, theta, reps=1):
     src = _f32(src)
     return lib().ora_time_g2_filter_steer(_fp(src), src.shape[0], src.shape[1], C.c_float(theta), reps)
+
+
+def time_g2_filter_steer_mt(src, theta, reps=1, threads=1):
+    """one image, rows split over `threads` host threads"""
+    src = _f32(src)
+    return lib().ora_time_g2_filter_steer_mt(_fp(src), src.shape[0], src.shape[1], C.c_float(theta), reps, int(threads))
 
 
 # ---- caller-side steps of the reference test (test/test.cpp:92-103), numpy only ----

@@ -216,3 +216,17 @@ def test_g4_orientation_extension_is_the_fourier_projection(ora):
     s2 = max(1.0, np.abs(E2).max())
     assert np.abs(2 * (E2 * np.cos(2 * ths)[:, None, None]).mean(0) - k2).max() <= 2e-5 * s2
     assert np.abs(2 * (E2 * np.sin(2 * ths)[:, None, None]).mean(0) - k3).max() <= 2e-5 * s2
+
+
+def test_row_bands_reassemble_the_whole_plane(ora):
+    """the row-parallel CPU baseline filters bands with reflected halo rows: any split gives the whole-image bits"""
+    img = rand_image(53, 70, seed=11)
+    for kx_i, ky_i in ((0, 1), (3, 3), (5, 6)):
+        kx, ky = ora.make_taps(2, kx_i, 4, 0.67), ora.make_taps(2, ky_i, 4, 0.67)
+        whole = ora.sepfilter2d(img, kx, ky)
+        for cuts in ((0, 53), (0, 1, 53), (0, 4, 9, 30, 49, 53), (0, 26, 27, 53)):
+            dst = np.full((53, 70), np.nan, np.float32)
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                ora.sepfilter2d_f32_rows(img, kx, ky, lo, hi, dst)
+            assert np.array_equal(dst, whole), cuts
+    assert ora.time_g2_filter_steer_mt(rand_image(64, 48, seed=2), 0.3, 1, 3) > 0.0
