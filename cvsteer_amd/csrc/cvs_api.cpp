@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -319,13 +320,14 @@ int search_placement(cvs_handle h, BasisArgs& a, float* scr)
     if (bytes < ((size_t)256 << 20)) return CVS_OK;  // the whole state sits in the Infinity Cache: nothing to find
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return CVS_OK;
-    constexpr int kExtra = 8;
+    constexpr int kExtra = 12;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (kExtra + 1) * bytes + ((size_t)4 << 30)) return CVS_OK;
     if (!h->ev0) {
         HIP_TRY(h, hipEventCreate(&h->ev0));
         HIP_TRY(h, hipEventCreate(&h->ev1));
     }
+    const auto t_begin = std::chrono::steady_clock::now();
     float* cand[kExtra + 1] = {h->state};
     int n = 1;
     for (; n <= kExtra; ++n)
@@ -373,6 +375,9 @@ int search_placement(cvs_handle h, BasisArgs& a, float* scr)
     h->state = cand[pick];
     a.basis = h->state + basis_off;
     if (a.orient) a.orient = h->state + orient_off;
+    if (std::getenv("CVS_TUNE_VERBOSE"))
+        std::fprintf(stderr, "[cvsteer] placement search took %.1f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     return rc;
 }
 
