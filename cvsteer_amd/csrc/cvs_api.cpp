@@ -388,9 +388,18 @@ int search_placement(cvs_handle h, BasisArgs& a, float* scr)
 // spread follows the physical placement of the state allocation, tools/alloc_modes.py).  All
 // orders produce identical results, so the first launch of a (variant, shape) times the candidates on the
 // caller's stream and keeps the winner; CVS_OPT_BLOCK_ORDER >= 0 pins an order instead.
+int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input);
+
+// launch configuration for the basis kernel about to run: order / strip height / workgroup width (tuned once per
+// shape), then -- with that configuration -- the placement search (once per state allocation)
 int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
 {
-    if (int rc = search_placement(h, a, scr)) return rc;
+    if (int rc = tune_launch(h, a, scr, variant, fresh_input)) return rc;
+    return search_placement(h, a, scr);
+}
+
+int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input)
+{
     a.wpb = h->wpb > 0 ? h->wpb : 4;
     a.xcd_even = h->xcd_weights ? h->xcd_weights / 100 : 5;
     a.xcd_odd = h->xcd_weights ? h->xcd_weights % 100 : 4;
