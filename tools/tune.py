@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""tools/tune.py -- sweep the basis kernel's launch knobs on the GPU box (strip rows x store policy)."""
+"""tools/tune.py -- sweep the basis kernel's launch knobs on the GPU box (strip rows x store policy).
+A coarse sequential sweep: every configuration is its own handle (its own state allocation -- see
+tools/alloc_modes.py for what that alone can do), so differences under ~15 % need tools/ab.py to confirm."""
 import os, sys, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")  # A/B runs compare like with like
