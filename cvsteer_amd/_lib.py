@@ -9,7 +9,7 @@ OK, E_BADARG, E_SIZE, E_HIP, E_NOMEM, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4
 KIND_G2, KIND_G4 = 2, 4
 MEM_HOST, MEM_DEVICE = 0, 1
 DEPTH_U8 = 0x100
-OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON, OPT_STORE_POLICY, OPT_G4_SPLIT, OPT_G4_EXTENSIONS, OPT_WAVES_PER_GROUP, OPT_BLOCK_ORDER, OPT_PERSIST_STATE = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON, OPT_STORE_POLICY, OPT_G4_SPLIT, OPT_G4_EXTENSIONS, OPT_BLOCK_ORDER, OPT_PERSIST_STATE = 1, 2, 3, 4, 5, 6, 8, 9
 OPT_XCD_WEIGHTS = 10
 OPT_PLACEMENT_SEARCH = 11
 PLANE_BASIS0, PLANE_C1, PLANE_C2, PLANE_C3, PLANE_THETA, PLANE_STRENGTH = 0, 32, 33, 34, 35, 36

@@ -50,7 +50,7 @@ struct cvs_context {
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0, wpb = 0, xcd_weights = 0, placement = 1;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     size_t placed_elems = 0;                  // state allocation (by size) the placement search has looked at
     int same_shape_calls = 0;                 // consecutive basis launches on the current state allocation
@@ -297,9 +297,7 @@ int use_nt_stores(cvs_handle h, size_t npix)
 struct TuneEntry {
     int seen = 0;
     int order = -1;      // -1 = not tuned yet
-    int strip_rows = 0;  // 0 = keep the default
-    int wpb = 4;         // waves per workgroup
-    int xw = 504;        // order 1: tiles per period for even / odd XCDs, 100 * e + o
+    int xw = 403;        // order 1: tiles per period for even / odd XCDs, 100 * e + o
 };
 std::mutex g_tune_mutex;
 std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
@@ -381,17 +379,18 @@ int search_placement(cvs_handle h, BasisArgs& a, float* scr)
     return rc;
 }
 
-// Block order autotune.  The basis kernel can walk its strips row-major, in groups of T bands, or
-// column-major; which one the memory system likes depends on how many planes the variant writes and --
-// measurably -- on the box (tools/ab.py: e.g. the 20-plane pipeline 65 -> 80 % column-major on one box,
-// the 12-plane setup 68 -> 82 % with T = 32 on another, the 7-plane pass always best row-major; part of that
-// spread follows the physical placement of the state allocation, tools/alloc_modes.py).  All
-// orders produce identical results, so the first launch of a (variant, shape) times the candidates on the
-// caller's stream and keeps the winner; CVS_OPT_BLOCK_ORDER >= 0 pins an order instead.
+// Launch-order autotune.  Measured on ONE handle (one state allocation; tools/ab_same.py -- comparisons across
+// handles are confounded by where each state block happens to live, tools/alloc_modes.py): the odd XCDs run the G2
+// kernels ~25 % slower per strip, so dealing the tiles 4:3 (or 5:4) towards the even XCDs (order 1) is worth +2-3 % on
+// every G2 variant; band-group / column-major orders (T >= 2), shorter strips and 8-wave workgroups never win; the
+// G4 pair kernel prefers the plain order (order 1: -7 %).  So G2 starts out with order 1 at 4:3 and G4 with order 0,
+// and the second launch of a (device, kind, variant, shape) times the few alternatives on the caller's stream and
+// keeps a challenger only if it wins by 2 % -- the XCD asymmetry is a property of the box, not of the code.
+// CVS_OPT_BLOCK_ORDER >= 0 pins the order (CVS_OPT_XCD_WEIGHTS the weights) and switches the timing off.
 int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input);
 
-// launch configuration for the basis kernel about to run: order / strip height / workgroup width (tuned once per
-// shape), then -- with that configuration -- the placement search (once per state allocation)
+// launch configuration for the basis kernel about to run: order (tuned once per shape), then -- with that
+// configuration -- the placement search (once per state allocation)
 int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
 {
     if (int rc = tune_launch(h, a, scr, variant, fresh_input)) return rc;
@@ -400,31 +399,28 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
 
 int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input)
 {
-    a.wpb = h->wpb > 0 ? h->wpb : 4;
-    a.xcd_even = h->xcd_weights ? h->xcd_weights / 100 : 5;
-    a.xcd_odd = h->xcd_weights ? h->xcd_weights % 100 : 4;
+    const int xw_pinned = h->xcd_weights;
+    a.xcd_even = xw_pinned ? xw_pinned / 100 : 4;
+    a.xcd_odd = xw_pinned ? xw_pinned % 100 : 3;
     if (h->block_order >= 0) {
         a.block_order = h->block_order;
         return CVS_OK;
     }
-    a.block_order = 0;
-    if (h->wpb > 0) return CVS_OK;  // a pinned workgroup width switches tuning off as well
-    if ((h->kind == CVS_KIND_G4 && h->g4_split != 2) || !basis_fast_path(h->kind, h->width, h->taps) ||
-        (size_t)a.rows * a.cols < ((size_t)1 << 20))
-        return CVS_OK;  // small images, the generic path and the non-default G4 layouts keep the plain grid
-    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->strip_rows > 0 ? 512 : 0) | (h->kind << 12), a.rows, a.cols,
-                                     h->strip_rows > 0 ? h->strip_rows : 0);
+    const bool fast = basis_fast_path(h->kind, h->width, h->taps) && !(h->kind == CVS_KIND_G4 && h->g4_split != 2);
+    const bool big = (size_t)a.rows * a.cols >= ((size_t)1 << 20);
+    // small images, the generic path and the non-default G4 layouts keep the plain grid
+    a.block_order = (fast && big && h->kind == CVS_KIND_G2) ? 1 : 0;
+    if (!fast || !big) return CVS_OK;
+    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->kind << 12), a.rows, a.cols, xw_pinned);
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
         TuneEntry& e = g_tune[key];
         if (e.order >= 0) {
             a.block_order = e.order;
-            a.wpb = e.wpb;
-            if (!h->xcd_weights) { a.xcd_even = e.xw / 100; a.xcd_odd = e.xw % 100; }
-            if (e.strip_rows > 0) a.strip_rows = e.strip_rows;
+            if (!xw_pinned) { a.xcd_even = e.xw / 100; a.xcd_odd = e.xw % 100; }
             return CVS_OK;
         }
-        // a shape seen for the first time runs on the plain grid: one-off images never pay for tuning
+        // a shape seen for the first time runs on the default order: one-off images never pay for tuning
         if (++e.seen < 2) return CVS_OK;
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -433,32 +429,20 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
         HIP_TRY(h, hipEventCreate(&h->ev0));
         HIP_TRY(h, hipEventCreate(&h->ev1));
     }
-    // candidates: {row-major, groups of 32 bands, column-major} at the chosen strip height, plus -- when the
-    // caller did not pin the strip height and the input is being re-filtered (so the timing is representative)
-    // -- row-major with the shortest strips
-    const int sr0 = a.strip_rows;
-    const int bands = (a.rows + sr0 - 1) / sr0;
-    const int sr_short = 2 * (2 * h->width + 1) - 2 * h->width;
-    // ... and row-major with more tiles for the even XCDs (5:4, 4:3), which run this kernel faster than the odd ones
-    struct Cand { int order, strip, wpb, xw; };
-    constexpr int kCand = 8;
+    struct Cand { int order, xw; };
     const int xw0 = a.xcd_even * 100 + a.xcd_odd;
-    Cand cand[kCand] = {{0, sr0, 4, xw0}, {32, sr0, 4, xw0}, {bands, sr0, 4, xw0}, {0, sr_short, 4, xw0},
-                        {0, sr0, 8, xw0}, {32, sr0, 8, xw0}, {1, sr0, 4, 504}, {1, sr0, 4, 403}};
+    // candidate 0 is the default of the kind; a pinned weight pair leaves only "weighted or not" open
+    Cand list[3];
     int ncand = 0;
-    Cand list[kCand];
-    const bool free_strip = !(h->strip_rows > 0 || fresh_input || sr_short == sr0);
-    const bool wide = h->kind == CVS_KIND_G2 && (a.orient != nullptr || a.frames != nullptr);  // 8-wave workgroups exist for these variants
-    for (int ci = 0; ci < kCand; ++ci) {
-        if (ci == 3 && !free_strip) continue;
-        if (cand[ci].wpb == 8 && !wide) continue;
-        if (cand[ci].order == 1 && h->xcd_weights) {  // weights pinned by the caller: one weighted candidate
-            if (ci != 6) continue;
-            cand[ci].xw = xw0;
-        }
-        list[ncand++] = cand[ci];
+    if (h->kind == CVS_KIND_G2) {
+        list[ncand++] = {1, xw0};
+        list[ncand++] = {0, xw0};
+        if (!xw_pinned) list[ncand++] = {1, 504};
+    } else {
+        list[ncand++] = {0, xw0};
+        list[ncand++] = {1, xw0};
     }
-    float tmin[kCand];
+    float tmin[3];
     for (float& t : tmin) t = std::numeric_limits<float>::max();
     // one untimed launch first (first touch of fresh allocations, clock ramp), then the candidates
     // interleaved over several rounds so that drift hits them equally; keep each candidate's fastest run
@@ -466,8 +450,6 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     for (int round = 0; round < 4; ++round) {
         for (int ci = 0; ci < ncand; ++ci) {
             a.block_order = list[ci].order;
-            a.strip_rows = list[ci].strip;
-            a.wpb = list[ci].wpb;
             a.xcd_even = list[ci].xw / 100;
             a.xcd_odd = list[ci].xw % 100;
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -484,20 +466,15 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
         if (tmin[ci] < tmin[best_ci] * 0.98f) best_ci = ci;  // a challenger must win by 2 % to displace the default
     if (std::getenv("CVS_TUNE_VERBOSE")) {
         std::fprintf(stderr, "[cvsteer] tune kind %d variant %d %dx%d:", h->kind, variant, a.rows, a.cols);
-        for (int ci = 0; ci < ncand; ++ci)
-            std::fprintf(stderr, " (order %d, strip %d, wpb %d, xcd %d) %.4f ms", list[ci].order, list[ci].strip, list[ci].wpb, list[ci].xw, tmin[ci]);
-        std::fprintf(stderr, " -> order %d strip %d wpb %d xcd %d\n", list[best_ci].order, list[best_ci].strip, list[best_ci].wpb, list[best_ci].xw);
+        for (int ci = 0; ci < ncand; ++ci) std::fprintf(stderr, " (order %d, xcd %d) %.4f ms", list[ci].order, list[ci].xw, tmin[ci]);
+        std::fprintf(stderr, " -> order %d xcd %d\n", list[best_ci].order, list[best_ci].xw);
     }
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
         g_tune[key].order = list[best_ci].order;
-        g_tune[key].strip_rows = list[best_ci].strip;
-        g_tune[key].wpb = list[best_ci].wpb;
         g_tune[key].xw = list[best_ci].xw;
     }
     a.block_order = list[best_ci].order;
-    a.strip_rows = list[best_ci].strip;
-    a.wpb = list[best_ci].wpb;
     a.xcd_even = list[best_ci].xw / 100;
     a.xcd_odd = list[best_ci].xw % 100;
     return CVS_OK;
@@ -781,10 +758,6 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "persist");
             h->persist = value;
             return CVS_OK;
-        case CVS_OPT_WAVES_PER_GROUP:
-            if (value != 0 && value != 4 && value != 8) return fail(h, CVS_E_BADARG, "waves per group");
-            h->wpb = value;
-            return CVS_OK;
         case CVS_OPT_PLACEMENT_SEARCH:
             if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "placement search");
             h->placement = value;
@@ -813,7 +786,6 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_BLOCK_ORDER: *value = h->block_order; return CVS_OK;
         case CVS_OPT_XCD_WEIGHTS: *value = h->xcd_weights; return CVS_OK;
         case CVS_OPT_PLACEMENT_SEARCH: *value = h->placement; return CVS_OK;
-        case CVS_OPT_WAVES_PER_GROUP: *value = h->wpb; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;
     }

@@ -41,7 +41,6 @@ struct BasisArgs {
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
-    int wpb;              // waves per workgroup: 4 (default) or 8 (orientation / pipeline variants only)
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
     int block_order;      // 0 = row-major grid, 1 = row-major weighted per XCD, T >= 2 = groups of T bands walked column by column
     int xcd_even, xcd_odd; // block_order 1: tiles per period for the even / odd XCDs (see basis_body)

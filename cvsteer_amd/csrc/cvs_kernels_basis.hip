@@ -153,9 +153,8 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 
 // the kernel body: one wave filters one strip.  `line` = this wave's LDS line (64 + 2W + 4 floats),
 // `zframe` = frame index of a batched launch.
-// WPB = waves (adjacent 64-column strips of one row band) per workgroup: 4, or 8 for the variants that write
-// many planes (measured: 12-plane setup 67 -> 83 %, 20-plane pipeline 64 -> 77 % with 8; 7/9-plane variants
-// lose 3-6 points) -- the autotuner in cvs_api.cpp decides per (variant, shape, box).
+// WPB = waves (adjacent 64-column strips of one row band) per workgroup.  Always 4: 8-wave workgroups were built
+// and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones.
 template <class B, int FLAGS, bool STREAM, bool BATCH, bool ONE, int WPB>
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe)
 {
@@ -174,7 +173,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
         // XCD-weighted row-major order.  Workgroup b runs on XCD b % 8 (observed on every launch, tools/xcd_map.py;
         // only speed depends on it), every XCD gets the same number of workgroups, and the XCDs are not equally
         // fast at this kernel: the odd ones need ~25 % longer per strip (tools/k1_timeline.py), so in the plain
-        // order the even ones idle for the last fifth of the launch.  Here the tiles are dealt in periods of
+        // order the even ones idle for the last fifth of the launch (measured on one handle: +2-3 % for every G2 variant).  Here the tiles are dealt in periods of
         // 4 * (ce + co): an even XCD takes ce tiles per period, an odd one co, and the grid is padded with
         // workgroups that find no tile and leave at once.  Period layout: cmin rows of the labels 0..7, then
         // (cmax - cmin) rows of the four labels of the heavier parity.
@@ -528,8 +527,8 @@ bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], 
 // grid of the XCD-weighted order (see basis_body): whole periods, 8 labels x cmax workgroups each
 static unsigned weighted_grid(BasisArgs& a)
 {
-    if (a.xcd_even < 1 || a.xcd_even > 16) a.xcd_even = 5;
-    if (a.xcd_odd < 1 || a.xcd_odd > 16) a.xcd_odd = 4;
+    if (a.xcd_even < 1 || a.xcd_even > 16) a.xcd_even = 4;
+    if (a.xcd_odd < 1 || a.xcd_odd > 16) a.xcd_odd = 3;
     const size_t tiles = (size_t)a.grid_x * a.grid_y, period = 4 * (size_t)(a.xcd_even + a.xcd_odd);
     const int cmax = a.xcd_even > a.xcd_odd ? a.xcd_even : a.xcd_odd;
     return (unsigned)(((tiles + period - 1) / period) * 8 * cmax);
@@ -540,9 +539,8 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
 {
     BasisArgs a = a_in;
     const int strips_x = (a.cols + 63) / 64;
-    // 8-wave workgroups exist for the G2 variants with an orientation / pipeline epilogue
     const bool orient_v = a.orient != nullptr && B::KIND == 2;
-    const int wpb = (a.wpb == 8 && (orient_v || (a.frames && B::KIND == 2))) ? 8 : 4;
+    constexpr int wpb = 4;
     dim3 grid((strips_x + wpb - 1) / wpb, (a.row_hi - a.row_lo + a.strip_rows - 1) / a.strip_rows);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
@@ -567,14 +565,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
             else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, false, WP>), grid, block, 0, s, a, f);             \
         }                                                                                                          \
     } while (0)
-// variants with F_ORIENT come in both workgroup widths (G2 only); the others in the 4-wave form
-#define CVS_LAUNCH_B(FL, BATCHED)                                                     \
-    do {                                                                              \
-        if constexpr (((FL) & F_ORIENT) != 0 && B::KIND == 2) {                       \
-            if (wpb == 8) { CVS_LAUNCH_W(FL, BATCHED, 8); break; }                    \
-        }                                                                             \
-        CVS_LAUNCH_W(FL, BATCHED, 4);                                                 \
-    } while (0)
+#define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 4)
 #define CVS_LAUNCH(FL) CVS_LAUNCH_B(FL, false)
     if (a.frames) {  // batched caller pipeline: one launch, grid.z = frames (G2 only)
         if constexpr (B::KIND == 2 && B::HALF == 0) {

@@ -72,14 +72,12 @@ enum {
     CVS_OPT_G4_EXTENSIONS = 6, /* 0 (default) = G4 exactly as the reference leaves it (no orientation, no e/mag/phase);
                                   1 = EXTENSION beyond the reference: cvs_setup(G4, CVS_SETUP_FULL) fills C1..C3 / theta /
                                   strength from the G4/H4 steering polynomials, and cvs_steer_* accept e/mag/phase */
-    CVS_OPT_WAVES_PER_GROUP = 7, /* basis kernel workgroup width: 0 (default) = autotuned, 4 or 8 waves (8 exists for the G2
-                                    variants with an orientation / pipeline epilogue; pinning it switches tuning off) */
-    CVS_OPT_BLOCK_ORDER = 8, /* order in which the basis kernel walks its strips: -1 (default) = timed once per (kernel
-                                variant, image shape) on first use and cached; 0 = row-major; 1 = row-major with more tiles for the
-                                faster XCDs (CVS_OPT_XCD_WEIGHTS); T >= 2 = groups of T row bands walked column by
+    CVS_OPT_BLOCK_ORDER = 8, /* order in which the basis kernel walks its strips: -1 (default) = the engine's choice (G2: 1,
+                                G4: 0), checked by timing once per (kernel variant, image shape) and cached; 0 = row-major;
+                                1 = row-major with more tiles for the faster XCDs (CVS_OPT_XCD_WEIGHTS); T >= 2 = groups of T row bands walked column by
                                 column (T >= number of bands: column-major).  Results do not depend on it. */
     CVS_OPT_XCD_WEIGHTS = 10, /* block order 1: 100 * e + o = tiles per period for the even / odd XCDs (1..16 each);
-                                 0 (default) = 5:4, or what the autotuner found (tuning) */
+                                 0 (default) = 4:3, or what the autotuner found (tuning) */
     CVS_OPT_PLACEMENT_SEARCH = 11, /* 1 (default): a handle that keeps filtering one shape (state >= 256 MiB) tries a few
                                       state allocations once and keeps the fastest; 0 = never;
                                       2 = always move to the last candidate (for tests) */

@@ -726,17 +726,18 @@ def test_block_order_never_changes_results(cv):
         cv.SteerableFiltersG2(None).set_option(L.OPT_BLOCK_ORDER, -2)
 
 
-def test_workgroup_width_never_changes_results(cv):
-    """CVS_OPT_WAVES_PER_GROUP (4- or 8-wave workgroups, any block order): identical outputs, ragged widths too"""
+def test_xcd_weighted_order_never_changes_results(cv):
+    """block order 1 with any CVS_OPT_XCD_WEIGHTS (tiles dealt unevenly to the XCDs, padded grid): identical outputs for
+    every variant, ragged widths and heights too"""
     import torch
     from cvsteer_amd import _lib as L
-    for shape in ((1100, 1500), (257, 449), (300, 2048 + 64)):
+    for shape in ((1100, 1500), (257, 449), (300, 2048 + 64), (1030, 64)):
         img = torch.rand(shape, device="cuda")
         ref = None
-        for wpb, order in ((4, 0), (8, 0), (4, 1), (8, 1), (8, 5), (8, 100000), (0, -1)):
+        for order, xw in ((0, 0), (1, 0), (1, 504), (1, 302), (1, 405), (1, 116), (1, 1601), (-1, 0)):
             f = cv.SteerableFiltersG2(None)
-            f.set_option(L.OPT_WAVES_PER_GROUP, wpb)
             f.set_option(L.OPT_BLOCK_ORDER, order)
+            f.set_option(L.OPT_XCD_WEIGHTS, xw)
             outs = f.pipeline(img)
             f.setup(img)
             cur = [o.clone() for o in outs] + [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle().clone()]
@@ -748,10 +749,10 @@ def test_workgroup_width_never_changes_results(cv):
             cur += [o.clone() for o in f.pipeline_batch(frames, outputs=(5, 6, 7))]
             if ref is None:
                 ref = cur
-            for a, b in zip(cur, ref):
-                assert torch.equal(a, b), (shape, wpb, order)
+            for a_, b_ in zip(cur, ref):
+                assert torch.equal(a_, b_), (shape, order, xw)
     with pytest.raises(cv.CvsError):
-        cv.SteerableFiltersG2(None).set_option(L.OPT_WAVES_PER_GROUP, 3)
+        cv.SteerableFiltersG2(None).set_option(L.OPT_XCD_WEIGHTS, 1700)
 
 
 def test_planes_beyond_2gib_row_banded(cv):
