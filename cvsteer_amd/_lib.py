@@ -12,6 +12,7 @@ DEPTH_U8 = 0x100
 OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON, OPT_STORE_POLICY, OPT_G4_SPLIT, OPT_G4_EXTENSIONS, OPT_BLOCK_ORDER, OPT_PERSIST_STATE = 1, 2, 3, 4, 5, 6, 8, 9
 OPT_XCD_WEIGHTS = 10
 OPT_PLACEMENT_SEARCH = 11
+OPT_AUTOTUNE = 12
 PLANE_BASIS0, PLANE_C1, PLANE_C2, PLANE_C3, PLANE_THETA, PLANE_STRENGTH = 0, 32, 33, 34, 35, 36
 
 

@@ -50,7 +50,7 @@ struct cvs_context {
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = 2, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 1;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 1, autotune = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     size_t placed_elems = 0;                  // state allocation (by size) the placement search has looked at
     int same_shape_calls = 0;                 // consecutive basis launches on the current state allocation
@@ -297,7 +297,9 @@ int use_nt_stores(cvs_handle h, size_t npix)
 struct TuneEntry {
     int seen = 0;
     int order = -1;      // -1 = not tuned yet
-    int xw = 403;        // order 1: tiles per period for even / odd XCDs, 100 * e + o
+    int xw = 403;
+    int strip_rows = 0;  // 0 = the default height
+    int g4_split = 2;        // order 1: tiles per period for even / odd XCDs, 100 * e + o
 };
 std::mutex g_tune_mutex;
 std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
@@ -402,25 +404,32 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     const int xw_pinned = h->xcd_weights;
     a.xcd_even = xw_pinned ? xw_pinned / 100 : 4;
     a.xcd_odd = xw_pinned ? xw_pinned % 100 : 3;
-    if (h->block_order >= 0) {
-        a.block_order = h->block_order;
-        return CVS_OK;
-    }
-    const bool fast = basis_fast_path(h->kind, h->width, h->taps) && !(h->kind == CVS_KIND_G4 && h->g4_split != 2);
+    a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
+    const bool fast = basis_fast_path(h->kind, h->width, h->taps);
     const bool big = (size_t)a.rows * a.cols >= ((size_t)1 << 20);
-    // small images, the generic path and the non-default G4 layouts keep the plain grid
-    a.block_order = (fast && big && h->kind == CVS_KIND_G2) ? 1 : 0;
+    if (h->block_order >= 0) a.block_order = h->block_order;
+    else a.block_order = (fast && big && h->kind == CVS_KIND_G2) ? 1 : 0;
+    // small images and the generic path keep the plain configuration
     if (!fast || !big) return CVS_OK;
-    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->kind << 12), a.rows, a.cols, xw_pinned);
+    // what is still open: the order (unless pinned), the strip height (unless pinned or the input stream is fresh
+    // images, where short strips are a must), the G4 bank layout (unless pinned)
+    const bool free_order = h->block_order < 0;
+    const bool free_strip = h->strip_rows <= 0 && !fresh_input && !a.frames;
+    const bool free_split = h->kind == CVS_KIND_G4 && h->g4_split < 0;
+    if (!h->autotune || (!free_order && !free_strip && !free_split)) return CVS_OK;
+    const int pins = (h->block_order + 1) * 4 + (h->strip_rows > 0 ? 2 : 0) + (h->g4_split >= 0 ? 1 : 0);
+    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->kind << 12) | (pins << 16), a.rows, a.cols, xw_pinned);
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
         TuneEntry& e = g_tune[key];
         if (e.order >= 0) {
             a.block_order = e.order;
             if (!xw_pinned) { a.xcd_even = e.xw / 100; a.xcd_odd = e.xw % 100; }
+            if (e.strip_rows > 0) a.strip_rows = e.strip_rows;
+            a.g4_split = e.g4_split;
             return CVS_OK;
         }
-        // a shape seen for the first time runs on the default order: one-off images never pay for tuning
+        // a shape seen for the first time runs on the defaults: one-off images never pay for tuning
         if (++e.seen < 2) return CVS_OK;
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -429,29 +438,36 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
         HIP_TRY(h, hipEventCreate(&h->ev0));
         HIP_TRY(h, hipEventCreate(&h->ev1));
     }
-    struct Cand { int order, xw; };
-    const int xw0 = a.xcd_even * 100 + a.xcd_odd;
-    // candidate 0 is the default of the kind; a pinned weight pair leaves only "weighted or not" open
-    Cand list[3];
+    struct Cand { int order, xw, strip, split; };
+    const int xw0 = a.xcd_even * 100 + a.xcd_odd, sr0 = a.strip_rows, sp0 = a.g4_split, o0 = a.block_order;
+    const int sr_short = 2 * (2 * h->width + 1) - 2 * h->width;
+    // candidate 0 is the default; the others change one thing each (measured alternatives, see above)
+    Cand list[6];
     int ncand = 0;
+    list[ncand++] = {o0, xw0, sr0, sp0};
     if (h->kind == CVS_KIND_G2) {
-        list[ncand++] = {1, xw0};
-        list[ncand++] = {0, xw0};
-        if (!xw_pinned) list[ncand++] = {1, 504};
+        if (free_order) list[ncand++] = {0, xw0, sr0, sp0};
+        if (free_order && !xw_pinned) list[ncand++] = {1, 504, sr0, sp0};
+        if (free_strip && sr_short != sr0) list[ncand++] = {o0, xw0, sr_short, sp0};  // with the weighted order 10-row strips win the 7/9-plane passes
     } else {
-        list[ncand++] = {0, xw0};
-        list[ncand++] = {1, xw0};
+        if (free_order) list[ncand++] = {1, xw0, sr0, sp0};
+        if (free_split) list[ncand++] = {o0, xw0, sr0, 0};  // one 11-plane kernel instead of the two half banks
     }
-    float tmin[3];
+    float tmin[6];
     for (float& t : tmin) t = std::numeric_limits<float>::max();
+    auto apply = [&](const Cand& c) {
+        a.block_order = c.order;
+        a.xcd_even = c.xw / 100;
+        a.xcd_odd = c.xw % 100;
+        a.strip_rows = c.strip;
+        a.g4_split = c.split;
+    };
     // one untimed launch first (first touch of fresh allocations, clock ramp), then the candidates
     // interleaved over several rounds so that drift hits them equally; keep each candidate's fastest run
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
     for (int round = 0; round < 4; ++round) {
         for (int ci = 0; ci < ncand; ++ci) {
-            a.block_order = list[ci].order;
-            a.xcd_even = list[ci].xw / 100;
-            a.xcd_odd = list[ci].xw % 100;
+            apply(list[ci]);
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
             HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
             HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -466,17 +482,19 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
         if (tmin[ci] < tmin[best_ci] * 0.98f) best_ci = ci;  // a challenger must win by 2 % to displace the default
     if (std::getenv("CVS_TUNE_VERBOSE")) {
         std::fprintf(stderr, "[cvsteer] tune kind %d variant %d %dx%d:", h->kind, variant, a.rows, a.cols);
-        for (int ci = 0; ci < ncand; ++ci) std::fprintf(stderr, " (order %d, xcd %d) %.4f ms", list[ci].order, list[ci].xw, tmin[ci]);
-        std::fprintf(stderr, " -> order %d xcd %d\n", list[best_ci].order, list[best_ci].xw);
+        for (int ci = 0; ci < ncand; ++ci)
+            std::fprintf(stderr, " (order %d, xcd %d, strip %d, split %d) %.4f ms", list[ci].order, list[ci].xw, list[ci].strip, list[ci].split, tmin[ci]);
+        std::fprintf(stderr, " -> candidate %d\n", best_ci);
     }
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
-        g_tune[key].order = list[best_ci].order;
-        g_tune[key].xw = list[best_ci].xw;
+        TuneEntry& e = g_tune[key];
+        e.order = list[best_ci].order;
+        e.xw = list[best_ci].xw;
+        e.strip_rows = list[best_ci].strip;
+        e.g4_split = list[best_ci].split;
     }
-    a.block_order = list[best_ci].order;
-    a.xcd_even = list[best_ci].xw / 100;
-    a.xcd_odd = list[best_ci].xw % 100;
+    apply(list[best_ci]);
     return CVS_OK;
 }
 
@@ -537,7 +555,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     h->last_image = image->data;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols, fresh);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
-    a.g4_split = h->g4_split;
+    a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
     a.diag = h->diag;
     if (steer) {
         PlaneRef rg, rh;
@@ -696,6 +714,7 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
         delete h;
         return CVS_E_NOMEM;
     }
+    if (const char* e = std::getenv("CVS_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::atoi(e) == 2 ? 2 : std::atoi(e) != 0;  // default for new handles (A/B tools switch it off)
     *out = h;
     return CVS_OK;
@@ -747,7 +766,7 @@ int cvs_set_option(cvs_handle h, int option, int value)
             h->store_policy = value;
             return CVS_OK;
         case CVS_OPT_G4_SPLIT:
-            if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "g4 split");
+            if (value < -1 || value > 2) return fail(h, CVS_E_BADARG, "g4 split");
             h->g4_split = value;
             return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS:
@@ -757,6 +776,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
         case CVS_OPT_PERSIST_STATE:
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "persist");
             h->persist = value;
+            return CVS_OK;
+        case CVS_OPT_AUTOTUNE:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "autotune");
+            h->autotune = value;
             return CVS_OK;
         case CVS_OPT_PLACEMENT_SEARCH:
             if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "placement search");
@@ -786,6 +809,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_BLOCK_ORDER: *value = h->block_order; return CVS_OK;
         case CVS_OPT_XCD_WEIGHTS: *value = h->xcd_weights; return CVS_OK;
         case CVS_OPT_PLACEMENT_SEARCH: *value = h->placement; return CVS_OK;
+        case CVS_OPT_AUTOTUNE: *value = h->autotune; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;
     }
@@ -1077,7 +1101,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.no_state = h->persist ? 0 : 1;
     a.find_on_e = h->find_on;
     a.frames = h->frame_tab;
-    a.g4_split = h->g4_split;
+    a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
     a.batch = n;
     a.frame_stride = h->frame_stride;
     if ((rc = tune_block_order(h, a, nullptr, 16 | 1 | 4 | (a.no_state ? 8 : 0)))) return rc;

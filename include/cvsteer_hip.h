@@ -78,11 +78,13 @@ enum {
                                 column (T >= number of bands: column-major).  Results do not depend on it. */
     CVS_OPT_XCD_WEIGHTS = 10, /* block order 1: 100 * e + o = tiles per period for the even / odd XCDs (1..16 each);
                                  0 (default) = 4:3, or what the autotuner found (tuning) */
+    CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the second launch of a shape times a few launch configurations and caches the
+                                winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
     CVS_OPT_PLACEMENT_SEARCH = 11, /* 1 (default): a handle that keeps filtering one shape (state >= 256 MiB) tries a few
                                       state allocations once and keeps the fastest; 0 = never;
                                       2 = always move to the last candidate (for tests) */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
-                                launch (blockIdx.z picks the half) */
+                                launch (blockIdx.z picks the half); -1 (default) = 2, or 0 where the autotuner finds it faster */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
                                 256 MiB Infinity Cache), 1 = plain, 2 = always nontemporal (tuning) */
 };

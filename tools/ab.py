@@ -2,7 +2,7 @@
 """tools/ab.py -- interleaved A/B rounds in ONE process (cdna guide rule 24): option values x legs."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")  # A/B runs compare like with like
+import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0"); _os.environ.setdefault("CVS_AUTOTUNE", "0")  # A/B runs compare like with like
 import torch
 import cvsteer_amd as cv
 from cvsteer_amd import _lib as L

@@ -3,7 +3,7 @@
 (CVS_OPT_G4_SPLIT = 0 / 1 / 2) x strip rows, interleaved rounds in one process."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")  # A/B runs compare like with like
+import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0"); _os.environ.setdefault("CVS_AUTOTUNE", "0")  # A/B runs compare like with like
 import torch
 import cvsteer_amd as cv
 from cvsteer_amd import _lib as L

@@ -2,7 +2,7 @@
 """tools/ab_rot.py -- M2 with rotating inputs (input read from HBM, not the Infinity Cache) vs strip rows."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")  # A/B runs compare like with like
+import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0"); _os.environ.setdefault("CVS_AUTOTUNE", "0")  # A/B runs compare like with like
 import torch
 import cvsteer_amd as cv
 from cvsteer_amd import _lib as L

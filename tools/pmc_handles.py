@@ -4,6 +4,7 @@ state allocation, 5 launches of the 12-plane setup per handle, handle after hand
 WITHOUT meaning under the profiler; the point is whether HBM traffic differs from allocation to allocation."""
 import os, sys
 os.environ["CVS_PLACEMENT_SEARCH"] = "0"
+os.environ["CVS_AUTOTUNE"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cvsteer_amd as cv

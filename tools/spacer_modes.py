@@ -4,6 +4,7 @@ shares a launch with decide the speed?  For each spacer size: allocate the space
 spacer; time M1 / M2 / M4 / M5 interleaved over all handles."""
 import os, sys, statistics
 os.environ["CVS_PLACEMENT_SEARCH"] = "0"
+os.environ["CVS_AUTOTUNE"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cvsteer_amd as cv

@@ -4,7 +4,7 @@ A coarse sequential sweep: every configuration is its own handle (its own state 
 tools/alloc_modes.py for what that alone can do), so differences under ~15 % need tools/ab.py to confirm."""
 import os, sys, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")  # A/B runs compare like with like
+import os as _os; _os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0"); _os.environ.setdefault("CVS_AUTOTUNE", "0")  # A/B runs compare like with like
 import torch
 import cvsteer_amd as cv
 from cvsteer_amd import _lib as L
