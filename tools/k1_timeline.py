@@ -13,12 +13,12 @@ from cvsteer_amd import _lib as L
 n = 4096
 sr = int(sys.argv[1]) if len(sys.argv) > 1 else 19
 order = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-tall = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+xw = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 img = torch.rand((n, n), device="cuda")
 f = cv.SteerableFiltersG2(None)
 f.set_strip_rows(sr)
 f.set_option(L.OPT_BLOCK_ORDER, order)
-f.set_option(L.OPT_TALL_ROWS, tall)
+f.set_option(L.OPT_XCD_WEIGHTS, xw)
 lib = cv.lib()
 lib.cvs_diag_set_buffer.argtypes = [C.c_void_p, C.c_void_p]
 bands = (n + sr - 1) // sr
@@ -49,12 +49,8 @@ for flags, name in ((cv.SETUP_BASIS, "M1 basis"), (cv.SETUP_FULL, "M4 full")):
     print("   resident waves per 5%% slice : " + " ".join("%4.0f" % o for o in occ))
     print("   of which past priming       : " + " ".join("%4.0f" % o for o in sto))
     # workgroup w = by * 16 + bx lands on XCD w % 8 (round-robin dispatch): does every XCD finish at the same time?
-    if order == 1:
-        xcd = xcc                                        # stamped from HW_REG_XCC_ID
-        print("   strips per XCD     : " + " ".join("%5d" % (xcd == k).sum() for k in range(8)))
-    else:
-        xcd = xcc                                        # stamped from HW_REG_XCC_ID
-        print("   strips per XCD     : " + " ".join("%5d" % (xcd == k).sum() for k in range(8)))
+    xcd = xcc                                            # stamped from HW_REG_XCC_ID
+    print("   strips per XCD     : " + " ".join("%5d" % (xcd == k).sum() for k in range(8)))
     colblk = (np.arange(nwaves) % 64 // 4)[used]         # 256-column block of the strip
     life = end - start
     print("   mean life by column block: " + " ".join("%4.1f" % life[colblk == k].mean() for k in range(16)))
