@@ -448,7 +448,9 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     if (h->kind == CVS_KIND_G2) {
         if (free_order) list[ncand++] = {0, xw0, sr0, sp0};
         if (free_order && !xw_pinned) list[ncand++] = {1, 504, sr0, sp0};
-        if (free_strip && sr_short != sr0) list[ncand++] = {o0, xw0, sr_short, sp0};  // with the weighted order 10-row strips win the 7/9-plane passes
+        // with the weighted order 10-row strips win the 7/9-plane passes, and 5:4 suits them a little better than 4:3
+        if (free_strip && sr_short != sr0) list[ncand++] = {o0, xw0, sr_short, sp0};
+        if (free_strip && sr_short != sr0 && free_order && !xw_pinned) list[ncand++] = {1, 504, sr_short, sp0};
     } else {
         if (free_order) list[ncand++] = {1, xw0, sr0, sp0};
         if (free_split) list[ncand++] = {o0, xw0, sr0, 0};  // one 11-plane kernel instead of the two half banks
