@@ -408,7 +408,11 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     const bool fast = basis_fast_path(h->kind, h->width, h->taps);
     const bool big = (size_t)a.rows * a.cols >= ((size_t)1 << 20);
     if (h->block_order >= 0) a.block_order = h->block_order;
-    else a.block_order = (fast && big && h->kind == CVS_KIND_G2) ? 1 : 0;
+    else {
+        // launches of 32 Mpix and more are long enough for the plain order (8192^2, one handle: M1 80.7 vs 80.2 %, M4 87.0 vs 80.5 %)
+        const bool huge = (size_t)a.rows * a.cols * (a.frames ? (size_t)a.batch : 1) >= ((size_t)32 << 20);
+        a.block_order = (fast && big && !huge && h->kind == CVS_KIND_G2) ? 1 : 0;
+    }
     // small images and the generic path keep the plain configuration
     if (!fast || !big) return CVS_OK;
     // what is still open: the order (unless pinned), the strip height (unless pinned or the input stream is fresh
@@ -446,7 +450,7 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     int ncand = 0;
     list[ncand++] = {o0, xw0, sr0, sp0};
     if (h->kind == CVS_KIND_G2) {
-        if (free_order) list[ncand++] = {0, xw0, sr0, sp0};
+        if (free_order) list[ncand++] = {o0 ? 0 : 1, xw0, sr0, sp0};  // the other order
         if (free_order && !xw_pinned) list[ncand++] = {1, 504, sr0, sp0};
         // with the weighted order 10-row strips win the 7/9-plane passes, and 5:4 suits them a little better than 4:3
         if (free_strip && sr_short != sr0) list[ncand++] = {o0, xw0, sr_short, sp0};
