@@ -52,8 +52,10 @@ struct cvs_context {
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
     int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 1, autotune = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
-    size_t placed_elems = 0;                  // state allocation (by size) the placement search has looked at
-    int same_shape_calls = 0;                 // consecutive basis launches on the current state allocation
+    // placement search bookkeeping, per kernel variant (a block that is fast for one variant need not be for another):
+    // launches of the variant on the current state allocation, and whether the search has run for it
+    int variant_calls[32] = {};
+    bool variant_placed[32] = {};
     std::string err;
 };
 
@@ -245,8 +247,8 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
         }
         HIP_TRY(h, hipMalloc(&h->state, elems * sizeof(float)));
         h->state_elems = elems;
-        h->same_shape_calls = 0;
-        h->placed_elems = 0;
+        std::memset(h->variant_calls, 0, sizeof(h->variant_calls));
+        std::memset(h->variant_placed, 0, sizeof(h->variant_placed));
     }
     h->rows = rows;
     h->cols = cols;
@@ -310,12 +312,14 @@ std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
 // other (tools/alloc_modes.py).  What does work is taking another block: a handle that keeps filtering
 // the same shape allocates a few candidate state blocks once, times the launch it is about to make on each,
 // keeps the fastest and frees the rest.  Results do not depend on it; it costs a few tens of milliseconds, so it
-// waits until the handle has filtered the shape a few times, and it needs the spare memory to exist.
-int search_placement(cvs_handle h, BasisArgs& a, float* scr)
+// waits until the handle has run a kernel variant on the shape a few times (once per variant: a block that is fast
+// for the 9-plane launch need not be for the 20-plane one), and it needs the spare memory to exist.
+int search_placement(cvs_handle h, BasisArgs& a, float* scr, int variant)
 {
-    if (!h->placement || h->placed_elems == h->state_elems || a.no_state) return CVS_OK;
-    if (++h->same_shape_calls < 8) return CVS_OK;
-    h->placed_elems = h->state_elems;
+    variant &= 31;
+    if (!h->placement || h->variant_placed[variant] || a.no_state) return CVS_OK;
+    if (++h->variant_calls[variant] < 8) return CVS_OK;
+    h->variant_placed[variant] = true;
     const size_t bytes = h->state_elems * sizeof(float);
     if (bytes < ((size_t)256 << 20)) return CVS_OK;  // the whole state sits in the Infinity Cache: nothing to find
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -396,7 +400,7 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
 int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
 {
     if (int rc = tune_launch(h, a, scr, variant, fresh_input)) return rc;
-    return search_placement(h, a, scr);
+    return search_placement(h, a, scr, variant);
 }
 
 int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input)
