@@ -26,6 +26,8 @@ g4 = os.environ.get("AB_KIND", "2") == "4"
 img = torch.rand((n, n), device="cuda")
 g, h = torch.empty_like(img), torch.empty_like(img)
 outs = [torch.empty_like(img) for _ in range(8)]
+imgs8 = [img] + [torch.rand((n, n), device="cuda") for _ in range(7)] if os.environ.get("AB_ROT") else None
+rot = {"i": 0}
 for hi in range(int(os.environ.get("AB_HANDLES", "2"))):
     f = cv.SteerableFiltersG4(None) if g4 else cv.SteerableFiltersG2(None)
     def apply(v):
@@ -34,6 +36,14 @@ for hi in range(int(os.environ.get("AB_HANDLES", "2"))):
     legs = {"M6 basis": (lambda: f.setup(img), 48), "M6 +steer": (lambda: f.setup_steer(img, 0.3, out=(g, h)), 56)} if g4 else {
         "M1 basis": (lambda: f.setup(img, flags=cv.SETUP_BASIS), 32), "M2 +steer": (lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h)), 40),
         "M4 full": (lambda: f.setup(img, flags=cv.SETUP_FULL), 52), "M5 pipeline": (lambda: f.pipeline(img, out=outs), 84)}
+    if imgs8 and not g4:   # AB_ROT=1: every launch filters a different image (inputs come from HBM, not the Infinity Cache)
+        def step_rot():
+            rot["i"] = (rot["i"] + 1) & 7
+            f.setup_steer(imgs8[rot["i"]], 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        def step_rot1():
+            rot["i"] = (rot["i"] + 1) & 7
+            f.setup(imgs8[rot["i"]], flags=cv.SETUP_BASIS)
+        legs = {"M1 rotating": (step_rot1, 32), "M2 rotating": (step_rot, 40)}
     print("handle %d" % hi)
     for name, (fn, bpp) in legs.items():
         res = {v: [] for v in specs}
