@@ -109,11 +109,19 @@ def main():
     ws, rank, local_rank = _dist_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # CVS_BENCH_TEST_BACKEND=gloo: exercise the N > 1 code path on a box with ONE GPU (every rank on device 0, the
+    # two scalars of the MAX reduction go through host memory).  Testing only -- the driver's runs use RCCL.
+    test_backend = os.environ.get("CVS_BENCH_TEST_BACKEND", "")
+    if test_backend:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if ws > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if test_backend:
+            dist.init_process_group(test_backend)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -142,7 +150,7 @@ def main():
     torch.cuda.synchronize()
     wall, ev_ms = _time_steps(torch, step, args.steps, args.warmup, barrier)
     if dist is not None:
-        t = torch.tensor([wall, ev_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall, ev_ms], device="cpu" if test_backend else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(t[0]), float(t[1])
     value = ws * args.steps * npix / wall / 1e6
