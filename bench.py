@@ -205,6 +205,44 @@ def main():
 
         leg("M2_rotating_8_inputs", step_rot, BYTES_PER_PIX["M2"])
         del imgs8
+        # throughput mode: consecutive images go to two handles on two HIP streams, so the tail of one launch overlaps
+        # the start-up of the next (tools/two_streams.py)
+        f2 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+        img2 = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)
+        g2_, h2_ = torch.empty_like(img), torch.empty_like(img)
+        side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        pair = [(f, img, (g, h)), (f2, img2, (g2_, h2_))]
+        flip = {"i": 0}
+
+        def step_two():
+            flip["i"] ^= 1
+            fi, im, oo = pair[flip["i"]]
+            with torch.cuda.stream(side[flip["i"]]):
+                fi.setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=oo)
+
+        def timed_two(k):
+            main = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            for st in side:
+                st.wait_event(e0)
+            for _ in range(k):
+                step_two()
+            for st in side:
+                main.wait_stream(st)
+            e1.record(main)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / k
+
+        timed_two(2 * WARM_NEW)
+        barrier()
+        ms2 = timed_two(ksteps)
+        extra["M2_two_streams_two_images"] = {"Mpix/s": round(npix / (ms2 * 1e-3) / 1e6, 1), "ms": round(ms2, 5),
+                                              "frac_hbm": round(BYTES_PER_PIX["M2"] * npix / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": 40,
+                                              "note": "alternating images on two handles / two streams; not the headline configuration"}
+        torch.cuda.current_stream().synchronize()
+        f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))  # back on the main stream
+        del f2, img2, g2_, h2_
         leg("M1_basis_only", lambda: f.setup(img, flags=cv.SETUP_BASIS), BYTES_PER_PIX["M1"])
         leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"])
         outs8 = [torch.empty_like(img) for _ in range(8)]
