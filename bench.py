@@ -11,10 +11,15 @@ SteerableFiltersG2.cpp:62-68) + steer(theta=0.3) (G2.cpp:137-145), as ONE fused 
 written = 40 algorithmic bytes per pixel (SURVEY.md 8(d) "M2").
 
 Multi-GPU: the image/batch axis shards with no data-path collective -- every rank filters its
-own images (weak scaling); RCCL is used for the barrier and the max-over-ranks reduction only.
+own images (weak scaling); RCCL is used for the barrier and the max-over-ranks reduction, and in
+the `C4_e2e` leg for the scatter of frames from rank 0 and the gather of results to it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+        N > 1 without WORLD_SIZE in the environment: this process starts N rank processes
+        (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE touching the GPU, waits for them and
+        exits with their status; rank 0 prints the JSON line.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        the launcher provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; --gpus must equal WORLD_SIZE.
 """
 import argparse
 import json
@@ -29,11 +34,63 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ROWS = COLS = 4096
 THETA = 0.3
 BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56}
+# calls on a new handle before a timed region: the engine times a few launch orders on the SECOND call with a
+# shape (bounded: ~20 launches, cached process-wide).  Nothing else is deferred -- the
+# placement search of round 1 is opt-in now and off here.  `M2_untuned` / `M2_first_call` report the legs without it.
+INIT_CALLS = 3
 
 
 def _dist_env():
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     return ws, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _spawn_ranks(n):
+    """--gpus N without a launcher: start N rank processes of this script, one per GPU.  This parent makes no
+    GPU call (it does not even import torch); it waits, forwards rank 0's stdout (inherited) and returns the
+    first non-zero exit status, ending the other ranks (the exact PIDs it started) if one fails."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"WORLD_SIZE": str(n), "RANK": str(r), "LOCAL_RANK": str(r), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "CVS_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+        # rank 0 owns stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.1)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("bench.py: rank process %d exited with status %d; stopping the others" % (p.pid, code), file=sys.stderr)
+                    for q in live:
+                        q.send_signal(signal.SIGTERM)
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.send_signal(signal.SIGTERM)
+        rc = 130
+    for q in procs:
+        try:
+            q.wait(timeout=30)
+        except Exception:
+            q.kill()
+    return rc
 
 
 def _time_steps(torch, fn, steps, warmup, barrier):
@@ -70,7 +127,6 @@ def _cpu_baseline(theta):
     # the example's own model of parallelism (example/steer.cpp:169): one image per thread, all cores.
     # Bounded: at most 64 threads, one 1920x1080 frame each, repeated for ~2-5 s of wall time.
     from concurrent.futures import ThreadPoolExecutor
-    import time
     threads = max(1, min(os.cpu_count() or 1, 64))
     frame = np.random.default_rng(99).random((1080, 1920), dtype=np.float32)
     per_thread = 12
@@ -98,36 +154,60 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (M1/M4/M5/G4)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (M1/M4/M5/G4/C3/C4)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--strip-rows", type=int, default=0)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args.gpus))   # before torch is imported: the parent never touches the GPU
+
+    ws, rank, local_rank = _dist_env()
+    if ws != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- start it as `python bench.py --gpus N` or as "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, ws))
 
     import torch
     import cvsteer_amd as cv
+    from cvsteer_amd import _lib as L
+    from cvsteer_amd import batch
 
-    ws, rank, local_rank = _dist_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    # CVS_BENCH_TEST_BACKEND=gloo: exercise the N > 1 code path on a box with ONE GPU (every rank on device 0, the
-    # two scalars of the MAX reduction go through host memory).  Testing only -- the driver's runs use RCCL.
+    # CVS_BENCH_TEST_BACKEND=gloo: rehearse the N > 1 code path on a box with ONE GPU (every rank on device 0,
+    # collectives through host memory).  Testing only -- real runs use RCCL, one rank per GPU.
     test_backend = os.environ.get("CVS_BENCH_TEST_BACKEND", "")
     if test_backend:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible (one rank per GPU; "
+                         "CVS_BENCH_TEST_BACKEND=gloo rehearses N ranks on one GPU)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
+    backend = "none"
     if ws > 1:
         import torch.distributed as dist
+        backend = test_backend or "nccl"
         if test_backend:
             dist.init_process_group(test_backend)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        assert dist.get_world_size() == ws == args.gpus
+    cdev = "cpu" if test_backend else dev    # where collective payloads live
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    dev = torch.device("cuda", local_rank)
+    def max_over_ranks(*vals):
+        if dist is None:
+            return vals
+        t = torch.tensor(vals, device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return tuple(float(v) for v in t)
+
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)  # i.i.d. uniform [0,1)
     f = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
@@ -141,27 +221,21 @@ def main():
     def step():
         f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
 
-    # engine initialisation, before the contract's W warm-ups: a handle times its launch orders on the 2nd call with
-    # a shape and may move its state block on the 8th (one-time, tens of milliseconds) -- a
-    # short --warmup must not push that into the timed region
-    INIT_CALLS = 10
     for _ in range(INIT_CALLS):
         step()
     torch.cuda.synchronize()
     wall, ev_ms = _time_steps(torch, step, args.steps, args.warmup, barrier)
-    if dist is not None:
-        t = torch.tensor([wall, ev_ms], device="cpu" if test_backend else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(t[0]), float(t[1])
+    wall, ev_ms = max_over_ranks(wall, ev_ms)
     value = ws * args.steps * npix / wall / 1e6
     k_ms = ev_ms / args.steps  # average launch-to-launch duration of the single kernel, HIP events
     achieved = BYTES_PER_PIX["M2"] * npix / (k_ms * 1e-3) / 1e9
 
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("k_basis_g2_steer_4096", {}).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/traffic.json (replayed from the committed rocprofv3 --pmc passes of this kernel; not measured in this run)"
         except Exception:
             traffic = None
 
@@ -172,9 +246,10 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "G2+H2 7-basis separable pass + scalar steer (theta=0.3), one 4096x4096 f32 image "
                                "per GPU per step, image resident in HBM, bases persisted (BASELINE configs[1])",
-                   "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective", "init_calls": INIT_CALLS},
+                   "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective",
+                   "init_calls": INIT_CALLS, "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "cvs::k_basis<BankG2, F_STEER>", "algorithmic_bytes_per_launch": BYTES_PER_PIX["M2"] * npix,
                      "avg_launch_ms": round(k_ms, 5)},
     }
@@ -183,16 +258,15 @@ def main():
     if not args.no_extra:
         extra = {}
         ksteps, kwarm = args.steps, max(10, args.warmup // 2)
-        # a handle tunes its launch order on the 2nd call with a shape and may move its state on the 8th:
-        # every leg warms up long enough for both to happen outside its timed region
-        WARM_NEW = 10
+        WARM_NEW = 6   # a new handle / new shape: first call + the one tuning call happen in here
 
-        def leg(name, fn, bpp, pix=npix):
-            w_, e_ = _time_steps(torch, fn, ksteps, kwarm, barrier)
-            ms = e_ / ksteps
-            extra[name] = {"Mpix/s": round(pix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5),
-                           "GB/s": round(bpp * pix / (ms * 1e-3) / 1e9, 1),
-                           "frac_hbm": round(bpp * pix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": bpp}
+        def rate(ms, bpp, pix):
+            return {"Mpix/s": round(pix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5), "GB/s": round(bpp * pix / (ms * 1e-3) / 1e9, 1),
+                    "frac_hbm": round(bpp * pix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": bpp}
+
+        def leg(name, fn, bpp, pix=npix, steps=None, warm=None):
+            w_, e_ = _time_steps(torch, fn, steps or ksteps, kwarm if warm is None else warm, barrier)
+            extra[name] = rate(e_ / (steps or ksteps), bpp, pix)
 
         # the headline loop re-filters ONE 64 MiB image, which can stay resident in the 256 MiB Infinity Cache
         # between steps; this leg rotates 8 distinct images (512 MiB) so every input read comes from HBM
@@ -204,121 +278,207 @@ def main():
             f.setup_steer(imgs8[rot["i"]], THETA, flags=cv.SETUP_BASIS, out=(g, h))
 
         leg("M2_rotating_8_inputs", step_rot, BYTES_PER_PIX["M2"])
-        del imgs8
-        # throughput mode: consecutive images go to two handles on two HIP streams, so the tail of one launch overlaps
-        # the start-up of the next (tools/two_streams.py)
-        f2 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-        img2 = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)
-        g2_, h2_ = torch.empty_like(img), torch.empty_like(img)
-        side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        pair = [(f, img, (g, h)), (f2, img2, (g2_, h2_))]
-        flip = {"i": 0}
 
-        def step_two():
-            flip["i"] ^= 1
-            fi, im, oo = pair[flip["i"]]
-            with torch.cuda.stream(side[flip["i"]]):
-                fi.setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=oo)
+        # the bare kernel: a fresh handle with the launch-order tuning and the placement search both off
+        # (the engine's default order from the first call), same image, same outputs
+        fu = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+        fu.set_option(L.OPT_AUTOTUNE, 0)
+        fu.set_option(L.OPT_PLACEMENT_SEARCH, 0)
+        leg("M2_untuned", lambda: fu.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], warm=max(2, args.warmup))
+        extra["M2_untuned"]["note"] = "fresh handle, CVS_OPT_AUTOTUNE=0, CVS_OPT_PLACEMENT_SEARCH=0 (engine defaults from the first call)"
+        rotu = {"i": 0}
 
-        def timed_two(k):
-            main = torch.cuda.current_stream()
+        def step_rot_u():
+            rotu["i"] = (rotu["i"] + 1) & 7
+            fu.setup_steer(imgs8[rotu["i"]], THETA, flags=cv.SETUP_BASIS, out=(g, h))
+
+        leg("M2_untuned_rotating_8_inputs", step_rot_u, BYTES_PER_PIX["M2"], warm=max(2, args.warmup))
+        del fu
+
+        # the reference's usage pattern: ONE object per image (example/steer.cpp:86, test/test.cpp:85) -- create,
+        # one fused call, wait, destroy.  `ms_call` = HIP events around the single call; `ms_object` = wall time of
+        # create + call + sync + destroy.  Cold = the process-wide state-block cache emptied first (hipMalloc of
+        # 0.8 GB inside the call); warm = the block of the previous object is taken over.
+        def one_object(image):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(main)
-            for st in side:
-                st.wait_event(e0)
-            for _ in range(k):
-                step_two()
-            for st in side:
-                main.wait_stream(st)
-            e1.record(main)
+            t0 = time.perf_counter()
+            fo = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            e0.record()
+            fo.setup_steer(image, THETA, flags=cv.SETUP_BASIS, out=(g, h))
+            e1.record()
             torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / k
+            del fo
+            return (time.perf_counter() - t0) * 1e3, e0.elapsed_time(e1)
 
-        timed_two(2 * WARM_NEW)
-        barrier()
-        ms2 = timed_two(ksteps)
-        extra["M2_two_streams_two_images"] = {"Mpix/s": round(npix / (ms2 * 1e-3) / 1e6, 1), "ms": round(ms2, 5),
-                                              "frac_hbm": round(BYTES_PER_PIX["M2"] * npix / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": 40,
-                                              "note": "alternating images on two handles / two streams; not the headline configuration"}
-        torch.cuda.current_stream().synchronize()
-        f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))  # back on the main stream
-        del f2, img2, g2_, h2_
-        leg("M1_basis_only", lambda: f.setup(img, flags=cv.SETUP_BASIS), BYTES_PER_PIX["M1"])
-        leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"])
-        outs8 = [torch.empty_like(img) for _ in range(8)]
-        leg("M5_pipeline", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"])
-        f.setup(img, flags=cv.SETUP_FULL)
-        leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36)
-        leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), 64)
-        f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)
-        leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"])
-        leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"])
-        # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed
-        # start-up cost of a launch (every wave primes its 8-row window before its first store) amortises
-        big2 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
-        fb = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-        gb, hb = torch.empty_like(big2), torch.empty_like(big2)
-        bsteps = max(5, args.steps // 4)
-        for nm, fn, bpp in (("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32),
-                            ("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40)):
-            w_, e_ = _time_steps(torch, fn, bsteps, WARM_NEW, barrier)
-            ms = e_ / bsteps
-            extra[nm] = {"Mpix/s": round(4 * npix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5),
-                         "GB/s": round(bpp * 4 * npix / (ms * 1e-3) / 1e9, 1),
-                         "frac_hbm": round(bpp * 4 * npix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": bpp}
-        del big2, fb, gb, hb
-        # BASELINE config 4 frame shape: 1080 x 1920 frames resident in HBM, full pipeline per frame
+        torch.cuda.synchronize()
+        cv.lib().cvs_release_cached_memory()
+        cold = one_object(imgs8[1])
+        runs = [one_object(imgs8[(2 + i) & 7]) for i in range(10)]
+        ms_call = sorted(r[1] for r in runs)[len(runs) // 2]
+        ms_obj = sorted(r[0] for r in runs)[len(runs) // 2]
+        extra["M2_first_call"] = dict(rate(ms_call, BYTES_PER_PIX["M2"], npix), ms_object=round(ms_obj, 4),
+                                      ms_call_cold=round(cold[1], 4), ms_object_cold=round(cold[0], 4),
+                                      note="one new handle per image, a different image each time; median of 10; "
+                                           "ms = events around the single call, ms_object = create+call+sync+destroy wall")
+        del imgs8
+
+        if ws == 1:
+            # throughput mode: consecutive images go to two handles on two HIP streams, so the tail of one launch
+            # overlaps the start-up of the next (tools/two_streams.py)
+            f2 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            img2 = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)
+            g2_, h2_ = torch.empty_like(img), torch.empty_like(img)
+            side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            pair = [(f, img, (g, h)), (f2, img2, (g2_, h2_))]
+            flip = {"i": 0}
+
+            def step_two():
+                flip["i"] ^= 1
+                fi, im, oo = pair[flip["i"]]
+                with torch.cuda.stream(side[flip["i"]]):
+                    fi.setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=oo)
+
+            def timed_two(k):
+                main = torch.cuda.current_stream()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                for st in side:
+                    st.wait_event(e0)
+                for _ in range(k):
+                    step_two()
+                for st in side:
+                    main.wait_stream(st)
+                e1.record(main)
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / k
+
+            timed_two(2 * WARM_NEW)
+            ms2 = timed_two(ksteps)
+            extra["M2_two_streams_two_images"] = dict(rate(ms2, 40, npix), note="alternating images on two handles / two streams; not the headline configuration")
+            torch.cuda.current_stream().synchronize()
+            f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))  # back on the main stream
+            del f2, img2, g2_, h2_
+            leg("M1_basis_only", lambda: f.setup(img, flags=cv.SETUP_BASIS), BYTES_PER_PIX["M1"])
+            leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"])
+            outs8 = [torch.empty_like(img) for _ in range(8)]
+            leg("M5_pipeline", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"])
+            f.setup(img, flags=cv.SETUP_FULL)
+            leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36)
+            leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), 64)
+            del outs8
+            f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)
+            leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"])
+            leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"])
+            del f4
+            # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed
+            # start-up cost of a launch (every wave primes its 8-row window before its first store) amortises
+            big2 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
+            fb = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            gb, hb = torch.empty_like(big2), torch.empty_like(big2)
+            bsteps = max(5, args.steps // 4)
+            leg("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
+            leg("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
+            del big2, fb, gb, hb
+
+        # ---- BASELINE config 4: 1080 x 1920 frames, the callers' whole pipeline per frame, 32 frames per GPU ----
+        # Two frame sets alternate so that every launch reads frames the previous launch did not touch (2 x 265 MB
+        # of inputs + 2.1 GB of outputs per launch pass through the 256 MiB Infinity Cache in between); >= 10 timed steps.
         nfr = 32
-        frames = torch.rand((nfr, 1080, 1920), generator=gen, device=dev, dtype=torch.float32)
+        fsets = [torch.rand((nfr, 1080, 1920), generator=gen, device=dev, dtype=torch.float32) for _ in range(2)]
         fout = torch.empty((nfr, 8, 1080, 1920), device=dev)
         ff = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-        csteps = max(2, args.steps // 20)
-        w_, e_ = _time_steps(torch, lambda: ff.pipeline_batch(frames, out=fout), csteps, WARM_NEW, barrier)
-        ms = e_ / csteps
+        csteps = max(10, args.steps // 10)
+        alt = {"i": 0}
+
+        def step_c4():
+            alt["i"] ^= 1
+            ff.pipeline_batch(fsets[alt["i"]], out=fout)
+
+        w_, e_ = _time_steps(torch, step_c4, csteps, WARM_NEW, barrier)
+        (ms,) = max_over_ranks(e_ / csteps)
         fp = nfr * 1080 * 1920
-        extra["C4_32x1080p_pipeline_batch"] = {"Mpix/s": round(fp / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms / nfr, 5),
-                                               "GB/s": round(84 * fp / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(84 * fp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                               "launches_per_batch": 1}
+        extra["C4_32x1080p_pipeline_batch"] = dict(rate(ms, 84, ws * fp), ms_per_frame=round(ms / nfr, 5), launches_per_batch=1,
+                                                   frames_per_gpu=nfr, timed_steps=csteps, frame_sets=2)
         ff.set_persist(False)
         fo3 = torch.empty((nfr, 3, 1080, 1920), device=dev)
-        w_, e_ = _time_steps(torch, lambda: ff.pipeline_batch(frames, out=fo3, outputs=(5, 6, 7)), csteps, WARM_NEW, barrier)
-        ms = e_ / csteps
-        extra["C4_32x1080p_feature_maps_only"] = {"Mpix/s": round(fp / (ms * 1e-3) / 1e6, 1), "ms_per_frame": round(ms / nfr, 5),
-                                                   "B/pix": 16, "GB/s": round(16 * fp / (ms * 1e-3) / 1e9, 1),
-                                                   "note": "edges + dark + bright only, no state persisted (what example/steer.cpp keeps)"}
-        del fout, fo3, frames, ff
-        # BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image (pyrDown is this
-        # build's own component -- the reference has no pyramid code)
-        big = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
-        fp3 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-        lv = fp3.pyramid(big, 5)
-        ppix = sum(l.shape[0] * l.shape[1] for l in lv)
-        hp = [cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank) for _ in lv]
 
-        def pyr_filter():
-            for hnd, l in zip(hp, lv):
-                hnd.setup(l, flags=cv.SETUP_BASIS)
+        def step_c4f():
+            alt["i"] ^= 1
+            ff.pipeline_batch(fsets[alt["i"]], out=fo3, outputs=(5, 6, 7))
 
-        c3 = max(3, args.steps // 10)
-        w_, e_ = _time_steps(torch, pyr_filter, c3, WARM_NEW, barrier)
-        w2_, e2_ = _time_steps(torch, lambda: fp3.pyramid(big, 5), c3, 2, barrier)
-        extra["C3_pyramid_8192_5_levels"] = {"filter_Mpix/s": round(ppix / (e_ / c3 * 1e-3) / 1e6, 1), "filter_ms": round(e_ / c3, 4),
-                                            "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                            "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix}
-        del big, lv, hp, fp3
-        # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in
-        # and out (64 MiB up, 9 x 64 MiB down through hipMemcpy2D, pageable memory)
-        import numpy as np
-        himg = img.cpu().numpy()
-        fh = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-        hg, hh = np.empty_like(himg), np.empty_like(himg)
-        fh.setup_steer(himg, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
-        t0 = time.perf_counter()
-        for _ in range(3):
+        w_, e_ = _time_steps(torch, step_c4f, csteps, WARM_NEW, barrier)
+        (ms,) = max_over_ranks(e_ / csteps)
+        extra["C4_32x1080p_feature_maps_only"] = dict(rate(ms, 16, ws * fp), ms_per_frame=round(ms / nfr, 5), timed_steps=csteps,
+                                                      note="edges + dark + bright only, no state persisted (what example/steer.cpp keeps)")
+        del fout, fo3
+
+        # ---- config 4 end to end: frames on rank 0 -> scatter (RCCL send/recv) -> pipeline per rank -> gather of the
+        # three feature maps on rank 0; the three phases timed separately (barrier + synchronize between them)
+        n_all = nfr * ws
+        shape = (1080, 1920)
+        all_frames = None
+        if rank == 0:
+            all_frames = fsets[0] if ws == 1 else torch.cat([fsets[0]] + [torch.rand((nfr,) + shape, generator=gen, device=dev) for _ in range(ws - 1)])
+        tms = {"scatter": 0.0, "compute": 0.0, "gather": 0.0}
+        reps = 3
+
+        def sync_all():
+            torch.cuda.synchronize()
+            barrier()
+
+        if not test_backend:   # the rehearsal backend has no device-to-device path
+            for rep in range(reps + 1):
+                sync_all(); t0 = time.perf_counter()
+                local = batch.scatter_frames(all_frames, n_all, shape, dev)
+                sync_all(); t1 = time.perf_counter()
+                res = ff.pipeline_batch(local, outputs=(5, 6, 7))
+                sync_all(); t2 = time.perf_counter()
+                full = batch.gather_planes(res, n_all)
+                sync_all(); t3 = time.perf_counter()
+                if rep:  # the first repetition warms allocations / RCCL channels
+                    tms["scatter"] += (t1 - t0) / reps; tms["compute"] += (t2 - t1) / reps; tms["gather"] += (t3 - t2) / reps
+            tot = sum(tms.values())
+            extra["C4_e2e"] = {"frames": n_all, "ms": {k: round(v * 1e3, 3) for k, v in tms.items()},
+                               "compute_only_Mpix/s": round(n_all * 1080 * 1920 / tms["compute"] / 1e6, 1),
+                               "end_to_end_Mpix/s": round(n_all * 1080 * 1920 / tot / 1e6, 1),
+                               "gathered": "3 feature maps per frame on rank 0" + ("" if rank or full is None else " %s" % (list(full.shape),)),
+                               "transport": "local copies (one rank)" if ws == 1 else "RCCL grouped send/recv over xGMI"}
+            del local, res, full
+        del fsets, ff, all_frames
+
+        if ws == 1:
+            # BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image (pyrDown is this
+            # build's own component -- the reference has no pyramid code)
+            big = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
+            fp3 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            lv = fp3.pyramid(big, 5)
+            ppix = sum(l.shape[0] * l.shape[1] for l in lv)
+            hp = [cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank) for _ in lv]
+
+            def pyr_filter():
+                for hnd, l in zip(hp, lv):
+                    hnd.setup(l, flags=cv.SETUP_BASIS)
+
+            c3 = max(5, args.steps // 10)
+            w_, e_ = _time_steps(torch, pyr_filter, c3, WARM_NEW, barrier)
+            w2_, e2_ = _time_steps(torch, lambda: fp3.pyramid(big, 5), c3, 2, barrier)
+            extra["C3_pyramid_8192_5_levels"] = {"filter_Mpix/s": round(ppix / (e_ / c3 * 1e-3) / 1e6, 1), "filter_ms": round(e_ / c3, 4),
+                                                "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix}
+            del big, lv, hp, fp3
+            # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in
+            # and out (64 MiB up, 2 x 64 MiB down), pageable host memory
+            import numpy as np
+            himg = img.cpu().numpy()
+            fh = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            hg, hh = np.empty_like(himg), np.empty_like(himg)
             fh.setup_steer(himg, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
-        dt = (time.perf_counter() - t0) / 3
-        extra["M2_host_planes_pcie_inclusive"] = {"Mpix/s": round(npix / dt / 1e6, 1), "ms": round(dt * 1e3, 3),
-                                                  "note": "host f32 image in, g2/h2 out to host, bases stay on device"}
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fh.setup_steer(himg, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
+            dt = (time.perf_counter() - t0) / 3
+            extra["M2_host_planes_pcie_inclusive"] = {"Mpix/s": round(npix / dt / 1e6, 1), "ms": round(dt * 1e3, 3),
+                                                      "note": "host f32 image in, g2/h2 out to host, bases stay on device"}
         out["extra"] = extra
 
     if rank == 0 and ws == 1 and not args.no_cpu:

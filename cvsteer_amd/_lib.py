@@ -45,6 +45,7 @@ SIGNATURES = {
     "cvs_steer_weights": (C.c_int, [C.c_int, C.c_float, _FP]),
     "cvs_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_void_p)]),
     "cvs_destroy": (C.c_int, [C.c_void_p]),
+    "cvs_release_cached_memory": (C.c_int, []),
     "cvs_last_error": (C.c_char_p, [C.c_void_p]),
     "cvs_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvs_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

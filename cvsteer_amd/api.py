@@ -25,6 +25,12 @@ except Exception:  # pragma: no cover
     torch = None
 
 
+# numpy mirror of `struct cvs_plane` (include/cvsteer_hip.h) for arrays of descriptors
+_PLANE_DTYPE = np.dtype({"names": ["data", "rows", "cols", "step", "mem"], "formats": ["u8", "i4", "i4", "u8", "i4"],
+                         "offsets": [Plane.data.offset, Plane.rows.offset, Plane.cols.offset, Plane.step.offset, Plane.mem.offset],
+                         "itemsize": C.sizeof(Plane)})
+
+
 def _is_torch(a):
     return torch is not None and isinstance(a, torch.Tensor)
 
@@ -340,9 +346,30 @@ class SteerableFiltersG2(SteerableFilters):
         of planes).  outputs: indices into (g2, h2, e, magnitude, phase, edges, dark, bright) to
         produce (default all 8); returns / fills out [n, len(outputs), H, W].  select_frame(i) then
         picks whose state the getters and steer() use (unless set_persist(False))."""
+        sel = list(range(8)) if outputs is None else [int(k) for k in outputs]
+        block = _is_torch(frames) and frames.dim() == 3 and frames.dtype == torch.float32 and frames.is_cuda
+        if block and out is None:
+            out = torch.empty((frames.shape[0], len(sel)) + tuple(frames.shape[1:]), dtype=torch.float32, device=frames.device)
+        if block and _is_torch(out) and out.dim() == 4 and out.is_cuda and out.dtype == torch.float32 \
+                and out.shape[0] == frames.shape[0] and out.shape[1] == len(sel) and frames.stride(2) == 1 and out.stride(3) == 1:
+            # one [n, H, W] block in, one [n, K, H, W] block out: the plane descriptors are filled in arithmetically
+            # (two numpy arrays laid out like `struct cvs_plane`), not one Python object per plane
+            n, rows, cols = (int(v) for v in frames.shape)
+            self._like = frames[0]
+            self._bind_stream(frames, out)
+            imgs = np.zeros(n, _PLANE_DTYPE)
+            imgs["data"] = frames.data_ptr() + np.arange(n, dtype=np.uint64) * np.uint64(frames.stride(0) * 4)
+            imgs["rows"], imgs["cols"], imgs["step"], imgs["mem"] = rows, cols, frames.stride(1) * 4, L.MEM_DEVICE
+            outs = np.zeros((n, 8), _PLANE_DTYPE)  # data == NULL means "not requested"
+            frame_off = np.arange(n, dtype=np.uint64) * np.uint64(out.stride(0) * 4)
+            for j, k in enumerate(sel):
+                outs["data"][:, k] = out.data_ptr() + frame_off + np.uint64(j * out.stride(1) * 4)
+                outs["rows"][:, k], outs["cols"][:, k], outs["step"][:, k], outs["mem"][:, k] = rows, cols, out.stride(2) * 4, L.MEM_DEVICE
+            self._check(lib().cvs_pipeline_batch(self._h, imgs.ctypes.data_as(L._PP), n, outs.ctypes.data_as(L._PP)), "cvs_pipeline_batch")
+            self._batch_keepalive = (frames, out)
+            return out
         planes = [_as_input(f) for f in frames]
         n = len(planes)
-        sel = list(range(8)) if outputs is None else [int(k) for k in outputs]
         self._like = planes[0]
         shape = tuple(planes[0].shape)
         if out is None:

@@ -50,8 +50,10 @@ struct cvs_context {
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 1, autotune = 1;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 0, autotune = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
+    hipEvent_t ev_order = nullptr;            // cvs_set_stream: orders the new stream behind the old one
+    bool used = false;                        // any work queued on `stream` so far
     // placement search bookkeeping, per kernel variant (a block that is fast for one variant need not be for another):
     // launches of the variant on the current state allocation, and whether the search has run for it
     int variant_calls[32] = {};
@@ -218,6 +220,7 @@ int begin(cvs_handle h, Call& c, std::initializer_list<const cvs_plane*> planes,
 {
     c.h = h;
     HIP_TRY(h, hipSetDevice(h->device));
+    h->used = true;
     size_t need = extra;
     for (const cvs_plane* p : planes) need += staged_elems(p);
     if (need) {
@@ -233,6 +236,67 @@ float* state_plane(cvs_handle h, int idx)
     return h->state + (size_t)h->cur_frame * h->frame_stride + (size_t)idx * h->plane_stride;
 }
 
+// Process-wide cache of released state blocks.  The reference's usage model is one short-lived object per image
+// (example/steer.cpp:86 inside the parallel_for_ body; test/test.cpp:85): a hipMalloc + hipFree of the 0.8 GiB state
+// block per image costs more than the filtering itself, so cvs_destroy parks the block here (after its stream has
+// drained) and the next handle on the same device that needs a block of about that size takes it over.  Bounded:
+// CVS_STATE_POOL_MB megabytes in all (default 4096, 0 = off), blocks at most twice the size asked for;
+// cvs_release_cached_memory() empties it.
+struct PoolBlock {
+    int device;
+    float* p;
+    size_t elems;
+};
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> g_pool;
+
+size_t pool_limit_bytes()
+{
+    static const size_t lim = [] {
+        const char* e = std::getenv("CVS_STATE_POOL_MB");
+        const long mb = e ? std::atol(e) : 4096;
+        return mb > 0 ? (size_t)mb << 20 : (size_t)0;
+    }();
+    return lim;
+}
+
+float* pool_take(int device, size_t elems, size_t* got)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i)
+        if (g_pool[i].device == device && g_pool[i].elems >= elems && g_pool[i].elems <= 2 * elems &&
+            (best < 0 || g_pool[i].elems < g_pool[best].elems))
+            best = i;
+    if (best < 0) return nullptr;
+    float* p = g_pool[best].p;
+    *got = g_pool[best].elems;
+    g_pool.erase(g_pool.begin() + best);
+    return p;
+}
+
+// the caller has synchronised the stream that last used the block
+void pool_give(int device, float* p, size_t elems)
+{
+    const size_t lim = pool_limit_bytes(), bytes = elems * sizeof(float);
+    std::vector<float*> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (bytes > lim) drop.push_back(p);
+        else {
+            size_t held = bytes;
+            for (const PoolBlock& b : g_pool) held += b.elems * sizeof(float);
+            while (held > lim && !g_pool.empty()) {  // oldest first
+                held -= g_pool.front().elems * sizeof(float);
+                drop.push_back(g_pool.front().p);
+                g_pool.erase(g_pool.begin());
+            }
+            g_pool.push_back({device, p, elems});
+        }
+    }
+    for (float* d : drop) (void)hipFree(d);
+}
+
 int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
 {
     const size_t pitch = round_up((size_t)cols, 64);
@@ -245,8 +309,14 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
             h->state = nullptr;
             h->state_elems = 0;
         }
-        HIP_TRY(h, hipMalloc(&h->state, elems * sizeof(float)));
-        h->state_elems = elems;
+        size_t got = 0;
+        if (float* cached = pool_take(h->device, elems, &got)) {
+            h->state = cached;
+            h->state_elems = got;
+        } else {
+            HIP_TRY(h, hipMalloc(&h->state, elems * sizeof(float)));
+            h->state_elems = elems;
+        }
         std::memset(h->variant_calls, 0, sizeof(h->variant_calls));
         std::memset(h->variant_placed, 0, sizeof(h->variant_placed));
     }
@@ -304,7 +374,8 @@ struct TuneEntry {
     int g4_split = 2;        // order 1: tiles per period for even / odd XCDs, 100 * e + o
 };
 std::mutex g_tune_mutex;
-std::map<std::tuple<int, int, int, int, int>, TuneEntry> g_tune;
+std::mutex g_placement_mutex;
+std::map<std::tuple<int, int, int, int, int, int>, TuneEntry> g_tune;
 
 // Placement search.  The many-plane variants run at one of two speeds (67-71 % or 81-84 % of the roofline at
 // 4096^2) depending on where the state block happens to be allocated -- same kernel, same order, same image;
@@ -324,22 +395,30 @@ int search_placement(cvs_handle h, BasisArgs& a, float* scr, int variant)
     if (bytes < ((size_t)256 << 20)) return CVS_OK;  // the whole state sits in the Infinity Cache: nothing to find
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return CVS_OK;
-    constexpr int kExtra = 12;
+    // Opt-in (CVS_OPT_PLACEMENT_SEARCH, off by default) and bounded: at most 12 candidate blocks and at most 8 GiB
+    // of transient memory in all, one search at a time per process (every hipMalloc / hipFree is a device-wide
+    // synchronisation, and hipMemGetInfo is only a snapshot).  A handle that finds another search running skips its own.
+    constexpr int kMaxExtra = 12;
+    constexpr size_t kMaxTransient = (size_t)8 << 30;
+    const int kExtra = (int)std::min<size_t>(kMaxExtra, kMaxTransient / bytes);
+    if (kExtra < 1) return CVS_OK;
+    std::unique_lock<std::mutex> search_lock(g_placement_mutex, std::try_to_lock);
+    if (!search_lock.owns_lock()) return CVS_OK;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (kExtra + 1) * bytes + ((size_t)4 << 30)) return CVS_OK;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (size_t)(kExtra + 1) * bytes + ((size_t)4 << 30)) return CVS_OK;
     if (!h->ev0) {
         HIP_TRY(h, hipEventCreate(&h->ev0));
         HIP_TRY(h, hipEventCreate(&h->ev1));
     }
     const auto t_begin = std::chrono::steady_clock::now();
-    float* cand[kExtra + 1] = {h->state};
+    float* cand[kMaxExtra + 1] = {h->state};
     int n = 1;
     for (; n <= kExtra; ++n)
         if (hipMalloc(&cand[n], bytes) != hipSuccess) {
             (void)hipGetLastError();
             break;
         }
-    float best[kExtra + 1];
+    float best[kMaxExtra + 1];
     float* const home = h->state;
     const ptrdiff_t basis_off = a.basis - home, orient_off = a.orient ? a.orient - home : 0;
     int rc = CVS_OK;
@@ -414,7 +493,7 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     if (h->block_order >= 0) a.block_order = h->block_order;
     else {
         // launches of 32 Mpix and more are long enough for the plain order (8192^2, one handle: M1 80.7 vs 80.2 %, M4 87.0 vs 80.5 %)
-        const bool huge = (size_t)a.rows * a.cols * (a.frames ? (size_t)a.batch : 1) >= ((size_t)32 << 20);
+        const bool huge = (size_t)a.rows * a.cols * (a.batch > 0 ? (size_t)a.batch : 1) >= ((size_t)32 << 20);
         // ... and the stateless pipeline is VALU-bound, not write-bound: nothing to balance (32 x 1080p: 106 -> 93 Gpix/s weighted)
         // ... and when every call brings a new image (inputs come from HBM, not the Infinity Cache) the plain order wins
         // too (8 rotating 4096^2 inputs, one handle: M2 70-72 % plain, 64-68 % weighted)
@@ -425,11 +504,13 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     // what is still open: the order (unless pinned), the strip height (unless pinned or the input stream is fresh
     // images, where short strips are a must), the G4 bank layout (unless pinned)
     const bool free_order = h->block_order < 0;
-    const bool free_strip = h->strip_rows <= 0 && !fresh_input && !a.frames;
+    const bool free_strip = h->strip_rows <= 0 && !fresh_input && a.batch == 0;
     const bool free_split = h->kind == CVS_KIND_G4 && h->g4_split < 0;
     if (!h->autotune || (!free_order && !free_strip && !free_split)) return CVS_OK;
-    const int pins = (h->block_order + 1) * 4 + (h->strip_rows > 0 ? 2 : 0) + (h->g4_split >= 0 ? 1 : 0);
-    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->kind << 12) | (pins << 16), a.rows, a.cols, xw_pinned);
+    // what the caller pinned is part of the key, in a field of its own (the raw block order can be as large as 1e6)
+    const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->g4_split >= 0 ? 1 : 0);
+    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->kind << 12) | (pins << 16), a.rows, a.cols, xw_pinned,
+                                     h->block_order);
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
         TuneEntry& e = g_tune[key];
@@ -738,14 +819,33 @@ int cvs_destroy(cvs_handle h)
     if (!h) return CVS_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    if (h->state) (void)hipFree(h->state);
+    if (h->state) pool_give(h->device, h->state, h->state_elems);  // the stream has drained: the block may be reused
     if (h->arena) (void)hipFree(h->arena);
     if (h->minmax) (void)hipFree(h->minmax);
     if (h->frame_tab) (void)hipFree(h->frame_tab);
     if (h->point_out) (void)hipFree(h->point_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_order) (void)hipEventDestroy(h->ev_order);
     delete h;
+    return CVS_OK;
+}
+
+int cvs_release_cached_memory(void)
+{
+    std::vector<PoolBlock> blocks;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        blocks.swap(g_pool);
+    }
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (const PoolBlock& b : blocks) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
     return CVS_OK;
 }
 
@@ -754,7 +854,22 @@ const char* cvs_last_error(cvs_handle h) { return h ? h->err.c_str() : "null han
 int cvs_set_stream(cvs_handle h, void* s)
 {
     if (!h) return CVS_E_BADARG;
-    h->stream = static_cast<hipStream_t>(s);
+    hipStream_t ns = static_cast<hipStream_t>(s);
+    if (ns == h->stream) return CVS_OK;
+    // The handle's state block, staging arena and frame table are reused from call to call: work already queued
+    // on the old stream must finish before the new stream touches them.  One event, recorded on the old stream and
+    // waited for by the new one (no host synchronisation); skipped while either stream is being captured.
+    hipStreamCaptureStatus c0 = hipStreamCaptureStatusNone, c1 = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(h->stream, &c0);
+    (void)hipStreamIsCapturing(ns, &c1);
+    (void)hipGetLastError();
+    if (h->used && c0 == hipStreamCaptureStatusNone && c1 == hipStreamCaptureStatusNone) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        if (!h->ev_order) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->ev_order, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(ns, h->ev_order, 0));
+    }
+    h->stream = ns;
     return CVS_OK;
 }
 
@@ -1055,6 +1170,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
             const cvs_plane* o = &outs[(size_t)i * 8 + k];
             if (!o->data) continue;
             if ((rc = check_plane(h, o, "out")) || (rc = check_same(h, o, rows, cols))) return rc;
+            if (o->data == images[i].data) return fail(h, CVS_E_BADARG, "an output plane aliases the input image");
             all_dev = all_dev && o->mem == CVS_MEM_DEVICE;
             max_bytes = std::max(max_bytes, (size_t)rows * o->step);
         }
@@ -1075,19 +1191,10 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
         return CVS_OK;
     }
     HIP_TRY(h, hipSetDevice(h->device));
+    h->used = true;
     h->have_basis = h->have_orient = false;
     if ((rc = ensure_state(h, rows, cols, n))) return rc;
     h->cur_frame = 0;
-    if (n > h->frame_tab_cap) {
-        if (h->frame_tab) {
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            HIP_TRY(h, hipFree(h->frame_tab));
-            h->frame_tab = nullptr;
-            h->frame_tab_cap = 0;
-        }
-        HIP_TRY(h, hipMalloc(&h->frame_tab, (size_t)n * sizeof(BatchFrame)));
-        h->frame_tab_cap = n;
-    }
     std::vector<BatchFrame> tab(n);
     for (int i = 0; i < n; ++i) {
         tab[i].in = images[i].data;
@@ -1097,12 +1204,51 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
             tab[i].out[k] = (o && o->data) ? PlaneRef{o->data, o->step / sizeof(float)} : PlaneRef{nullptr, 0};
         }
     }
-    // pageable source: the runtime stages it before returning, so `tab` may go out of scope
-    HIP_TRY(h, hipMemcpyAsync(h->frame_tab, tab.data(), (size_t)n * sizeof(BatchFrame), hipMemcpyHostToDevice, h->stream));
+    // Regularly strided frames -- one [n, H, W] block in, one [n, K, H, W] block out, the usual case -- need no
+    // table: frame z is frame 0 plus z strides, computed in the kernel from its arguments.  Anything else (a list
+    // of unrelated planes) goes through a device table, uploaded on the handle's stream.
+    bool regular = true;
+    ptrdiff_t d_in = 0, d_out = 0;
+    bool have_out_stride = false;
+    for (int i = 1; i < n && regular; ++i) {
+        const ptrdiff_t di = tab[i].in - tab[0].in;
+        if (i == 1) d_in = di;
+        regular = di == d_in * i && d_in >= 0 && tab[i].in_pitch == tab[0].in_pitch;
+        for (int k = 0; k < 8 && regular; ++k) {
+            if ((tab[i].out[k].p == nullptr) != (tab[0].out[k].p == nullptr)) regular = false;
+            else if (tab[i].out[k].p) {
+                const ptrdiff_t dk = tab[i].out[k].p - tab[0].out[k].p;
+                if (!have_out_stride) { d_out = dk / i; have_out_stride = true; }
+                regular = dk == d_out * i && d_out >= 0 && tab[i].out[k].pitch == tab[0].out[k].pitch;
+            }
+        }
+    }
+    if (!regular) {
+        if (n > h->frame_tab_cap) {
+            if (h->frame_tab) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                HIP_TRY(h, hipFree(h->frame_tab));
+                h->frame_tab = nullptr;
+                h->frame_tab_cap = 0;
+            }
+            HIP_TRY(h, hipMalloc(&h->frame_tab, (size_t)n * sizeof(BatchFrame)));
+            h->frame_tab_cap = n;
+        }
+        // pageable source: the runtime stages it before returning, so `tab` may go out of scope
+        HIP_TRY(h, hipMemcpyAsync(h->frame_tab, tab.data(), (size_t)n * sizeof(BatchFrame), hipMemcpyHostToDevice, h->stream));
+    }
     BasisArgs a{};
     a.rows = rows;
     a.cols = cols;
     a.in_pitch = pitch;
+    if (regular) {
+        a.batch_regular = 1;
+        a.in = tab[0].in;
+        a.in_pitch = tab[0].in_pitch;
+        a.in_frame_stride = (size_t)d_in;
+        a.out_frame_stride = (size_t)d_out;
+        for (int k = 0; k < 8; ++k) a.pipe_out[k] = tab[0].out[k];
+    }
     a.basis = h->state;
     a.pitch = h->pitch;
     a.plane_stride = h->plane_stride;
@@ -1113,7 +1259,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.pipe = 1;
     a.no_state = h->persist ? 0 : 1;
     a.find_on_e = h->find_on;
-    a.frames = h->frame_tab;
+    a.frames = regular ? nullptr : h->frame_tab;
     a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
     a.batch = n;
     a.frame_stride = h->frame_stride;

@@ -52,8 +52,12 @@ struct BasisArgs {
     PlaneRef pipe_out[8]; // any entry may be {nullptr, 0}
     // batched launch: n frames of identical geometry, frame z takes in/out from frames[z] and its
     // state planes at basis + z*frame_stride (orient likewise)
-    const BatchFrame* frames;  // device pointer, or nullptr = single image
+    const BatchFrame* frames;  // device pointer, or nullptr = single image / regular batch
     int batch;
+    // regular batch (frames == nullptr, batch_regular = 1): frame z reads in + z*in_frame_stride and writes
+    // pipe_out[k].p + z*out_frame_stride -- pointers from kernel arguments only, no table, no upload
+    int batch_regular;
+    size_t in_frame_stride, out_frame_stride;  // elements
     size_t frame_stride;       // elements between the state blocks of consecutive frames
     // diagnostic builds only (-DCVS_DIAG_STAMPS, tools/k1_timeline.py): per-wave {start, first store, end}
     // 100 MHz real-time stamps; never read by the product, nullptr in normal builds

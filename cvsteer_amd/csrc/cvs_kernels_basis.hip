@@ -232,15 +232,24 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     float* orient_p = a.orient;
     PlaneRef pipe_out[8];
     if constexpr (BATCH) {
-        const BatchFrame* fr = a.frames + zframe;
-        in_p = reinterpret_cast<const float*>(uniform64(reinterpret_cast<unsigned long long>(fr->in)));
-        in_pitch = uniform64(fr->in_pitch);
         basis_p += (size_t)zframe * a.frame_stride;
         orient_p += (size_t)zframe * a.frame_stride;
+        if (a.frames) {  // per-frame pointers from the device table
+            const BatchFrame* fr = a.frames + zframe;
+            in_p = reinterpret_cast<const float*>(uniform64(reinterpret_cast<unsigned long long>(fr->in)));
+            in_pitch = uniform64(fr->in_pitch);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            pipe_out[k].p = reinterpret_cast<float*>(uniform64(reinterpret_cast<unsigned long long>(fr->out[k].p)));
-            pipe_out[k].pitch = uniform64(fr->out[k].pitch);
+            for (int k = 0; k < 8; ++k) {
+                pipe_out[k].p = reinterpret_cast<float*>(uniform64(reinterpret_cast<unsigned long long>(fr->out[k].p)));
+                pipe_out[k].pitch = uniform64(fr->out[k].pitch);
+            }
+        } else {  // regularly strided frames (one [n, H, W] block in, one [n, K, H, W] block out): scalar arithmetic only
+            in_p += (size_t)zframe * a.in_frame_stride;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                pipe_out[k].p = a.pipe_out[k].p ? a.pipe_out[k].p + (size_t)zframe * a.out_frame_stride : nullptr;
+                pipe_out[k].pitch = a.pipe_out[k].pitch;
+            }
         }
     } else {
 #pragma unroll
@@ -554,7 +563,11 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     const bool orient = orient_v;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     constexpr int NBTOT = B::KIND == 2 ? 7 : 11;
-    const bool one = ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float) <= kMaxPlaneBytes;
+    // the single-resource form addresses the whole image from row 0: a banded launch (a caller plane of 2 GiB or
+    // more beside a small state block, e.g. a narrow column view of a huge image) must use the per-plane form,
+    // which honours row_lo / row_hi / row_base
+    const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;
+    const bool one = !banded && ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float) <= kMaxPlaneBytes;
 #define CVS_LAUNCH_W(FL, BATCHED, WP)                                                                              \
     do {                                                                                                           \
         if (one) {                                                                                                 \
@@ -567,7 +580,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     } while (0)
 #define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 4)
 #define CVS_LAUNCH(FL) CVS_LAUNCH_B(FL, false)
-    if (a.frames) {  // batched caller pipeline: one launch, grid.z = frames (G2 only)
+    if (a.frames || a.batch_regular) {  // batched caller pipeline: one launch, grid.z = frames (G2 only)
         if constexpr (B::KIND == 2 && B::HALF == 0) {
             grid.z = a.batch;
             if (a.no_state) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE, true);
@@ -616,7 +629,8 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
     }
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     constexpr int NBTOT = BG::KIND == 2 ? 7 : 11;
-    const bool one = ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float) <= kMaxPlaneBytes;
+    const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;  // see launch_fast
+    const bool one = !banded && ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float) <= kMaxPlaneBytes;
 #define CVS_PAIR(FL, ST, ON) hipLaunchKernelGGL((k_basis_pair<BG, BH, FL, ST, ON>), grid, block, 0, s, a, fg, fh)
     if (steer) {
         if (a.nt_stores) { if (one) CVS_PAIR(F_STEER, true, true); else CVS_PAIR(F_STEER, true, false); }
@@ -734,7 +748,7 @@ static hipError_t for_each_band(const BasisArgs& a_in, int width, F&& fn)
 hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
                         float* scratch, hipStream_t s)
 {
-    if (a.frames) {  // batched launch: the API layer has already checked geometry and taps
+    if (a.frames || a.batch_regular) {  // batched launch: the API layer has already checked geometry and taps
         Folded<BankG2> f;
         if (kind != 2 || width != BankG2::W || !fold_taps<BankG2>(taps, f)) return hipErrorInvalidValue;
         BasisArgs b = a;

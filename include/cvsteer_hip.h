@@ -80,9 +80,12 @@ enum {
                                  0 (default) = 4:3, or what the autotuner found (tuning) */
     CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the second launch of a shape times a few launch configurations and caches the
                                 winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
-    CVS_OPT_PLACEMENT_SEARCH = 11, /* 1 (default): a handle that keeps filtering one shape (state >= 256 MiB) tries a few
-                                      state allocations once and keeps the fastest; 0 = never;
-                                      2 = always move to the last candidate (for tests) */
+    CVS_OPT_PLACEMENT_SEARCH = 11, /* 0 (default) = never.  1 = OPT-IN tuning aid: on its 8th launch of one kernel variant a
+                                      handle (state >= 256 MiB) allocates up to 12 more state blocks -- at most 8 GiB of
+                                      transient device memory in all -- times the launch on each and keeps the fastest.
+                                      Cost: tens of milliseconds, a stream synchronisation, device-wide hipMalloc/hipFree
+                                      stalls; one search at a time per process.  2 = always move to the last candidate
+                                      (tests).  Results never depend on it. */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
                                 launch (blockIdx.z picks the half); -1 (default) = 2, or 0 where the autotuner finds it faster */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
@@ -127,8 +130,16 @@ int cvs_steer_weights(int kind, float theta, float* out);
 /* SteerableFiltersG2::SteerableFiltersG2 / G4 ctor minus setup (G2.cpp:44-56, G4.cpp:47-63):
  * builds the tap vectors, binds HIP device `device`. */
 int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out);
+/* ~SteerableFiltersG2/G4.  The handle's state block (its largest allocation) is not freed but parked in a
+ * process-wide cache -- the reference's callers build one short-lived object per image (example/steer.cpp:86,
+ * test/test.cpp:85), and the next handle on the same device takes the block over instead of allocating.
+ * The cache is bounded (CVS_STATE_POOL_MB, default 4096; 0 = off). */
 int cvs_destroy(cvs_handle h);
+/* frees every block held by that cache */
+int cvs_release_cached_memory(void);
 const char* cvs_last_error(cvs_handle h);
+/* Bind the handle to a HIP stream.  The handle's buffers are reused from call to call, so when the stream changes
+ * the new stream is made to wait (event, no host sync) for the work already queued on the old one. */
 int cvs_set_stream(cvs_handle h, void* hip_stream);
 int cvs_set_option(cvs_handle h, int option, int value);
 int cvs_get_option(cvs_handle h, int option, int* value);

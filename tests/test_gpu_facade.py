@@ -43,3 +43,14 @@ def test_cpp_facade_runs_reference_test(ora, fish, golden_dir, tmp_path):
     g4 = np.fromfile(os.path.join(str(tmp_path), "g4.f32"), np.float32).reshape(shape)
     og, oh = ora.g4_steer_scalar(ora.basis(4, fish, 6, 0.5), 0.3)
     assert np.abs(g4 - og).max() <= 1e-5 * max(1.0, np.abs(og).max())
+
+
+def test_cpp_facade_protected_create_and_wrap():
+    """SteerableFilters::create / ::wrap (SteerableFilters.cpp:33-51) are protected statics: a tiny subclass in
+    tests/cpp/test_protected.cpp calls them like user code would; wrap runs on the GPU through cvs_wrap."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_protected")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cvsteer_amd", "facade"), "-s"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cvsteer.protected OK" in r.stdout

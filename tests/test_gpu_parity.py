@@ -236,6 +236,47 @@ def test_mag_phase_weights_find(cv, ora):
     assert np.array_equal(f.findBrightLines(e, op), outs[2])
 
 
+def test_wrap_standalone_entry(cv, ora):
+    """SteerableFilters::wrap (SteerableFilters.cpp:46-51) through its own entry point cvs_wrap / OP_WRAP:
+    out = angle > pi ? angle - 2 pi : angle with both constants narrowed to f32 -- bit for bit against the
+    oracle, on host planes, device planes (dword and 16-byte paths) and in place, around pi, 2 pi and NaN."""
+    import torch
+    pi32 = np.float32(np.pi)
+    special = np.array([0.0, -0.0, np.pi, np.nextafter(pi32, np.float32(4)), np.nextafter(pi32, np.float32(0)), -np.pi,
+                        2 * np.pi, np.nextafter(np.float32(2 * np.pi), np.float32(7)), 3 * np.pi, -3 * np.pi, 6.2831855, 1e30,
+                        -1e30, np.inf, -np.inf, np.nan, 3.1415925, 3.1415927, 3.1415930], np.float32)
+    rng = np.random.default_rng(77)
+    for shape in ((1, special.size), (37, 91), (64, 256)):           # 91 columns: dword path; 256: dwordx4 path
+        a = (rng.random(shape, dtype=np.float32) * np.float32(4 * np.pi) - np.float32(2 * np.pi)).astype(np.float32)
+        a.flat[:special.size] = special[:a.size]
+        want = ora.wrap(a)
+        assert want.shape == a.shape
+        # the definition itself (not only the oracle): values above pi (as f32) move down by 2 pi (as f32)
+        chk = np.where(a > pi32, a + np.float32(-2.0 * np.pi), a)
+        assert np.array_equal(want, chk, equal_nan=True)
+        f = cv.SteerableFiltersG2(None)
+        got_host = f.wrap(a)
+        assert np.array_equal(got_host, want, equal_nan=True), shape
+        ta = torch.from_numpy(a).cuda()
+        got_dev = f.wrap(ta)
+        assert np.array_equal(got_dev.cpu().numpy(), want, equal_nan=True), shape
+        # in place, as the reference calls it (wrap(m_theta, m_theta), G2.cpp:98,110)
+        pa = cv.api._plane(ta)
+        rc = cv.lib().cvs_wrap(f._h, C.byref(pa), C.byref(pa))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(ta.cpu().numpy(), want, equal_nan=True), shape
+    # range: everything in [0, 2 pi) lands in (-pi, pi]
+    a = np.linspace(0, 2 * np.pi, 100001, dtype=np.float32)[:-1].reshape(100, 1000)
+    w = cv.SteerableFiltersG2(None).wrap(a)
+    assert w.max() <= pi32 and w.min() > -pi32
+    # size mismatch is an error, like every other plane pair
+    with pytest.raises(cv.CvsError):
+        f = cv.SteerableFiltersG2(None)
+        pa, po = cv.api._plane(np.zeros((3, 4), np.float32)), cv.api._plane(np.zeros((3, 5), np.float32))
+        f._check(cv.lib().cvs_wrap(f._h, C.byref(pa), C.byref(po)), "cvs_wrap")
+
+
 # ----------------------------------------------------------------------------- the reference's own test
 def _recode(u8):
     from PIL import Image
@@ -809,6 +850,46 @@ def test_planes_beyond_2gib_row_banded(cv):
     assert torch.equal(g4[lo + 6:hi - 6], g4s[6:-6]) and torch.equal(h4[lo + 6:hi - 6], h4s[6:-6])
     g4s, h4s = s4.setup_steer(sub[rows2 - 100:], -0.7)
     assert torch.equal(g4[rows2 - 94:], g4s[6:]) and torch.equal(h4[rows2 - 94:], h4s[6:])
+
+
+def test_narrow_view_of_a_2gib_plane_small_state(cv, ora):
+    """A narrow column view of a plane of 2 GiB and more: the state block is small (single-resource form
+    eligible) but the caller's input / output pitch forces row bands.  The banded launches must honour the band
+    (the single-resource form ignored row_lo / row_base and rewrote rows at the seam).  Checked
+    against the oracle at the top, at the band seam and at the bottom rows, for G2 (+ steer into a strided
+    output) and G4."""
+    import torch
+    rows, big_cols, cols, W = 16400, 32768, 1024, 4        # 16400 x 32768 f32 = 2.15 GB: two bands
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    big = torch.rand((rows, big_cols), device="cuda", generator=gen)
+    out_big = torch.empty((2, rows, big_cols), device="cuda")
+    view = big[:, 4096:4096 + cols]
+    f = cv.SteerableFiltersG2(None)
+    g, h = f.setup_steer(view, 0.3, out=(out_big[0][:, :cols], out_big[1][:, 64:64 + cols]))
+    whole = cv.SteerableFiltersG2(None)                    # same pixels from a compact copy: one launch, no bands
+    gw, hw = whole.setup_steer(view.contiguous(), 0.3)
+    assert torch.equal(g, gw) and torch.equal(h, hw)
+    for p in range(7):
+        assert torch.equal(f.basis(p), whole.basis(p)), p
+    band = 0x7ffffff0 // (big_cols * 4) - 2 * W
+    seam = band // 19 * 19
+    assert 0 < seam < rows
+    host = view.cpu().numpy()
+    for lo, hi in ((0, 64), (seam - 40, seam + 40), (rows - 64, rows)):
+        lo_h, hi_h = max(0, lo - 2 * W), min(rows, hi + 2 * W)  # halo rows so the crop filters like the whole image
+        truth = ora.basis(2, np.ascontiguousarray(host[lo_h:hi_h]), 4, 0.67, f64=True)
+        keep_lo = 0 if lo_h == 0 else W
+        keep_hi = (hi_h - lo_h) if hi_h == rows else (hi_h - lo_h) - W
+        for p in (0, 3, 6):
+            got = f.basis(p)[lo_h + keep_lo:lo_h + keep_hi].cpu().numpy()
+            assert np.abs(got - truth[p][keep_lo:keep_hi]).max() <= TOL, (lo, hi, p)
+    f4 = cv.SteerableFiltersG4(None)
+    g4, h4 = f4.setup_steer(view, -0.7)
+    w4 = cv.SteerableFiltersG4(None)
+    g4w, h4w = w4.setup_steer(view.contiguous(), -0.7)
+    assert torch.equal(g4, g4w) and torch.equal(h4, h4w)
+    for p in (0, 5, 10):
+        assert torch.equal(f4.basis(p), w4.basis(p)), p
 
 
 def test_placement_search_keeps_results_and_state(cv):
