@@ -56,6 +56,7 @@ SIGNATURES = {
     "cvs_sync": (C.c_int, [C.c_void_p]),
     "cvs_setup": (C.c_int, [C.c_void_p, _PP, C.c_uint]),
     "cvs_setup_steer": (C.c_int, [C.c_void_p, _PP, C.c_uint, C.c_float, _PP, _PP]),
+    "cvs_setup_rows": (C.c_int, [C.c_void_p, _PP, C.c_uint, C.c_int, C.c_int]),
     "cvs_state_plane": (C.c_int, [C.c_void_p, C.c_int, _PP]),
     "cvs_read_state": (C.c_int, [C.c_void_p, C.c_int, _PP]),
     "cvs_steer_scalar": (C.c_int, [C.c_void_p, C.c_float, _PP, _PP, _PP, _PP, _PP]),
@@ -73,6 +74,36 @@ SIGNATURES = {
     "cvs_normalize_u8": (C.c_int, [C.c_void_p, _PP, C.c_void_p, C.c_size_t, C.c_int]),
     "cvs_convert_u8": (C.c_int, [C.c_void_p, _PP, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_int]),
 }
+
+
+
+class BatchCfg(C.Structure):
+    """struct cvs_batch_cfg"""
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("n_frames", C.c_int32), ("outputs", C.c_uint32),
+                ("root", C.c_int32), ("gather", C.c_int32), ("self_via_transport", C.c_int32)]
+
+
+class BatchTiming(C.Structure):
+    """struct cvs_batch_timing"""
+    _fields_ = [("scatter_ms", C.c_double), ("compute_ms", C.c_double), ("gather_ms", C.c_double)]
+
+
+BATCH_ID_BYTES = 128
+TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1, 2
+_VPP = C.POINTER(C.c_void_p)
+SIGNATURES.update({
+    "cvs_batch_create_local": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, _IP, _VPP]),
+    "cvs_batch_unique_id": (C.c_int, [C.c_void_p]),
+    "cvs_batch_create_rank": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, _VPP]),
+    "cvs_batch_destroy": (C.c_int, [C.c_void_p]),
+    "cvs_batch_last_error": (C.c_char_p, [C.c_void_p]),
+    "cvs_batch_info": (C.c_int, [C.c_void_p, _IP, _IP, _IP]),
+    "cvs_batch_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cvs_batch_run": (C.c_int, [C.c_void_p, C.POINTER(BatchCfg), _PP, _PP, C.POINTER(BatchTiming)]),
+    "cvs_batch_local_result": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(_FP), _IP, _IP, _IP, _IP]),
+    "cvs_batch_pyramid_setup": (C.c_int, [C.c_void_p, _PP, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(BatchTiming)]),
+    "cvs_batch_level": (C.c_int, [C.c_void_p, C.c_int, _VPP, _PP]),
+})
 
 _lib = None
 

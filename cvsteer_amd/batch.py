@@ -107,3 +107,144 @@ def run_sharded(frames_on_root, n_frames, frame_shape, device, frame_fn, n_outpu
     local = scatter_frames(frames_on_root, n_frames, frame_shape, device, root, group)
     result = process_frames(local, frame_fn, n_outputs)
     return result, (gather_planes(result, n_frames, root, group) if gather else None)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Native path: a binding of cvs_batch_* (cvsteer_amd/csrc/cvs_batch.cpp).  Sharding, staging, the per-rank launch
+# and the RCCL calls (ncclSend / ncclRecv groups, ncclBroadcast) all happen in the library; this class only hands
+# over pointers.  The torch.distributed functions above are the same plan expressed with torch collectives -- they
+# exist so that the N > 1 bookkeeping can be tested on CPU (gloo); on a GPU box the native path is the product.
+# ----------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+
+import numpy as _np
+
+from . import _lib as _L
+from ._lib import CvsError as _CvsError
+
+
+class NativeBatch:
+    """The batch axis of example/steer.cpp:169 over the GPUs of one node, through the C ABI.
+
+    NativeBatch.local(devices)            -- this process drives all listed devices (ncclCommInitAll)
+    NativeBatch.from_torch_distributed()  -- one process per GPU: rank 0 makes the RCCL id, torch.distributed
+                                             (already initialised) carries the 128 bytes to the other ranks
+    """
+
+    def __init__(self, handle, world, rank, device):
+        self._b, self.world, self.rank, self.device = handle, world, rank, device
+
+    # -- construction --
+    @classmethod
+    def local(cls, devices=(0,), kind=_L.KIND_G2, width=4, spacing=0.67):
+        devs = (_C.c_int * len(devices))(*[int(d) for d in devices])
+        h = _C.c_void_p()
+        rc = _L.lib().cvs_batch_create_local(kind, width, spacing, len(devices), devs, _C.byref(h))
+        return cls._made(rc, h, len(devices), 0, int(devices[0]), "cvs_batch_create_local")
+
+    @classmethod
+    def from_torch_distributed(cls, device, kind=_L.KIND_G2, width=4, spacing=0.67, group=None):
+        world, rank = _group_info(group)
+        ident = (_C.c_char * _L.BATCH_ID_BYTES)()
+        if rank == 0:
+            rc = _L.lib().cvs_batch_unique_id(ident)
+            if rc:
+                raise _CvsError(rc, "cvs_batch_unique_id", "RCCL could not be loaded")
+        box = [bytes(ident)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        ident = (_C.c_char * _L.BATCH_ID_BYTES).from_buffer_copy(box[0])
+        h = _C.c_void_p()
+        rc = _L.lib().cvs_batch_create_rank(kind, width, spacing, ident, world, rank, int(device), _C.byref(h))
+        return cls._made(rc, h, world, rank, int(device), "cvs_batch_create_rank")
+
+    @classmethod
+    def _made(cls, rc, h, world, rank, device, where):
+        if rc:
+            msg = _L.lib().cvs_batch_last_error(h).decode() if h else ""
+            if h:
+                _L.lib().cvs_batch_destroy(h)
+            raise _CvsError(rc, where, msg)
+        return cls(h, world, rank, device)
+
+    def close(self):
+        h, self._b = getattr(self, "_b", None), None
+        if h:
+            _L.lib().cvs_batch_destroy(h)
+
+    __del__ = close
+
+    def _check(self, rc, where):
+        if rc:
+            raise _CvsError(rc, where, _L.lib().cvs_batch_last_error(self._b).decode())
+
+    @property
+    def transport(self):
+        w, n, t = _C.c_int(), _C.c_int(), _C.c_int()
+        self._check(_L.lib().cvs_batch_info(self._b, _C.byref(w), _C.byref(n), _C.byref(t)), "cvs_batch_info")
+        return {_L.TRANSPORT_NONE: "none", _L.TRANSPORT_RCCL: "rccl", _L.TRANSPORT_COPY: "device copies (rehearsal)"}[t.value]
+
+    def set_persist(self, on):
+        self._check(_L.lib().cvs_batch_set_option(self._b, _L.OPT_PERSIST_STATE, 1 if on else 0), "cvs_batch_set_option")
+
+    # -- config 4 --
+    def run(self, frames, n_frames, frame_shape, outputs=(5, 6, 7), out=None, root=0, gather=True, self_via_transport=False):
+        """frames: [n_frames, H, W] float32 CUDA tensor on the root (None elsewhere).  Returns
+        (out [n_frames, len(outputs), H, W] on the root or None, {'scatter','compute','gather'} milliseconds)."""
+        rows, cols = (int(v) for v in frame_shape)
+        sel = [int(k) for k in outputs]
+        cfg = _L.BatchCfg(rows, cols, int(n_frames), sum(1 << k for k in sel), int(root), 1 if gather else 0, 1 if self_via_transport else 0)
+        imgs = outs = None
+        is_root = frames is not None
+        if is_root:
+            assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and tuple(frames.shape) == (n_frames, rows, cols)
+            from .api import _PLANE_DTYPE
+            imgs = _np.zeros(n_frames, _PLANE_DTYPE)
+            imgs["data"] = frames.data_ptr() + _np.arange(n_frames, dtype=_np.uint64) * _np.uint64(rows * cols * 4)
+            imgs["rows"], imgs["cols"], imgs["step"], imgs["mem"] = rows, cols, cols * 4, _L.MEM_DEVICE
+            if gather:
+                if out is None:
+                    out = torch.empty((n_frames, len(sel), rows, cols), dtype=torch.float32, device=frames.device)
+                assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (n_frames, len(sel), rows, cols)
+                outs = _np.zeros((n_frames, 8), _PLANE_DTYPE)
+                off = _np.arange(n_frames, dtype=_np.uint64) * _np.uint64(len(sel) * rows * cols * 4)
+                for j, k in enumerate(sel):
+                    outs["data"][:, k] = out.data_ptr() + off + _np.uint64(j * rows * cols * 4)
+                    outs["rows"][:, k], outs["cols"][:, k], outs["step"][:, k], outs["mem"][:, k] = rows, cols, cols * 4, _L.MEM_DEVICE
+            torch.cuda.current_stream(frames.device).synchronize()  # the library works on its own streams
+        t = _L.BatchTiming()
+        rc = _L.lib().cvs_batch_run(self._b, _C.byref(cfg), imgs.ctypes.data_as(_L._PP) if imgs is not None else None,
+                                    outs.ctypes.data_as(_L._PP) if outs is not None else None, _C.byref(t))
+        self._check(rc, "cvs_batch_run")
+        return (out if (is_root and gather) else None), {"scatter": t.scatter_ms, "compute": t.compute_ms, "gather": t.gather_ms}
+
+    # -- config 3 --
+    def pyramid_setup(self, image, rows, cols, levels, flags=1, root=0):
+        """image: [H, W] float32 CUDA tensor on the root (None elsewhere).  Returns timing in milliseconds."""
+        pl = None
+        if image is not None:
+            assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous() and tuple(image.shape) == (rows, cols)
+            pl = _L.Plane(image.data_ptr(), rows, cols, cols * 4, _L.MEM_DEVICE)
+            torch.cuda.current_stream(image.device).synchronize()
+        t = _L.BatchTiming()
+        rc = _L.lib().cvs_batch_pyramid_setup(self._b, _C.byref(pl) if pl is not None else None, int(rows), int(cols), int(levels),
+                                              int(flags), int(root), _C.byref(t))
+        self._check(rc, "cvs_batch_pyramid_setup")
+        self._keep = image
+        return {"broadcast": t.scatter_ms, "compute": t.compute_ms, "gather": t.gather_ms}
+
+    def level_plane(self, level, which):
+        """root only: state plane `which` (cvs_lib PLANE_*) of pyramid level `level`, copied into a new CUDA tensor"""
+        h = _C.c_void_p()
+        self._check(_L.lib().cvs_batch_level(self._b, int(level), _C.byref(h), None), "cvs_batch_level")
+        v = _L.Plane()
+        rc = _L.lib().cvs_state_plane(h, int(which), _C.byref(v))
+        if rc:
+            raise _CvsError(rc, "cvs_state_plane", _L.lib().cvs_last_error(h).decode())
+        out = torch.empty((v.rows, v.cols), dtype=torch.float32, device=torch.device("cuda", self.device))
+        dst = _L.Plane(out.data_ptr(), v.rows, v.cols, v.cols * 4, _L.MEM_DEVICE)
+        rc = _L.lib().cvs_read_state(h, int(which), _C.byref(dst))
+        if rc:
+            raise _CvsError(rc, "cvs_read_state", _L.lib().cvs_last_error(h).decode())
+        _L.lib().cvs_sync(h)
+        return out

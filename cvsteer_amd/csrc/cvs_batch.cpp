@@ -1,0 +1,656 @@
+// cvs_batch.cpp -- the batch axis over the GPUs of one node, natively (BASELINE configs 3 and 4).
+//
+// The reference's only parallel axis is independent images: example/steer.cpp:169 runs
+// cv::parallel_for_(Range(0, N), body) with one fa::SteerableFiltersG2 per file (steer.cpp:69-124).  Here that
+// axis is spread over GPUs: frame f of F belongs to rank floor(f * G / F) (contiguous blocks), every rank runs the
+// fused pipeline on its block with NO collective on the data path, and RCCL moves data only at the edges:
+//   * cvs_batch_run:            grouped ncclSend / ncclRecv from the root (scatter of input frames) and to the root
+//                               (gather of the requested output planes) -- one point-to-point xGMI link per peer;
+//   * cvs_batch_pyramid_setup:  one large image (+ its Gaussian pyramid): ncclBroadcast of the image, every rank
+//                               filters its band of rows of every level (cvs_setup_rows; halo rows are read from the
+//                               broadcast copy, so there is no exchange step), bands gathered into the root's state.
+// Two ways to form the world: one process driving several devices (ncclCommInitAll), or one process per GPU
+// (ncclCommInitRank with an id the caller distributes -- torch.distributed, MPI, a file).
+//
+// Built on the public single-GPU ABI only (cvs_create, cvs_pipeline_batch, cvs_setup_rows, ...).  RCCL is loaded at
+// run time (dlopen of librccl.so.1, whichever copy the process already has) so that single-GPU users of the library
+// do not need it.  Rehearsal: when a device is listed more than once (a one-GPU box standing in for several ranks)
+// RCCL cannot be used -- it refuses two ranks on one device -- and the transport falls back to stream-ordered
+// device copies; `cvs_batch_info` reports which transport is in use.
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cvsteer_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------- RCCL, lazily
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl* rccl(std::string* why = nullptr)
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = std::getenv("CVS_RCCL_LIB");
+        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.so) break;
+        }
+        if (!r.so) {
+            r.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+            return;
+        }
+        bool ok = true;
+        auto sym = [&](const char* name) {
+            void* p = dlsym(r.so, name);
+            if (!p) { ok = false; r.why = std::string("librccl lacks ") + name; }
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) {
+            dlclose(r.so);
+            r.so = nullptr;
+        }
+    });
+    if (!r.so && why) *why = r.why;
+    return r.so ? &r : nullptr;
+}
+
+// contiguous block [lo, hi) of `rank`: item f belongs to rank floor(f * world / n)
+void shard_range(int n, int world, int rank, int* lo, int* hi)
+{
+    *lo = (int)(((long long)rank * n + world - 1) / world);
+    *hi = (int)(((long long)(rank + 1) * n + world - 1) / world);
+}
+
+enum { TRANSPORT_NONE = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2 };
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t elems = 0;
+};
+
+// one rank this process drives
+struct Slot {
+    int rank = 0, device = 0;
+    hipStream_t stream = nullptr;
+    cvs_handle h = nullptr;                 // the frame batch engine
+    std::vector<cvs_handle> level;          // pyramid: one handle per level
+    std::vector<DevBuf> level_img;          // pyramid: levels 1.. (level 0 = the broadcast image)
+    ncclComm_t comm = nullptr;
+    DevBuf in, out, image;                  // staging: input frames / output planes of this rank's shard; broadcast image
+    int last_n = 0, last_k = 0, last_rows = 0, last_cols = 0;  // layout of `out` after the last cvs_batch_run
+    bool last_staged = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+}  // namespace
+
+struct cvs_batch_context {
+    int kind = 0, width = 0, world = 0, transport = TRANSPORT_NONE;
+    float spacing = 0.f;
+    std::vector<Slot> slots;  // local ranks, ascending
+    // pyramid state of the last cvs_batch_pyramid_setup
+    int pyr_levels = 0, pyr_root = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(cvs_batch b, int code, const std::string& what)
+{
+    if (b) b->err = what;
+    return code;
+}
+
+#define B_HIP(b, expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) return fail(b, e__ == hipErrorOutOfMemory ? CVS_E_NOMEM : CVS_E_HIP,      \
+                                           std::string(#expr) + ": " + hipGetErrorString(e__));         \
+    } while (0)
+
+#define B_NCCL(b, expr)                                                                                  \
+    do {                                                                                                 \
+        ncclResult_t r__ = (expr);                                                                       \
+        if (r__ != ncclSuccess) return fail(b, CVS_E_HIP, std::string(#expr) + ": " + rccl()->GetErrorString(r__)); \
+    } while (0)
+
+#define B_CVS(b, h, expr)                                                                                \
+    do {                                                                                                 \
+        int rc__ = (expr);                                                                               \
+        if (rc__ != CVS_OK) return fail(b, rc__, std::string(#expr) + ": " + cvs_last_error(h));         \
+    } while (0)
+
+int reserve(cvs_batch b, Slot& s, DevBuf& buf, size_t elems)
+{
+    if (elems <= buf.elems) return CVS_OK;
+    B_HIP(b, hipSetDevice(s.device));
+    if (buf.p) {
+        B_HIP(b, hipStreamSynchronize(s.stream));
+        B_HIP(b, hipFree(buf.p));
+        buf = DevBuf();
+    }
+    B_HIP(b, hipMalloc(&buf.p, elems * sizeof(float)));
+    buf.elems = elems;
+    return CVS_OK;
+}
+
+Slot* local(cvs_batch b, int rank)
+{
+    for (Slot& s : b->slots)
+        if (s.rank == rank) return &s;
+    return nullptr;
+}
+
+int init_slot(cvs_batch b, Slot& s)
+{
+    B_HIP(b, hipSetDevice(s.device));
+    B_HIP(b, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : s.ev) B_HIP(b, hipEventCreate(&e));
+    int rc = cvs_create(b->kind, b->width, b->spacing, s.device, &s.h);
+    if (rc != CVS_OK) return fail(b, rc, "cvs_create");
+    B_CVS(b, s.h, cvs_set_stream(s.h, s.stream));
+    return CVS_OK;
+}
+
+// ---- transport: point-to-point moves between ranks, enqueued on the ranks' streams ----
+// A "move" = count floats from (src_rank, src) to (dst_rank, dst).  Both ends are queued inside one group; with RCCL an
+// end that is not local to this process is simply not queued here (its own process queues it).
+struct Move {
+    int src_rank, dst_rank;
+    const float* src;
+    float* dst;
+    size_t count;
+};
+
+int run_moves(cvs_batch b, const std::vector<Move>& moves)
+{
+    if (moves.empty()) return CVS_OK;
+    if (b->transport == TRANSPORT_RCCL) {
+        Rccl* R = rccl();
+        B_NCCL(b, R->GroupStart());
+        for (const Move& m : moves) {
+            if (Slot* s = local(b, m.src_rank)) {
+                B_HIP(b, hipSetDevice(s->device));
+                B_NCCL(b, R->Send(m.src, m.count, ncclFloat, m.dst_rank, s->comm, s->stream));
+            }
+            if (Slot* d = local(b, m.dst_rank)) {
+                B_HIP(b, hipSetDevice(d->device));
+                B_NCCL(b, R->Recv(m.dst, m.count, ncclFloat, m.src_rank, d->comm, d->stream));
+            }
+        }
+        B_NCCL(b, R->GroupEnd());
+        return CVS_OK;
+    }
+    // rehearsal transport (ranks sharing a device, one process): the copy runs on the destination's stream after an
+    // event on the source's stream -- the same ordering a send / recv pair gives
+    for (const Move& m : moves) {
+        Slot* s = local(b, m.src_rank);
+        Slot* d = local(b, m.dst_rank);
+        if (!s || !d) return fail(b, CVS_E_UNSUPPORTED, "copy transport needs both ranks in this process");
+        B_HIP(b, hipSetDevice(s->device));
+        hipEvent_t e;
+        B_HIP(b, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        B_HIP(b, hipEventRecord(e, s->stream));
+        B_HIP(b, hipSetDevice(d->device));
+        B_HIP(b, hipStreamWaitEvent(d->stream, e, 0));
+        B_HIP(b, hipMemcpyAsync(m.dst, m.src, m.count * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+        // the source must not be overwritten before the copy has run: order the source stream behind it
+        hipEvent_t done;
+        B_HIP(b, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        B_HIP(b, hipEventRecord(done, d->stream));
+        B_HIP(b, hipSetDevice(s->device));
+        B_HIP(b, hipStreamWaitEvent(s->stream, done, 0));
+        B_HIP(b, hipEventDestroy(e));
+        B_HIP(b, hipEventDestroy(done));
+    }
+    return CVS_OK;
+}
+
+int record_all(cvs_batch b, int which)
+{
+    for (Slot& s : b->slots) {
+        B_HIP(b, hipSetDevice(s.device));
+        B_HIP(b, hipEventRecord(s.ev[which], s.stream));
+    }
+    return CVS_OK;
+}
+
+int sync_all(cvs_batch b)
+{
+    for (Slot& s : b->slots) {
+        B_HIP(b, hipSetDevice(s.device));
+        B_HIP(b, hipStreamSynchronize(s.stream));
+    }
+    return CVS_OK;
+}
+
+void fill_timing(cvs_batch b, cvs_batch_timing* t)
+{
+    if (!t) return;
+    t->scatter_ms = t->compute_ms = t->gather_ms = 0.0;
+    for (Slot& s : b->slots) {
+        float ms[3] = {0.f, 0.f, 0.f};
+        (void)hipSetDevice(s.device);
+        for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms[i], s.ev[i], s.ev[i + 1]);
+        t->scatter_ms = std::max(t->scatter_ms, (double)ms[0]);
+        t->compute_ms = std::max(t->compute_ms, (double)ms[1]);
+        t->gather_ms = std::max(t->gather_ms, (double)ms[2]);
+    }
+}
+
+// is `p` a dense rows x cols f32 device plane (no row padding)?
+bool dense_device(const cvs_plane* p, int rows, int cols)
+{
+    return p && p->data && p->mem == CVS_MEM_DEVICE && p->rows == rows && p->cols == cols && p->step == (size_t)cols * sizeof(float);
+}
+
+int create_common(int kind, int width, float spacing, cvs_batch* out, cvs_batch* made)
+{
+    if (!out) return CVS_E_BADARG;
+    *out = nullptr;
+    if (cvs_num_basis(kind) == 0 || width < 1) return CVS_E_BADARG;
+    cvs_batch b = new (std::nothrow) cvs_batch_context();
+    if (!b) return CVS_E_NOMEM;
+    b->kind = kind;
+    b->width = width;
+    b->spacing = spacing;
+    *made = b;
+    return CVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cvs_batch_create_local(int kind, int width, float spacing, int ndev, const int* devices, cvs_batch* out)
+{
+    cvs_batch b = nullptr;
+    int rc = create_common(kind, width, spacing, out, &b);
+    if (rc) return rc;
+    if (ndev < 1 || !devices) { delete b; return CVS_E_BADARG; }
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) { delete b; return CVS_E_HIP; }  // no CPU fallback
+    bool dup = false;
+    for (int i = 0; i < ndev; ++i) {
+        if (devices[i] < 0 || devices[i] >= have) { delete b; return CVS_E_BADARG; }
+        for (int j = 0; j < i; ++j) dup = dup || devices[j] == devices[i];
+    }
+    b->world = ndev;
+    b->slots.resize(ndev);
+    for (int i = 0; i < ndev; ++i) {
+        b->slots[i].rank = i;
+        b->slots[i].device = devices[i];
+        if ((rc = init_slot(b, b->slots[i]))) { *out = b; return rc; }  // caller reads the error, then destroys
+    }
+    if (dup) {
+        b->transport = TRANSPORT_COPY;   // rehearsal: several ranks on one device
+    } else {
+        std::string why;
+        Rccl* R = rccl(&why);
+        if (!R) {
+            if (ndev == 1) b->transport = TRANSPORT_NONE;  // one rank needs no transport at all
+            else { *out = b; return fail(b, CVS_E_HIP, "RCCL is not available: " + why); }
+        } else {
+            std::vector<ncclComm_t> comms(ndev);
+            ncclResult_t r = R->CommInitAll(comms.data(), ndev, devices);
+            if (r != ncclSuccess) { *out = b; return fail(b, CVS_E_HIP, std::string("ncclCommInitAll: ") + R->GetErrorString(r)); }
+            for (int i = 0; i < ndev; ++i) b->slots[i].comm = comms[i];
+            b->transport = TRANSPORT_RCCL;
+        }
+    }
+    *out = b;
+    return CVS_OK;
+}
+
+int cvs_batch_unique_id(void* id128)
+{
+    if (!id128) return CVS_E_BADARG;
+    Rccl* R = rccl();
+    if (!R) return CVS_E_HIP;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return CVS_E_HIP;
+    static_assert(sizeof(id) == CVS_BATCH_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(id128, &id, sizeof(id));
+    return CVS_OK;
+}
+
+int cvs_batch_create_rank(int kind, int width, float spacing, const void* id128, int world, int rank, int device, cvs_batch* out)
+{
+    cvs_batch b = nullptr;
+    int rc = create_common(kind, width, spacing, out, &b);
+    if (rc) return rc;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { delete b; return CVS_E_BADARG; }
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) { delete b; return CVS_E_HIP; }
+    if (device < 0 || device >= have) { delete b; return CVS_E_BADARG; }
+    b->world = world;
+    b->slots.resize(1);
+    b->slots[0].rank = rank;
+    b->slots[0].device = device;
+    *out = b;
+    if ((rc = init_slot(b, b->slots[0]))) return rc;
+    std::string why;
+    Rccl* R = rccl(&why);
+    if (!R) return fail(b, CVS_E_HIP, "RCCL is not available: " + why);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    B_HIP(b, hipSetDevice(device));
+    ncclResult_t r = R->CommInitRank(&b->slots[0].comm, world, id, rank);
+    if (r != ncclSuccess) return fail(b, CVS_E_HIP, std::string("ncclCommInitRank: ") + R->GetErrorString(r));
+    b->transport = TRANSPORT_RCCL;
+    return CVS_OK;
+}
+
+int cvs_batch_destroy(cvs_batch b)
+{
+    if (!b) return CVS_E_BADARG;
+    for (Slot& s : b->slots) {
+        (void)hipSetDevice(s.device);
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.comm && rccl()) (void)rccl()->CommDestroy(s.comm);
+        if (s.h) (void)cvs_destroy(s.h);
+        for (cvs_handle h : s.level)
+            if (h) (void)cvs_destroy(h);
+        for (DevBuf& d : s.level_img)
+            if (d.p) (void)hipFree(d.p);
+        for (DevBuf* d : {&s.in, &s.out, &s.image})
+            if (d->p) (void)hipFree(d->p);
+        for (hipEvent_t e : s.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete b;
+    return CVS_OK;
+}
+
+const char* cvs_batch_last_error(cvs_batch b) { return b ? b->err.c_str() : "null batch"; }
+
+int cvs_batch_info(cvs_batch b, int* world, int* nlocal, int* transport)
+{
+    if (!b) return CVS_E_BADARG;
+    if (world) *world = b->world;
+    if (nlocal) *nlocal = (int)b->slots.size();
+    if (transport) *transport = b->transport;
+    return CVS_OK;
+}
+
+int cvs_batch_set_option(cvs_batch b, int option, int value)
+{
+    if (!b) return CVS_E_BADARG;
+    for (Slot& s : b->slots) B_CVS(b, s.h, cvs_set_option(s.h, option, value));
+    return CVS_OK;
+}
+
+int cvs_batch_run(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, const cvs_plane* outputs, cvs_batch_timing* timing)
+{
+    if (!b || !cfg) return CVS_E_BADARG;
+    if (b->kind != CVS_KIND_G2) return fail(b, CVS_E_UNSUPPORTED, "the caller pipeline exists for G2 only");
+    const int rows = cfg->rows, cols = cfg->cols, F = cfg->n_frames, root = cfg->root;
+    if (rows <= 0 || cols <= 0 || F < 1) return fail(b, CVS_E_SIZE, "empty batch");
+    if (root < 0 || root >= b->world) return fail(b, CVS_E_BADARG, "root");
+    if (!(cfg->outputs & 0xffu)) return fail(b, CVS_E_BADARG, "no output requested");
+    int sel[8], K = 0;
+    for (int k = 0; k < 8; ++k)
+        if (cfg->outputs & (1u << k)) sel[K++] = k;
+    const size_t plane = (size_t)rows * cols;
+    Slot* rs = local(b, root);
+    const bool via = cfg->self_via_transport != 0 && b->transport != TRANSPORT_NONE;
+    if (rs) {
+        if (!inputs) return fail(b, CVS_E_BADARG, "the root rank needs the input frames");
+        if (cfg->gather && !outputs) return fail(b, CVS_E_BADARG, "the root rank needs output planes to gather into");
+        for (int f = 0; f < F; ++f) {
+            if (!dense_device(&inputs[f], rows, cols)) return fail(b, CVS_E_SIZE, "input frames must be dense f32 device planes of rows x cols");
+            for (int j = 0; cfg->gather && j < K; ++j)
+                if (!dense_device(&outputs[(size_t)f * 8 + sel[j]], rows, cols))
+                    return fail(b, CVS_E_SIZE, "requested output planes must be dense f32 device planes of rows x cols");
+        }
+    }
+    if (b->world > 1 && b->transport == TRANSPORT_NONE) return fail(b, CVS_E_HIP, "no transport");
+    int rc;
+    // staging on every local rank that does not work in place
+    for (Slot& s : b->slots) {
+        int lo, hi;
+        shard_range(F, b->world, s.rank, &lo, &hi);
+        const size_t n = (size_t)(hi - lo);
+        const bool in_place = s.rank == root && !via;
+        if (!in_place && n && (rc = reserve(b, s, s.in, n * plane))) return rc;
+        // the root writes its own shard straight into the caller's planes when it gathers; everybody else stages
+        const bool out_in_place = s.rank == root && cfg->gather && !via;
+        if (!out_in_place && n && (rc = reserve(b, s, s.out, n * K * plane))) return rc;
+    }
+    if ((rc = record_all(b, 0))) return rc;
+    // ---- scatter: root -> ranks, frame by frame (a frame is one contiguous message) ----
+    {
+        std::vector<Move> mv;
+        for (int r = 0; r < b->world; ++r) {
+            if (r == root && !via) continue;
+            int lo, hi;
+            shard_range(F, b->world, r, &lo, &hi);
+            Slot* d = local(b, r);
+            for (int f = lo; f < hi; ++f)
+                mv.push_back({root, r, rs ? inputs[f].data : nullptr, d ? d->in.p + (size_t)(f - lo) * plane : nullptr, plane});
+        }
+        if ((rc = run_moves(b, mv))) return rc;
+    }
+    if ((rc = record_all(b, 1))) return rc;
+    // ---- compute: the fused pipeline on every local rank's block, one launch per rank ----
+    for (Slot& s : b->slots) {
+        int lo, hi;
+        shard_range(F, b->world, s.rank, &lo, &hi);
+        const int n = hi - lo;
+        if (!n) continue;
+        const bool in_place = s.rank == root && !via;
+        const bool out_in_place = s.rank == root && cfg->gather && !via;
+        std::vector<cvs_plane> im(n), ou((size_t)n * 8);
+        std::memset(ou.data(), 0, ou.size() * sizeof(cvs_plane));
+        for (int i = 0; i < n; ++i) {
+            im[i] = in_place ? inputs[lo + i] : cvs_plane{s.in.p + (size_t)i * plane, rows, cols, (size_t)cols * sizeof(float), CVS_MEM_DEVICE};
+            for (int j = 0; j < K; ++j)
+                ou[(size_t)i * 8 + sel[j]] = out_in_place ? outputs[(size_t)(lo + i) * 8 + sel[j]]
+                                                          : cvs_plane{s.out.p + ((size_t)i * K + j) * plane, rows, cols, (size_t)cols * sizeof(float), CVS_MEM_DEVICE};
+        }
+        B_CVS(b, s.h, cvs_pipeline_batch(s.h, im.data(), n, ou.data()));
+        s.last_n = n;
+        s.last_k = K;
+        s.last_rows = rows;
+        s.last_cols = cols;
+        s.last_staged = !out_in_place;
+    }
+    if ((rc = record_all(b, 2))) return rc;
+    // ---- gather: ranks -> root, plane by plane ----
+    if (cfg->gather) {
+        std::vector<Move> mv;
+        for (int r = 0; r < b->world; ++r) {
+            if (r == root && !via) continue;
+            int lo, hi;
+            shard_range(F, b->world, r, &lo, &hi);
+            Slot* s = local(b, r);
+            for (int f = lo; f < hi; ++f)
+                for (int j = 0; j < K; ++j)
+                    mv.push_back({r, root, s ? s->out.p + ((size_t)(f - lo) * K + j) * plane : nullptr,
+                                  rs ? outputs[(size_t)f * 8 + sel[j]].data : nullptr, plane});
+        }
+        if ((rc = run_moves(b, mv))) return rc;
+    }
+    if ((rc = record_all(b, 3))) return rc;
+    if ((rc = sync_all(b))) return rc;   // outputs are on the root when the call returns
+    fill_timing(b, timing);
+    return CVS_OK;
+}
+
+int cvs_batch_local_result(cvs_batch b, int rank, float** data, int* n_frames, int* n_planes, int* rows, int* cols)
+{
+    if (!b || !data) return CVS_E_BADARG;
+    Slot* s = local(b, rank);
+    if (!s) return fail(b, CVS_E_BADARG, "rank is not local to this process");
+    if (!s->last_staged) return fail(b, CVS_E_STATE, "this rank wrote its block straight into the caller's planes");
+    *data = s->out.p;
+    if (n_frames) *n_frames = s->last_n;
+    if (n_planes) *n_planes = s->last_k;
+    if (rows) *rows = s->last_rows;
+    if (cols) *cols = s->last_cols;
+    return CVS_OK;
+}
+
+int cvs_batch_pyramid_setup(cvs_batch b, const cvs_plane* image, int rows, int cols, int levels, unsigned flags, int root,
+                            cvs_batch_timing* timing)
+{
+    if (!b) return CVS_E_BADARG;
+    if (rows <= 0 || cols <= 0 || levels < 1 || levels > 16) return fail(b, CVS_E_BADARG, "pyramid geometry");
+    if (root < 0 || root >= b->world) return fail(b, CVS_E_BADARG, "root");
+    if (b->world > 1 && b->transport == TRANSPORT_NONE) return fail(b, CVS_E_HIP, "no transport");
+    if (!(flags & CVS_SETUP_BASIS)) flags |= CVS_SETUP_BASIS;
+    Slot* rs = local(b, root);
+    if (rs && !dense_device(image, rows, cols)) return fail(b, CVS_E_SIZE, "the image must be a dense f32 device plane of rows x cols on the root");
+    const int nb = cvs_num_basis(b->kind);
+    const int nplanes = nb + ((flags & CVS_SETUP_ORIENT) ? 5 : 0);
+    std::vector<int> lr(levels), lc(levels);
+    lr[0] = rows;
+    lc[0] = cols;
+    for (int l = 1; l < levels; ++l) {
+        lr[l] = (lr[l - 1] + 1) / 2;
+        lc[l] = (lc[l - 1] + 1) / 2;
+    }
+    int rc;
+    const size_t plane0 = (size_t)rows * cols;
+    for (Slot& s : b->slots) {
+        if (s.rank != root && (rc = reserve(b, s, s.image, plane0))) return rc;
+        while ((int)s.level.size() < levels) {
+            cvs_handle h = nullptr;
+            rc = cvs_create(b->kind, b->width, b->spacing, s.device, &h);
+            if (rc != CVS_OK) return fail(b, rc, "cvs_create (level handle)");
+            B_CVS(b, h, cvs_set_stream(h, s.stream));
+            s.level.push_back(h);
+            s.level_img.push_back(DevBuf());
+        }
+        for (int l = 1; l < levels; ++l)
+            if ((rc = reserve(b, s, s.level_img[l], (size_t)lr[l] * lc[l]))) return rc;
+    }
+    b->pyr_levels = levels;
+    b->pyr_root = root;
+    if ((rc = record_all(b, 0))) return rc;
+    // ---- broadcast of the image: every rank reads its bands AND their halo rows from its own copy ----
+    // CVS_BATCH_SELF_TRANSPORT=1 (tests): a one-rank world still issues the (degenerate) ncclBroadcast
+    const bool self_bcast = b->world == 1 && b->transport == TRANSPORT_RCCL && std::getenv("CVS_BATCH_SELF_TRANSPORT");
+    if (b->world > 1 || self_bcast) {
+        if (b->transport == TRANSPORT_RCCL) {
+            Rccl* R = rccl();
+            B_NCCL(b, R->GroupStart());
+            for (Slot& s : b->slots) {
+                B_HIP(b, hipSetDevice(s.device));
+                const float* src = s.rank == root ? image->data : s.image.p;
+                float* dst = s.rank == root ? image->data : s.image.p;
+                B_NCCL(b, R->Broadcast(src, dst, plane0, ncclFloat, root, s.comm, s.stream));
+            }
+            B_NCCL(b, R->GroupEnd());
+        } else {
+            std::vector<Move> mv;
+            for (Slot& s : b->slots)
+                if (s.rank != root) mv.push_back({root, s.rank, image->data, s.image.p, plane0});
+            if ((rc = run_moves(b, mv))) return rc;
+        }
+    }
+    if ((rc = record_all(b, 1))) return rc;
+    // ---- every rank: the whole pyramid (cheap, redundant), then its band of rows of every level ----
+    for (Slot& s : b->slots) {
+        const float* lvl0 = s.rank == root ? image->data : s.image.p;
+        for (int l = 0; l < levels; ++l) {
+            cvs_plane cur{l == 0 ? const_cast<float*>(lvl0) : s.level_img[l].p, lr[l], lc[l], (size_t)lc[l] * sizeof(float), CVS_MEM_DEVICE};
+            if (l + 1 < levels) {
+                cvs_plane nxt{s.level_img[l + 1].p, lr[l + 1], lc[l + 1], (size_t)lc[l + 1] * sizeof(float), CVS_MEM_DEVICE};
+                B_CVS(b, s.level[l], cvs_pyr_down(s.level[l], &cur, &nxt));
+            }
+            int lo, hi;
+            shard_range(lr[l], b->world, s.rank, &lo, &hi);
+            if (hi > lo) {
+                B_CVS(b, s.level[l], cvs_setup_rows(s.level[l], &cur, flags, lo, hi));
+            } else if (s.rank == root) {
+                // an empty band on the root (a level with fewer rows than ranks): its state planes must still exist at
+                // full size, because the other ranks' bands are received into them -- row 0 is rewritten by the gather
+                B_CVS(b, s.level[l], cvs_setup_rows(s.level[l], &cur, flags, 0, 1));
+            }
+        }
+    }
+    if ((rc = record_all(b, 2))) return rc;
+    // ---- gather of the bands into the root's state planes (rows of a plane are contiguous: one message per plane) ----
+    if (b->world > 1) {
+        std::vector<Move> mv;
+        for (int l = 0; l < levels; ++l) {
+            for (int r = 0; r < b->world; ++r) {
+                if (r == root) continue;
+                int lo, hi;
+                shard_range(lr[l], b->world, r, &lo, &hi);
+                if (hi <= lo) continue;
+                Slot* s = local(b, r);
+                for (int p = 0; p < nplanes; ++p) {
+                    const int which = p < nb ? CVS_PLANE_BASIS0 + p : CVS_PLANE_C1 + (p - nb);
+                    cvs_plane sv{}, dv{};
+                    if (s) B_CVS(b, s->level[l], cvs_state_plane(s->level[l], which, &sv));
+                    if (rs) B_CVS(b, rs->level[l], cvs_state_plane(rs->level[l], which, &dv));
+                    const size_t pitch = (s ? sv.step : dv.step) / sizeof(float);
+                    mv.push_back({r, root, s ? sv.data + (size_t)lo * pitch : nullptr, rs ? dv.data + (size_t)lo * pitch : nullptr,
+                                  (size_t)(hi - lo) * pitch});
+                }
+            }
+        }
+        if ((rc = run_moves(b, mv))) return rc;
+    }
+    if ((rc = record_all(b, 3))) return rc;
+    if ((rc = sync_all(b))) return rc;
+    fill_timing(b, timing);
+    return CVS_OK;
+}
+
+int cvs_batch_level(cvs_batch b, int level, cvs_handle* h, cvs_plane* level_image)
+{
+    if (!b || !h) return CVS_E_BADARG;
+    Slot* rs = local(b, b->pyr_root);
+    if (!rs) return fail(b, CVS_E_STATE, "the gathered state lives on the root rank, which is not local to this process");
+    if (level < 0 || level >= b->pyr_levels) return fail(b, CVS_E_BADARG, "level");
+    *h = rs->level[level];
+    if (level_image) {
+        int r = 0, c = 0;
+        (void)cvs_shape(*h, &r, &c);
+        *level_image = cvs_plane{level == 0 ? nullptr : rs->level_img[level].p, r, c, (size_t)c * sizeof(float), CVS_MEM_DEVICE};
+    }
+    return CVS_OK;
+}
+
+}  // extern "C"

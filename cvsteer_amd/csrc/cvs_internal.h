@@ -42,6 +42,8 @@ struct BasisArgs {
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
+    int out_row_lo, out_row_hi;    // caller: compute output rows [out_row_lo, out_row_hi) only (0, 0 = the whole image);
+                                   // the band-split of one large image over several GPUs (cvs_setup_rows)
     int block_order;      // 0 = row-major grid, 1 = row-major weighted per XCD, T >= 2 = groups of T bands walked column by column
     int xcd_even, xcd_odd; // block_order 1: tiles per period for the even / odd XCDs (see basis_body)
     int grid_x, grid_y;   // filled by the launcher

@@ -723,11 +723,14 @@ template <class F>
 static hipError_t for_each_band(const BasisArgs& a_in, int width, F&& fn)
 {
     const int per = band_rows(a_in, width);
-    for (int lo = 0; lo < a_in.rows; lo += per) {
+    // a caller-given row range (one GPU's band of a large image) is walked exactly like the whole image
+    const int lo0 = a_in.out_row_hi > a_in.out_row_lo ? a_in.out_row_lo : 0;
+    const int hi0 = a_in.out_row_hi > a_in.out_row_lo ? a_in.out_row_hi : a_in.rows;
+    for (int lo = lo0; lo < hi0; lo += per) {
         BasisArgs a = a_in;
         if (a.strip_rows > per) a.strip_rows = per;
         a.row_lo = lo;
-        a.row_hi = lo + per < a.rows ? lo + per : a.rows;
+        a.row_hi = lo + per < hi0 ? lo + per : hi0;
         // the bottom band also reads reflected rows: rows - 2 - k, which lie above row_hi - 1, never below row_base
         a.row_base = lo > width ? lo - width : 0;
         if (per >= a.rows) a.row_base = 0;

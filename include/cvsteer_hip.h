@@ -161,6 +161,13 @@ int cvs_setup(cvs_handle h, const cvs_plane* image, unsigned flags);
 int cvs_setup_steer(cvs_handle h, const cvs_plane* image, unsigned flags, float theta,
                     const cvs_plane* g, const cvs_plane* hq);
 
+/* cvs_setup restricted to the output rows [row_lo, row_hi) of the image: the band one GPU takes when a single large
+ * image (a pyramid level, BASELINE config 3) is split over several GPUs.  The whole image must be
+ * present (the rows around the band are read, the image borders reflect as usual); state rows outside the band keep
+ * whatever they held.  Values inside the band are bit-identical to those of a whole-image cvs_setup.  Images that
+ * take the generic path (non-default taps, tiny images) are filtered whole. */
+int cvs_setup_rows(cvs_handle h, const cvs_plane* image, unsigned flags, int row_lo, int row_hi);
+
 /* device view of a state plane (zero copy; valid until the next setup) */
 int cvs_state_plane(cvs_handle h, int which, cvs_plane* view);
 /* copy a state plane out (getDominantOrientationAngle()/Strength() getters, G2.h:40-41,
@@ -218,6 +225,56 @@ int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst);
 int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem);
 /* Mat::convertTo(dst, CV_8UC1, alpha, beta) -- the `--gain` branch of example/steer.cpp:92-97 */
 int cvs_convert_u8(cvs_handle h, const cvs_plane* src, float alpha, float beta, uint8_t* dst, size_t dst_step, int dst_mem);
+
+/* ---------------- the batch axis over the GPUs of one node (cvs_batch.cpp) ----------------
+ * example/steer.cpp:169 runs cv::parallel_for_(Range(0, N), body): one independent SteerableFiltersG2 pipeline per
+ * file (steer.cpp:69-124).  Here frame f of F belongs to rank floor(f * G / F) (contiguous blocks), every rank runs
+ * cvs_pipeline_batch on its block -- no collective on the data path -- and RCCL moves data only at the edges.
+ * A world is formed either by ONE process driving several devices (cvs_batch_create_local: ncclCommInitAll; a
+ * device listed twice = rehearsal on a smaller box, transport = device copies instead of RCCL) or by one process per
+ * GPU (cvs_batch_unique_id on one rank, the 128 bytes distributed by the caller, cvs_batch_create_rank everywhere).
+ * Every rank of the world calls cvs_batch_run / cvs_batch_pyramid_setup with the same arguments; ranks that do not
+ * hold the root pass NULL planes.  Calls return when the root holds the results. */
+typedef struct cvs_batch_context* cvs_batch;
+enum { CVS_BATCH_ID_BYTES = 128 };
+enum { CVS_BATCH_TRANSPORT_NONE = 0, CVS_BATCH_TRANSPORT_RCCL = 1, CVS_BATCH_TRANSPORT_COPY = 2 };
+
+typedef struct cvs_batch_cfg {
+    int32_t rows, cols;          /* size of every frame */
+    int32_t n_frames;            /* frames in the batch (all of them, on the root) */
+    uint32_t outputs;            /* bit k = pipeline output k is wanted: g2,h2,e,magnitude,phase,edges,dark,bright */
+    int32_t root;                /* rank that holds the inputs and receives the outputs */
+    int32_t gather;              /* 1 = outputs are gathered on the root; 0 = they stay on the ranks (cvs_batch_local_result) */
+    int32_t self_via_transport;  /* tests: the root's own block also travels through send / recv */
+} cvs_batch_cfg;
+
+typedef struct cvs_batch_timing {  /* HIP-event times on the ranks' streams, maximum over this process's ranks */
+    double scatter_ms, compute_ms, gather_ms;
+} cvs_batch_timing;
+
+int cvs_batch_create_local(int kind, int width, float spacing, int ndev, const int* devices, cvs_batch* out);
+int cvs_batch_unique_id(void* id128);
+int cvs_batch_create_rank(int kind, int width, float spacing, const void* id128, int world, int rank, int device, cvs_batch* out);
+int cvs_batch_destroy(cvs_batch b);
+const char* cvs_batch_last_error(cvs_batch b);
+int cvs_batch_info(cvs_batch b, int* world, int* nlocal, int* transport);
+/* cvs_set_option on every engine of the batch (e.g. CVS_OPT_PERSIST_STATE = 0: outputs only) */
+int cvs_batch_set_option(cvs_batch b, int option, int value);
+/* BASELINE config 4 -- the loop of example/steer.cpp:169 over the node: inputs = n_frames dense f32 device planes on the
+ * root, outputs = n_frames * 8 planes on the root, frame-major, order of cvs_pipeline (entries not selected by
+ * cfg->outputs are ignored).  scatter (grouped ncclSend/ncclRecv) -> one cvs_pipeline_batch launch per rank ->
+ * gather (grouped ncclSend/ncclRecv).  The root's own block is processed in place. */
+int cvs_batch_run(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, const cvs_plane* outputs, cvs_batch_timing* timing);
+/* after a run with gather = 0 (or on a non-root rank): this rank's block, [n_frames][n_planes][rows][cols] dense */
+int cvs_batch_local_result(cvs_batch b, int rank, float** data, int* n_frames, int* n_planes, int* rows, int* cols);
+/* BASELINE config 3 -- one large image and its Gaussian pyramid split over the ranks by rows: ncclBroadcast of the
+ * image from the root, every rank builds the (cheap) pyramid and runs cvs_setup_rows on its band of every level, the
+ * bands are gathered into the ROOT's state planes.  Afterwards cvs_batch_level hands out, on the root, one ordinary
+ * handle per level whose state (cvs_state_plane / cvs_read_state / cvs_steer_*) is complete -- bit-identical to a
+ * single-GPU cvs_setup of that level. */
+int cvs_batch_pyramid_setup(cvs_batch b, const cvs_plane* image, int rows, int cols, int levels, unsigned flags, int root,
+                            cvs_batch_timing* timing);
+int cvs_batch_level(cvs_batch b, int level, cvs_handle* h, cvs_plane* level_image);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,218 @@
+"""GPU tests (-m gpu): the native batch layer (cvs_batch_*, cvsteer_amd/csrc/cvs_batch.cpp) -- the batch axis of
+example/steer.cpp:69-124,169 and the row-band split of one large image / pyramid.
+
+A gpurun box has ONE GPU, so:
+  * RCCL itself is exercised in a one-rank world (ncclCommInitAll / ncclCommInitRank with 1 rank): with
+    self_via_transport the root's block really travels through grouped ncclSend / ncclRecv, and the pyramid issues
+    its ncclBroadcast;
+  * the N > 1 bookkeeping (sharding, staging, ordering, band seams, empty shards) runs with several ranks sharing
+    device 0, where the library switches to its rehearsal transport (stream-ordered device copies);
+  * a two-PROCESS world with the HIP engine as the frame function runs over torch.distributed / gloo.
+Everything is checked bit for bit against the single-handle engine (which tests/test_gpu_parity.py pins to the oracle).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import cvsteer_amd
+    return cvsteer_amd
+
+
+def _frames(n, rows, cols, seed):
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.rand((n, rows, cols), device="cuda", generator=gen)
+
+
+def _reference(cv, frames, sel):
+    eng = cv.SteerableFiltersG2(None)
+    return eng.pipeline_batch(frames, outputs=sel)
+
+
+@pytest.mark.parametrize("via", [False, True])
+def test_one_rank_world_rccl(cv, via):
+    import torch
+    from cvsteer_amd import batch
+    frames = _frames(5, 70, 200, 3)
+    want = _reference(cv, frames, (5, 6, 7))
+    nb = batch.NativeBatch.local((0,))
+    assert nb.transport in ("rccl", "none")
+    if via and nb.transport != "rccl":
+        pytest.skip("RCCL could not be loaded on this box")
+    got, t = nb.run(frames, 5, (70, 200), outputs=(5, 6, 7), self_via_transport=via)
+    assert torch.equal(got, want)
+    assert t["compute"] > 0.0
+    # all eight outputs, a second call on the same object (staging reuse), other geometry
+    frames2 = _frames(3, 129, 513, 4)
+    got2, _ = nb.run(frames2, 3, (129, 513), outputs=tuple(range(8)), self_via_transport=via)
+    assert torch.equal(got2, _reference(cv, frames2, tuple(range(8))))
+    nb.close()
+
+
+def test_rank_per_process_bootstrap_one_rank(cv):
+    """cvs_batch_unique_id + cvs_batch_create_rank (the one-process-per-GPU way to form a world), here with one rank"""
+    import torch
+    from cvsteer_amd import batch
+    try:
+        nb = batch.NativeBatch.from_torch_distributed(0)
+    except cv.CvsError as e:
+        pytest.skip("RCCL not available: %s" % e)
+    assert nb.world == 1 and nb.transport == "rccl"
+    frames = _frames(4, 64, 128, 9)
+    got, _ = nb.run(frames, 4, (64, 128), outputs=(0, 1, 7), self_via_transport=True)
+    assert torch.equal(got, _reference(cv, frames, (0, 1, 7)))
+    nb.close()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 5), (3, 7), (3, 2), (4, 1), (8, 32)])
+def test_rehearsal_world_sharded_equals_unsharded(cv, world, n_frames):
+    """several ranks on device 0: contiguous blocks, empty shards, root in place, gather order"""
+    import torch
+    from cvsteer_amd import batch
+    rows, cols = (1080 // 8, 1920 // 8) if n_frames == 32 else (48, 136)
+    frames = _frames(n_frames, rows, cols, 10 + world)
+    want = _reference(cv, frames, (2, 5, 6, 7))
+    nb = batch.NativeBatch.local((0,) * world)
+    assert nb.transport.startswith("device copies")
+    got, t = nb.run(frames, n_frames, (rows, cols), outputs=(2, 5, 6, 7))
+    assert torch.equal(got, want)
+    # a root other than rank 0
+    if world > 1:
+        got_r, _ = nb.run(frames, n_frames, (rows, cols), outputs=(2, 5, 6, 7), root=world - 1)
+        assert torch.equal(got_r, want)
+    nb.close()
+
+
+def test_batch_argument_errors(cv):
+    import torch
+    from cvsteer_amd import batch
+    nb = batch.NativeBatch.local((0,))
+    frames = _frames(2, 32, 64, 1)
+    with pytest.raises(cv.CvsError):
+        nb.run(frames, 2, (32, 64), outputs=())             # nothing requested
+    with pytest.raises(cv.CvsError):
+        nb.run(frames, 2, (32, 64), root=3)                 # no such rank
+    with pytest.raises(cv.CvsError):
+        batch.NativeBatch.local((0, 99))                    # no such device
+    nb.close()
+
+
+@pytest.mark.parametrize("world", [1, 3, 4])
+def test_pyramid_bands_equal_single_gpu(cv, world, monkeypatch):
+    """config 3: broadcast + row bands of every level + gather into the root's state == one GPU, bit for bit
+    (band seams, image borders, odd level sizes, a level with fewer rows than a strip)"""
+    import torch
+    from cvsteer_amd import _lib as L
+    from cvsteer_amd import batch
+    if world == 1:
+        monkeypatch.setenv("CVS_BATCH_SELF_TRANSPORT", "1")   # the one-rank world still issues ncclBroadcast
+    rows, cols, levels = 523, 777, 5
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    img = torch.rand((rows, cols), device="cuda", generator=gen)
+    single = cv.SteerableFiltersG2(None)
+    lv = single.pyramid(img, levels)
+    nb = batch.NativeBatch.local((0,) * world)
+    t = nb.pyramid_setup(img, rows, cols, levels, flags=cv.SETUP_FULL)
+    assert t["compute"] > 0.0
+    for l, plane in enumerate(lv):
+        ref = cv.SteerableFiltersG2(plane)
+        for p in range(7):
+            assert torch.equal(nb.level_plane(l, L.PLANE_BASIS0 + p), ref.basis(p)), (l, p)
+        assert torch.equal(nb.level_plane(l, L.PLANE_THETA), ref.getDominantOrientationAngle()), l
+        assert torch.equal(nb.level_plane(l, L.PLANE_C1), ref.coefficients()[0]), l
+    nb.close()
+    # G4 basis planes through the same path
+    nb4 = batch.NativeBatch.local((0,) * world, kind=L.KIND_G4, width=6, spacing=0.5)
+    nb4.pyramid_setup(img, rows, cols, 3, flags=cv.SETUP_BASIS)
+    for l in range(3):
+        ref = cv.SteerableFiltersG4(lv[l])
+        for p in (0, 5, 10):
+            assert torch.equal(nb4.level_plane(l, L.PLANE_BASIS0 + p), ref.basis(p)), (l, p)
+    nb4.close()
+
+
+def test_setup_rows_band_is_bit_identical(cv):
+    """cvs_setup_rows: any band of rows equals the same rows of a whole-image setup, incl. bands touching the borders"""
+    import ctypes as C
+    import torch
+    img = torch.rand((300, 333), device="cuda")
+    whole = cv.SteerableFiltersG2(img)
+    for lo, hi in ((0, 300), (0, 7), (5, 6), (100, 181), (293, 300)):
+        f = cv.SteerableFiltersG2(None)
+        f._bind_stream(img)
+        p = cv.api._plane(img)
+        f._check(cv.lib().cvs_setup_rows(f._h, C.byref(p), cv.SETUP_FULL, lo, hi), "cvs_setup_rows")
+        for k in (0, 3, 6):
+            assert torch.equal(f.basis(k)[lo:hi], whole.basis(k)[lo:hi]), (lo, hi, k)
+        assert torch.equal(f.getDominantOrientationAngle()[lo:hi], whole.getDominantOrientationAngle()[lo:hi])
+    f = cv.SteerableFiltersG2(None)
+    p = cv.api._plane(img)
+    with pytest.raises(cv.CvsError):
+        f._check(cv.lib().cvs_setup_rows(f._h, C.byref(p), cv.SETUP_FULL, 10, 10), "cvs_setup_rows")
+
+
+# ------------------------------------------------------------------ two processes, the HIP engine as the frame function
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    import cvsteer_amd as cv
+    from cvsteer_amd import batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)   # both ranks share the box's one GPU; gloo carries the frames through host memory
+        shape = (96, 160)
+        frames = None
+        if rank == 0:
+            frames = torch.from_numpy(np.random.default_rng(5).random((n_frames,) + shape, dtype=np.float32))
+        eng = cv.SteerableFiltersG2(None, device=0)
+
+        def frame_fn(img, outs):   # the product's frame function: the HIP pipeline, nothing else
+            res = eng.pipeline(img.cuda())
+            for o, r in zip(outs, res):
+                o.copy_(r)
+
+        local, gathered = batch.run_sharded(frames, n_frames, shape, torch.device("cpu"), frame_fn, 8)
+        lo, hi = batch.shard_range(n_frames, world, rank)
+        assert local.shape == (hi - lo, 8) + shape
+        if rank == 0:
+            want = cv.SteerableFiltersG2(None, device=0).pipeline_batch(frames.cuda()).cpu()
+            assert gathered.shape == want.shape
+            assert torch.equal(gathered, want)   # sharded over two processes == one launch, bit for bit
+            q.put("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [5, 1])
+def test_two_processes_hip_frame_function(n_frames):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok"
