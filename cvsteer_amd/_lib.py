@@ -13,6 +13,7 @@ OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON, OPT_STORE_POLICY, OPT_G4_SPLIT, OPT_
 OPT_XCD_WEIGHTS = 10
 OPT_PLACEMENT_SEARCH = 11
 OPT_AUTOTUNE = 12
+OPT_HOST_OVERLAP = 13
 PLANE_BASIS0, PLANE_C1, PLANE_C2, PLANE_C3, PLANE_THETA, PLANE_STRENGTH = 0, 32, 33, 34, 35, 36
 
 

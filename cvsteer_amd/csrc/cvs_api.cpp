@@ -8,7 +8,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +21,7 @@
 #include <tuple>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cvs_internal.h"
@@ -53,6 +56,10 @@ struct cvs_context {
     int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 0, autotune = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     hipEvent_t ev_order = nullptr;            // cvs_set_stream: orders the new stream behind the old one
+    // overlapped host path (host_pipeline): copy streams and per-band events, created on first use
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    std::vector<hipEvent_t> band_ev;
+    int host_overlap = 1;                     // CVS_OPT_HOST_OVERLAP
     bool used = false;                        // any work queued on `stream` so far
     // placement search bookkeeping, per kernel variant (a block that is fast for one variant need not be for another):
     // launches of the variant on the current state allocation, and whether the search has run for it
@@ -119,6 +126,11 @@ struct Call {
     std::vector<Pending> outs;
     bool touched_host = false;
     size_t need = 0;
+    // overlapped host path: in_ref only reserves the device copy of a HOST image, host_pipeline moves the bytes
+    bool defer = false;
+    const cvs_plane* deferred_image = nullptr;
+    uint8_t* deferred_u8 = nullptr;   // device staging of an 8-bit host image
+    size_t deferred_u8_pitch = 0;
 };
 
 int arena_reserve(cvs_handle h, size_t elems)
@@ -163,6 +175,13 @@ int in_ref(Call& c, const cvs_plane* p, PlaneRef& r)
         if (mem_of(p) == CVS_MEM_HOST) {
             const size_t bpitch = round_up((size_t)p->cols, 256);
             uint8_t* b = reinterpret_cast<uint8_t*>(arena_take(h, round_up(bpitch * p->rows / 4 + 64, 64)));
+            if (c.defer) {
+                c.deferred_image = p;
+                c.deferred_u8 = b;
+                c.deferred_u8_pitch = bpitch;
+                r = {d, pitch};
+                return CVS_OK;
+            }
             HIP_TRY(h, hipMemcpy2DAsync(b, bpitch, p->data, p->step, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, h->stream));
             c.touched_host = true;
             src = b;
@@ -178,6 +197,11 @@ int in_ref(Call& c, const cvs_plane* p, PlaneRef& r)
     }
     const size_t pitch = round_up((size_t)p->cols, 64);
     float* d = arena_take(h, pitch * p->rows);
+    if (c.defer) {
+        c.deferred_image = p;
+        r = {d, pitch};
+        return CVS_OK;
+    }
     HIP_TRY(h, hipMemcpy2DAsync(d, pitch * sizeof(float), p->data, p->step, (size_t)p->cols * sizeof(float), p->rows,
                                 hipMemcpyHostToDevice, h->stream));
     c.touched_host = true;
@@ -503,6 +527,9 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     if (!fast || !big) return CVS_OK;
     // what is still open: the order (unless pinned), the strip height (unless pinned or the input stream is fresh
     // images, where short strips are a must), the G4 bank layout (unless pinned)
+    // a stream of fresh images keeps its defaults (plain order, 10-row strips): the timing loop below re-filters ONE
+    // image, i.e. it would measure the cache-resident case and pick for the wrong regime
+    if (fresh_input) return CVS_OK;
     const bool free_order = h->block_order < 0;
     const bool free_strip = h->strip_rows <= 0 && !fresh_input && a.batch == 0;
     const bool free_split = h->kind == CVS_KIND_G4 && h->g4_split < 0;
@@ -597,6 +624,134 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     return CVS_OK;
 }
 
+// Overlapped host path.  The reference's callers hand over HOST images and expect HOST results
+// (test/test.cpp:73,85-90; example/steer.cpp:73-104).  Done naively that is upload, kernel, download, one after the
+// other: 64 MiB up + 128 MiB down at 56 GB/s each = 3.6 ms around a 0.11 ms kernel.  The host link is full duplex, so
+// the image is cut into row bands and three things run at once: the upload of band b+1 (this thread, stream s_up), the
+// filtering of band b (the handle's stream; cvs_setup_rows machinery, values bit-identical to a whole-image launch)
+// and the download of band b-1's outputs (a second host thread, stream s_down).  Host memory may be pageable: the
+// runtime pins it on the fly (tools/pcie_probe.hip: pageable = pinned = 56 GB/s per direction; both directions from
+// two threads 2.66 ms instead of 3.58).  What remains is max(upload, download) plus one band of latency.
+int host_pipeline(cvs_handle h, Call& c, BasisArgs& a, float* scr)
+{
+    const int W = h->width;
+    int nbands = 8;
+    if (const char* e = std::getenv("CVS_HOST_BANDS")) nbands = std::max(1, std::min(64, std::atoi(e)));  // tuning aid
+    int per = (a.rows + nbands - 1) / nbands;
+    per = std::max(a.strip_rows, (per + a.strip_rows - 1) / a.strip_rows * a.strip_rows);
+    nbands = (a.rows + per - 1) / per;
+    if (!h->s_up) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking));
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->s_down, hipStreamNonBlocking));
+    }
+    while ((int)h->band_ev.size() < 2 * nbands + 1) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->band_ev.push_back(e);
+    }
+    hipEvent_t* up = h->band_ev.data();
+    hipEvent_t* comp = h->band_ev.data() + nbands;
+    // the copy streams start behind whatever the handle's stream still has queued on these buffers
+    hipEvent_t start = h->band_ev[2 * nbands];
+    HIP_TRY(h, hipEventRecord(start, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_up, start, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_down, start, 0));
+    // plain order, default weights: the launch-order tuner works on whole resident images, not on bands
+    a.block_order = 0;
+    a.xcd_even = 4;
+    a.xcd_odd = 3;
+
+    // download thread: band b's outputs leave as soon as its kernel has finished
+    std::mutex mu;
+    std::condition_variable cv;
+    int enqueued = 0;
+    bool abort_dl = false;
+    hipError_t dl_err = hipSuccess;
+    const std::vector<Pending> outs = c.outs;
+    const int rows = a.rows, device = h->device;
+    hipStream_t s_down = h->s_down;
+    std::thread downloader;
+    if (!outs.empty()) {
+        downloader = std::thread([&, rows, device, s_down, per, nbands] {
+            hipError_t e = hipSetDevice(device);
+            for (int b = 0; b < nbands && e == hipSuccess; ++b) {
+                {
+                    std::unique_lock<std::mutex> lock(mu);
+                    cv.wait(lock, [&] { return enqueued > b || abort_dl; });
+                    if (abort_dl) break;
+                }
+                const int lo = b * per, hi = std::min(rows, lo + per);
+                e = hipStreamWaitEvent(s_down, comp[b], 0);
+                for (const Pending& o : outs) {
+                    if (e != hipSuccess) break;
+                    if (o.host->step == o.pitch * sizeof(float) && o.host->step == (size_t)o.host->cols * sizeof(float)) {  // dense on both sides
+                        e = hipMemcpyAsync(reinterpret_cast<char*>(o.host->data) + (size_t)lo * o.host->step, o.dev + (size_t)lo * o.pitch,
+                                           (size_t)(hi - lo) * o.host->step, hipMemcpyDeviceToHost, s_down);
+                        continue;
+                    }
+                    e = hipMemcpy2DAsync(reinterpret_cast<char*>(o.host->data) + (size_t)lo * o.host->step, o.host->step, o.dev + (size_t)lo * o.pitch,
+                                         o.pitch * sizeof(float), (size_t)o.host->cols * sizeof(float), hi - lo, hipMemcpyDeviceToHost, s_down);
+                }
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+            dl_err = e;
+        });
+    }
+    auto stop = [&](int rc) {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            abort_dl = true;
+        }
+        cv.notify_all();
+        if (downloader.joinable()) downloader.join();
+        return rc;
+    };
+    const cvs_plane* img = c.deferred_image;  // nullptr: the image is already on the device, only outputs travel
+    int up_to = 0;                            // rows of the image uploaded so far
+    for (int b = 0; b < nbands; ++b) {
+        const int lo = b * per, hi = std::min(a.rows, lo + per);
+        if (img) {
+            const int need = std::min(a.rows, hi + W);  // the band's kernel reads W rows beyond its last output row
+            if (need > up_to) {
+                hipError_t e;
+                if (c.deferred_u8) {
+                    e = hipMemcpy2DAsync(c.deferred_u8 + (size_t)up_to * c.deferred_u8_pitch, c.deferred_u8_pitch,
+                                         reinterpret_cast<const char*>(img->data) + (size_t)up_to * img->step, img->step, (size_t)img->cols, need - up_to,
+                                         hipMemcpyHostToDevice, h->s_up);
+                    if (e == hipSuccess)
+                        e = launch_u8_to_f32(c.deferred_u8 + (size_t)up_to * c.deferred_u8_pitch, c.deferred_u8_pitch, need - up_to, img->cols,
+                                             const_cast<float*>(a.in) + (size_t)up_to * a.in_pitch, a.in_pitch, h->s_up);
+                } else {
+                    e = hipMemcpy2DAsync(const_cast<float*>(a.in) + (size_t)up_to * a.in_pitch, a.in_pitch * sizeof(float),
+                                         reinterpret_cast<const char*>(img->data) + (size_t)up_to * img->step, img->step, (size_t)img->cols * sizeof(float),
+                                         need - up_to, hipMemcpyHostToDevice, h->s_up);
+                }
+                if (e != hipSuccess) return stop(fail_hip(h, e, "host pipeline upload"));
+                up_to = need;
+            }
+            hipError_t e = hipEventRecord(up[b], h->s_up);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, up[b], 0);
+            if (e != hipSuccess) return stop(fail_hip(h, e, "host pipeline ordering"));
+        }
+        BasisArgs ab = a;
+        ab.out_row_lo = lo;
+        ab.out_row_hi = hi;
+        hipError_t e = launch_basis(h->kind, h->width, h->taps, ab, scr, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(comp[b], h->stream);
+        if (e != hipSuccess) return stop(fail_hip(h, e, "host pipeline launch"));
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            enqueued = b + 1;
+        }
+        cv.notify_all();
+    }
+    if (downloader.joinable()) downloader.join();
+    if (dl_err != hipSuccess) return fail_hip(h, dl_err, "host pipeline download");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    c.outs.clear();  // nothing left for finish() to copy
+    return CVS_OK;
+}
+
 int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, float theta, const cvs_plane* g,
              const cvs_plane* hq, const cvs_plane* const* pipe_outs = nullptr, int nframes = 1, int frame = 0,
              int out_row_lo = 0, int out_row_hi = 0)
@@ -633,6 +788,20 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         for (int k = 0; k < 8; ++k) po[k] = pipe_outs[k];
     rc = begin(h, c, {image, steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7]}, scratch);
     if (rc) return rc;
+    // host planes on the fast path of a large enough image: upload, filtering and download overlap band by band
+    // (it pays when a sizeable upload can hide behind the downloads: an f32 host image with host outputs -- measured
+    // 3.06 vs 3.70 ms per 4096^2 image; with an 8-bit or device image the downloads alone set the pace and the bands
+    // only add per-copy overhead, 2.98 vs 2.85 ms: tools/host_probe.py)
+    bool any_host = false;
+    for (const cvs_plane* o : {steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7]})
+        any_host = any_host || (o && o->mem == CVS_MEM_HOST);
+    any_host = any_host && mem_of(image) == CVS_MEM_HOST && !is_u8(image);
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(h->stream, &cap_st);
+    const bool overlap = h->host_overlap && any_host && !may_generic && nframes == 1 && out_row_hi <= out_row_lo &&
+                         cap_st == hipStreamCaptureStatusNone && (size_t)image->rows * image->cols >= ((size_t)1 << 20) &&
+                         image->rows >= 16 * (2 * h->width + 1) && !(h->kind == CVS_KIND_G4 && (flags & CVS_SETUP_ORIENT));
+    c.defer = overlap;
     h->have_basis = h->have_orient = false;
     if ((rc = ensure_state(h, image->rows, image->cols, nframes))) return rc;
     h->cur_frame = frame;
@@ -678,6 +847,12 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
             if ((rc = out_ref(c, po[k], a.pipe_out[k]))) return rc;
     }
     float* scr = scratch ? arena_take(h, scratch) : nullptr;
+    if (overlap) {
+        if ((rc = host_pipeline(h, c, a, scr))) return rc;
+        h->have_basis = !(pipe_outs && !h->persist);
+        h->have_orient = h->have_basis && (flags & CVS_SETUP_ORIENT) != 0;
+        return CVS_OK;
+    }
     {
         const bool orient_k = a.orient != nullptr;
         const int variant = (orient_k ? 1 : 0) | (steer ? 2 : 0) | (a.pipe ? 4 : 0) | (a.no_state ? 8 : 0);
@@ -837,6 +1012,9 @@ int cvs_destroy(cvs_handle h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+    for (hipEvent_t e : h->band_ev) (void)hipEventDestroy(e);
+    if (h->s_up) (void)hipStreamDestroy(h->s_up);
+    if (h->s_down) (void)hipStreamDestroy(h->s_down);
     delete h;
     return CVS_OK;
 }
@@ -931,6 +1109,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value < -1 || value > 1000000) return fail(h, CVS_E_BADARG, "block order");
             h->block_order = value;
             return CVS_OK;
+        case CVS_OPT_HOST_OVERLAP:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "host overlap");
+            h->host_overlap = value;
+            return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -945,6 +1127,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
         case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
         case CVS_OPT_BLOCK_ORDER: *value = h->block_order; return CVS_OK;
+        case CVS_OPT_HOST_OVERLAP: *value = h->host_overlap; return CVS_OK;
         case CVS_OPT_XCD_WEIGHTS: *value = h->xcd_weights; return CVS_OK;
         case CVS_OPT_PLACEMENT_SEARCH: *value = h->placement; return CVS_OK;
         case CVS_OPT_AUTOTUNE: *value = h->autotune; return CVS_OK;

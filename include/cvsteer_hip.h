@@ -86,6 +86,9 @@ enum {
                                       Cost: tens of milliseconds, a stream synchronisation, device-wide hipMalloc/hipFree
                                       stalls; one search at a time per process.  2 = always move to the last candidate
                                       (tests).  Results never depend on it. */
+    CVS_OPT_HOST_OVERLAP = 13, /* cvs_setup / cvs_setup_steer / cvs_pipeline with HOST planes on images of 1 Mpix and more:
+                                  1 (default) = the image goes up, is filtered and comes down in row bands, all three at once
+                                  (full-duplex host link, a second host thread for the downloads); 0 = one after the other */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
                                 launch (blockIdx.z picks the half); -1 (default) = 2, or 0 where the autotuner finds it faster */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the

@@ -146,6 +146,7 @@ def test_setup_rows_band_is_bit_identical(cv):
     whole = cv.SteerableFiltersG2(img)
     for lo, hi in ((0, 300), (0, 7), (5, 6), (100, 181), (293, 300)):
         f = cv.SteerableFiltersG2(None)
+        f._like = img                  # results as CUDA tensors
         f._bind_stream(img)
         p = cv.api._plane(img)
         f._check(cv.lib().cvs_setup_rows(f._h, C.byref(p), cv.SETUP_FULL, lo, hi), "cvs_setup_rows")

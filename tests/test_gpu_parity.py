@@ -892,6 +892,63 @@ def test_narrow_view_of_a_2gib_plane_small_state(cv, ora):
         assert torch.equal(f4.basis(p), w4.basis(p)), p
 
 
+def test_overlapped_host_path_matches_device_path(cv):
+    """host planes of 1 Mpix and more travel in row bands, upload / filtering / download
+    overlapped (two copy streams + a download thread).  Results must be bit-identical to the same call on device
+    planes and to the non-overlapped host path, for f32 and 8-bit host images, fused steer and the whole pipeline."""
+    import torch
+    from cvsteer_amd import _lib as L
+    rng = np.random.default_rng(31)
+    img = rng.random((1531, 1100), dtype=np.float32)          # odd sizes: ragged last band, ragged last strip
+    dev = torch.from_numpy(img).cuda()
+    ref = cv.SteerableFiltersG2(None)
+    g_d, h_d = ref.setup_steer(dev, 0.3, flags=cv.SETUP_FULL)
+    want_basis = [ref.basis(p).cpu().numpy() for p in range(7)]
+    want_theta = ref.getDominantOrientationAngle().cpu().numpy()
+    for overlap in (1, 0):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_HOST_OVERLAP, overlap)
+        g_h, h_h = f.setup_steer(img, 0.3, flags=cv.SETUP_FULL)       # numpy in, numpy out
+        assert isinstance(g_h, np.ndarray)
+        assert np.array_equal(g_h, g_d.cpu().numpy()) and np.array_equal(h_h, h_d.cpu().numpy()), overlap
+        for p in range(7):
+            assert np.array_equal(f.basis(p), want_basis[p]), (overlap, p)
+        assert np.array_equal(f.getDominantOrientationAngle(), want_theta, equal_nan=True)
+        # host image, device outputs / device image, host outputs
+        g_m, h_m = torch.empty_like(dev), torch.empty_like(dev)
+        f.setup_steer(img, 0.3, out=(g_m, h_m))
+        assert torch.equal(g_m, g_d) and torch.equal(h_m, h_d)
+        g_n, h_n = np.empty_like(img), np.empty_like(img)
+        f.setup_steer(dev, 0.3, out=(g_n, h_n))
+        assert np.array_equal(g_n, g_d.cpu().numpy()) and np.array_equal(h_n, h_d.cpu().numpy())
+        # strided host planes (a column window of a wider array), second call on the same handle
+        wide_in = rng.random((1531, 1500), dtype=np.float32)
+        wide_out = np.zeros((2, 1531, 1400), np.float32)
+        f.setup_steer(wide_in[:, 100:1200], -0.9, out=(wide_out[0][:, 7:1107], wide_out[1][:, 300:1400]))
+        gw, hw = ref.setup_steer(torch.from_numpy(np.ascontiguousarray(wide_in[:, 100:1200])).cuda(), -0.9)
+        assert np.array_equal(wide_out[0][:, 7:1107], gw.cpu().numpy()) and np.array_equal(wide_out[1][:, 300:1400], hw.cpu().numpy())
+        assert not wide_out[0][:, :7].any() and not wide_out[0][:, 1107:].any()          # nothing written beside the planes
+        # the callers' whole sequence with host planes in and out
+        outs_h = f.pipeline(img)
+        outs_d = ref.pipeline(dev)
+        for a, b in zip(outs_h, outs_d):
+            assert np.array_equal(a, b.cpu().numpy(), equal_nan=True)
+        # 8-bit host image: bytes travel, widening on the device (test/test.cpp:73,85)
+        u8 = (rng.random((1531, 1100)) * 255).astype(np.uint8)
+        f8 = cv.SteerableFiltersG2(None)
+        f8.set_option(L.OPT_HOST_OVERLAP, overlap)
+        g8, h8 = f8.setup_steer(u8, 0.3)
+        gr, hr = ref.setup_steer(torch.from_numpy(u8.astype(np.float32)).cuda(), 0.3)
+        assert np.array_equal(g8, gr.cpu().numpy()) and np.array_equal(h8, hr.cpu().numpy())
+    # G4 through the same path
+    f4, r4 = cv.SteerableFiltersG4(None), cv.SteerableFiltersG4(None)
+    g4, h4 = f4.setup_steer(img, 0.3)
+    g4d, h4d = r4.setup_steer(dev, 0.3)
+    assert np.array_equal(g4, g4d.cpu().numpy()) and np.array_equal(h4, h4d.cpu().numpy())
+    for p in (0, 10):
+        assert np.array_equal(f4.basis(p), r4.basis(p).cpu().numpy())
+
+
 def test_placement_search_keeps_results_and_state(cv):
     """CVS_OPT_PLACEMENT_SEARCH: after a few launches of one shape the handle may move its state to another
     allocation; outputs and state must be what a handle without the search produces, before and after"""
