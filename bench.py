@@ -163,6 +163,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_spawn_ranks(args.gpus))   # before torch is imported: the parent never touches the GPU
 
+    # stdout carries exactly one thing, the JSON line: libraries that print banners there (RCCL does, at communicator
+    # creation) are sent to stderr at the file-descriptor level, and the line goes out through the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     ws, rank, local_rank = _dist_env()
     if ws != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- start it as `python bench.py --gpus N` or as "
@@ -498,7 +504,8 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,7 +28,21 @@ if stats:
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    # the same kernel over the TIMED region only: the trace also holds the engine's one-off tuning launches (other strip
+    # heights / orders, ~60 launches) and the warm-ups; bench.py's roofline.avg_launch_ms covers the last `steps` launches
+    trace = newest(os.path.join(G, "prof_stats", "*", "*_kernel_trace.csv"))
     line = [l for l in open(os.path.join(G, "prof_stats.log")) if l.startswith("{")]
+    if trace and line:
+        steps = json.loads(line[-1])["steps"]
+        durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace[0]))
+                if "k_basis<cvs::BankG2, 2" in r["Kernel_Name"] or "k_basisINS_6BankG2ELi2" in r["Kernel_Name"]]
+        durs = [d for _, d in sorted(durs)][-steps:]
+        if durs:
+            starts = sorted(int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace[0])) if "BankG2, 2" in r["Kernel_Name"])[-steps:]
+            with open(os.path.join(P, "%s_kernel_stats.csv" % rnd), "a") as f:
+                w = csv.writer(f)
+                w.writerow(["# timed region: last %d launches of the headline kernel" % len(durs), len(durs), sum(durs), "%.1f" % (sum(durs) / len(durs)),
+                            min(durs), max(durs), "launch-to-launch %.1f ns" % ((starts[-1] - starts[0]) / max(1, len(starts) - 1))])
     if line:
         open(os.path.join(P, "%s_bench_under_rocprof.json" % rnd), "w").write(line[-1])
 allst = newest(os.path.join(G, "prof_stats_all", "*", "*_kernel_stats.csv"))
@@ -69,6 +83,10 @@ for k in sorted(write):
     f2 = 2.0 * fetch.get(k, 0.0)
     summary["kernels"][k] = {"FETCH_SIZE_bytes_raw": fetch.get(k), "read_bytes_corrected_x2": f2,
                              "WRITE_SIZE_bytes": write[k], "hbm_bytes_per_launch": f2 + write[k]}
+# the headline kernel on 8 rotating inputs (tools/rot_loop.py): strips of 10 rows, plain order
+rf, rw = pmc("FETCH_SIZE", "pmc_rot_%s"), pmc("WRITE_SIZE", "pmc_rot_%s")
+summary["rotating_inputs"] = {k: {"FETCH_SIZE_bytes_raw": rf.get(k), "read_bytes_corrected_x2": 2.0 * rf.get(k, 0.0), "WRITE_SIZE_bytes": rw[k],
+                                  "read_amplification_vs_image": 2.0 * rf.get(k, 0.0) / plane} for k in sorted(rw) if "cvs::" in k}
 json.dump(summary, open(os.path.join(P, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 
 # the headline kernel: G2 bank, F_STEER (2), streaming stores, not batched

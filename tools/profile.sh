@@ -22,5 +22,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $C rc=$?" >> $O/pmc_$C.log
   timeout 200 rocprofv3 --pmc $C --output-format csv -d $O/pmc_cal_$C -- ./tools/membench > $O/pmc_cal_$C.log 2>&1
 done
+# the same counters for a stream of fresh images (8 rotating inputs: every input read comes from HBM)
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_rot_$C -- python3 tools/rot_loop.py > $O/pmc_rot_$C.log 2>&1
+done
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/pmc_SQ -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $O/pmc_SQ.log 2>&1
 echo "pmc SQ rc=$?" >> $O/pmc_SQ.log
