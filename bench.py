@@ -481,16 +481,22 @@ def main():
             himgs = [np.random.default_rng(500 + i).random((ROWS, COLS), dtype=np.float32) for i in range(8)]
             hg, hh = np.empty_like(himgs[0]), np.empty_like(himgs[0])
 
+            fhs = {}
+            for overlap in (0, 1):
+                fhs[overlap] = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+                fhs[overlap].set_option(L.OPT_HOST_OVERLAP, overlap)
+                fhs[overlap].setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
+
             def host_stream(overlap):
-                fh = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-                fh.set_option(L.OPT_HOST_OVERLAP, overlap)
-                fh.setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
                 t0 = time.perf_counter()
                 for im in himgs:
-                    fh.setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
+                    fhs[overlap].setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
                 return (time.perf_counter() - t0) / len(himgs)
 
-            dt_seq, dt_ovl = host_stream(0), host_stream(1)
+            # two interleaved passes, the better one of each mode (the first pass also pages the host arrays in)
+            dt_seq, dt_ovl = min(host_stream(0), host_stream(0)), min(host_stream(1), host_stream(1))
+            dt_seq, dt_ovl = min(dt_seq, host_stream(0)), min(dt_ovl, host_stream(1))
+            del fhs
             extra["M2_host_planes_pcie_inclusive"] = {"Mpix/s": round(npix / dt_ovl / 1e6, 1), "ms": round(dt_ovl * 1e3, 3),
                                                       "sequential_Mpix/s": round(npix / dt_seq / 1e6, 1), "sequential_ms": round(dt_seq * 1e3, 3),
                                                       "note": "stream of 8 host f32 images in, g2/h2 out to host, bases stay on device; "

@@ -37,8 +37,10 @@ struct cvs_context {
     // state planes: nb basis, then c1,c2,c3,theta,strength
     int rows = 0, cols = 0;
     size_t pitch = 0, plane_stride = 0;
-    float* state = nullptr;
-    size_t state_elems = 0;
+    float* state = nullptr;      // = sb.base
+    size_t state_elems = 0;      // = sb.elems
+    StateBlock sb;               // owner of the state memory (cvs_state.cpp)
+    size_t placed_stride = 0;    // plane size the placement search has already run for (its answer may be "plain block")
     bool have_basis = false, have_orient = false;
     // batched state: num_frames blocks of (nb+5) planes; cur_frame selects the block all state
     // accessors and steer calls address
@@ -53,7 +55,7 @@ struct cvs_context {
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 0, autotune = 1;
+    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 1, autotune = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     hipEvent_t ev_order = nullptr;            // cvs_set_stream: orders the new stream behind the old one
     // overlapped host path (host_pipeline): copy streams and per-band events, created on first use
@@ -61,10 +63,6 @@ struct cvs_context {
     std::vector<hipEvent_t> band_ev;
     int host_overlap = 1;                     // CVS_OPT_HOST_OVERLAP
     bool used = false;                        // any work queued on `stream` so far
-    // placement search bookkeeping, per kernel variant (a block that is fast for one variant need not be for another):
-    // launches of the variant on the current state allocation, and whether the search has run for it
-    int variant_calls[32] = {};
-    bool variant_placed[32] = {};
     std::string err;
 };
 
@@ -266,13 +264,8 @@ float* state_plane(cvs_handle h, int idx)
 // drained) and the next handle on the same device that needs a block of about that size takes it over.  Bounded:
 // CVS_STATE_POOL_MB megabytes in all (default 4096, 0 = off), blocks at most twice the size asked for;
 // cvs_release_cached_memory() empties it.
-struct PoolBlock {
-    int device;
-    float* p;
-    size_t elems;
-};
 std::mutex g_pool_mutex;
-std::vector<PoolBlock> g_pool;
+std::vector<StateBlock> g_pool;
 
 size_t pool_limit_bytes()
 {
@@ -284,66 +277,82 @@ size_t pool_limit_bytes()
     return lim;
 }
 
-float* pool_take(int device, size_t elems, size_t* got)
+// a plain block of about the size asked for, or a per-plane block of exactly the geometry asked for
+bool pool_take(int device, size_t elems, bool vmm, size_t piece_bytes_min, int nplanes, StateBlock& out)
 {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     int best = -1;
-    for (int i = 0; i < (int)g_pool.size(); ++i)
-        if (g_pool[i].device == device && g_pool[i].elems >= elems && g_pool[i].elems <= 2 * elems &&
-            (best < 0 || g_pool[i].elems < g_pool[best].elems))
-            best = i;
-    if (best < 0) return nullptr;
-    float* p = g_pool[best].p;
-    *got = g_pool[best].elems;
+    for (int i = 0; i < (int)g_pool.size(); ++i) {
+        const StateBlock& b = g_pool[i];
+        if (b.device != device || b.vmm != vmm) continue;
+        const bool fits = vmm ? ((int)b.pieces.size() == nplanes && b.piece_bytes >= piece_bytes_min && b.piece_bytes <= piece_bytes_min + piece_bytes_min / 4 + ((size_t)2 << 20))
+                              : (b.elems >= elems && b.elems <= 2 * elems);
+        if (fits && (best < 0 || b.elems < g_pool[best].elems)) best = i;
+    }
+    if (best < 0) return false;
+    out = g_pool[best];
     g_pool.erase(g_pool.begin() + best);
-    return p;
+    return true;
 }
 
 // the caller has synchronised the stream that last used the block
-void pool_give(int device, float* p, size_t elems)
+void pool_give(StateBlock& blk)
 {
-    const size_t lim = pool_limit_bytes(), bytes = elems * sizeof(float);
-    std::vector<float*> drop;
+    const size_t lim = pool_limit_bytes(), bytes = blk.elems * sizeof(float);
+    std::vector<StateBlock> drop;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
-        if (bytes > lim) drop.push_back(p);
+        if (bytes > lim) drop.push_back(blk);
         else {
             size_t held = bytes;
-            for (const PoolBlock& b : g_pool) held += b.elems * sizeof(float);
+            for (const StateBlock& b : g_pool) held += b.elems * sizeof(float);
             while (held > lim && !g_pool.empty()) {  // oldest first
                 held -= g_pool.front().elems * sizeof(float);
-                drop.push_back(g_pool.front().p);
+                drop.push_back(g_pool.front());
                 g_pool.erase(g_pool.begin());
             }
-            g_pool.push_back({device, p, elems});
+            g_pool.push_back(blk);
         }
     }
-    for (float* d : drop) (void)hipFree(d);
+    blk = StateBlock();
+    for (StateBlock& d : drop) state_block_free(d);
 }
 
 int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
 {
     const size_t pitch = round_up((size_t)cols, 64);
-    const size_t stride = round_up(pitch * rows, 64);
-    const size_t elems = stride * (h->nb + 5) * (size_t)nframes;
-    if (elems > h->state_elems) {
+    size_t stride = round_up(pitch * rows, 64);
+    const int nplanes = h->nb + 5;
+    // Large single-image states get one physical allocation per plane, placed by a bounded search (cvs_state.cpp);
+    // small ones (they live in the Infinity Cache anyway) and frame batches take a plain block.
+    const bool want_planes = h->placement != 0 && nframes == 1 && stride * sizeof(float) >= ((size_t)8 << 20) &&
+                             stride * sizeof(float) * nplanes >= ((size_t)256 << 20);
+    bool reuse = h->state != nullptr;
+    if (reuse) {
+        if (want_planes && h->sb.vmm) reuse = (int)h->sb.pieces.size() == nplanes && h->sb.piece_bytes >= stride * sizeof(float) &&
+                                              h->sb.piece_bytes <= stride * sizeof(float) + stride + ((size_t)2 << 20);
+        else if (want_planes) reuse = h->placed_stride == stride && stride * nplanes <= h->state_elems;  // searched: a plain block it is
+        else reuse = !h->sb.vmm && stride * nplanes * (size_t)nframes <= h->state_elems;
+    }
+    if (!reuse) {
         if (h->state) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
-            HIP_TRY(h, hipFree(h->state));
+            state_block_free(h->sb);
             h->state = nullptr;
             h->state_elems = 0;
         }
-        size_t got = 0;
-        if (float* cached = pool_take(h->device, elems, &got)) {
-            h->state = cached;
-            h->state_elems = got;
-        } else {
-            HIP_TRY(h, hipMalloc(&h->state, elems * sizeof(float)));
-            h->state_elems = elems;
+        const size_t elems = stride * nplanes * (size_t)nframes;
+        if (!pool_take(h->device, elems, want_planes, stride * sizeof(float), nplanes, h->sb)) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(h->stream, &cap);
+            if (want_planes && cap == hipStreamCaptureStatusNone) HIP_TRY(h, state_block_alloc_planes(h->device, nplanes, rows, pitch, h->stream, h->placement, h->sb));
+            else HIP_TRY(h, state_block_alloc_plain(h->device, elems, h->sb));
         }
-        std::memset(h->variant_calls, 0, sizeof(h->variant_calls));
-        std::memset(h->variant_placed, 0, sizeof(h->variant_placed));
+        h->state = h->sb.base;
+        h->state_elems = h->sb.elems;
+        h->placed_stride = want_planes ? stride : 0;
     }
+    if (h->sb.vmm) stride = h->sb.piece_bytes / sizeof(float);  // planes start at piece boundaries
     h->rows = rows;
     h->cols = cols;
     h->pitch = pitch;
@@ -398,95 +407,7 @@ struct TuneEntry {
     int g4_split = 2;        // order 1: tiles per period for even / odd XCDs, 100 * e + o
 };
 std::mutex g_tune_mutex;
-std::mutex g_placement_mutex;
 std::map<std::tuple<int, int, int, int, int, int>, TuneEntry> g_tune;
-
-// Placement search.  The many-plane variants run at one of two speeds (67-71 % or 81-84 % of the roofline at
-// 4096^2) depending on where the state block happens to be allocated -- same kernel, same order, same image;
-// nothing at the API level (padding, offsets, contiguity, allocation size) moves a block from one mode to the
-// other (tools/alloc_modes.py).  What does work is taking another block: a handle that keeps filtering
-// the same shape allocates a few candidate state blocks once, times the launch it is about to make on each,
-// keeps the fastest and frees the rest.  Results do not depend on it; it costs a few tens of milliseconds, so it
-// waits until the handle has run a kernel variant on the shape a few times (once per variant: a block that is fast
-// for the 9-plane launch need not be for the 20-plane one), and it needs the spare memory to exist.
-int search_placement(cvs_handle h, BasisArgs& a, float* scr, int variant)
-{
-    variant &= 31;
-    if (!h->placement || h->variant_placed[variant] || a.no_state) return CVS_OK;
-    if (++h->variant_calls[variant] < 8) return CVS_OK;
-    h->variant_placed[variant] = true;
-    const size_t bytes = h->state_elems * sizeof(float);
-    if (bytes < ((size_t)256 << 20)) return CVS_OK;  // the whole state sits in the Infinity Cache: nothing to find
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return CVS_OK;
-    // Opt-in (CVS_OPT_PLACEMENT_SEARCH, off by default) and bounded: at most 12 candidate blocks and at most 8 GiB
-    // of transient memory in all, one search at a time per process (every hipMalloc / hipFree is a device-wide
-    // synchronisation, and hipMemGetInfo is only a snapshot).  A handle that finds another search running skips its own.
-    constexpr int kMaxExtra = 12;
-    constexpr size_t kMaxTransient = (size_t)8 << 30;
-    const int kExtra = (int)std::min<size_t>(kMaxExtra, kMaxTransient / bytes);
-    if (kExtra < 1) return CVS_OK;
-    std::unique_lock<std::mutex> search_lock(g_placement_mutex, std::try_to_lock);
-    if (!search_lock.owns_lock()) return CVS_OK;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (size_t)(kExtra + 1) * bytes + ((size_t)4 << 30)) return CVS_OK;
-    if (!h->ev0) {
-        HIP_TRY(h, hipEventCreate(&h->ev0));
-        HIP_TRY(h, hipEventCreate(&h->ev1));
-    }
-    const auto t_begin = std::chrono::steady_clock::now();
-    float* cand[kMaxExtra + 1] = {h->state};
-    int n = 1;
-    for (; n <= kExtra; ++n)
-        if (hipMalloc(&cand[n], bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            break;
-        }
-    float best[kMaxExtra + 1];
-    float* const home = h->state;
-    const ptrdiff_t basis_off = a.basis - home, orient_off = a.orient ? a.orient - home : 0;
-    int rc = CVS_OK;
-    for (int k = 0; k < n && rc == CVS_OK; ++k) {
-        best[k] = std::numeric_limits<float>::max();
-        a.basis = cand[k] + basis_off;
-        if (a.orient) a.orient = cand[k] + orient_off;
-        for (int r = 0; r < 4; ++r) {  // the first launch on a fresh block pays for its first touch
-            if (hipEventRecord(h->ev0, h->stream) != hipSuccess || launch_basis(h->kind, h->width, h->taps, a, scr, h->stream) != hipSuccess ||
-                hipEventRecord(h->ev1, h->stream) != hipSuccess || hipEventSynchronize(h->ev1) != hipSuccess) {
-                rc = fail(h, CVS_E_HIP, "placement search");
-                break;
-            }
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-            if (r > 0 && ms < best[k]) best[k] = ms;
-        }
-    }
-    int pick = 0;
-    if (rc == CVS_OK)
-        for (int k = 1; k < n; ++k)
-            if (best[k] < best[pick] && best[k] < best[0] * 0.975f) pick = k;  // moving must be worth 2.5 % (timing noise is ~1 %)
-    if (rc == CVS_OK && h->placement == 2 && n > 1) pick = n - 1;  // test mode: always move
-    if (std::getenv("CVS_TUNE_VERBOSE")) {
-        std::fprintf(stderr, "[cvsteer] placement %dx%d:", a.rows, a.cols);
-        for (int k = 0; k < n; ++k) std::fprintf(stderr, " %.4f", best[k]);
-        std::fprintf(stderr, " ms -> block %d\n", pick);
-    }
-    // other frames / planes of the old block may hold state this launch does not rewrite: take it along
-    if (pick != 0 && rc == CVS_OK && hipMemcpyAsync(cand[pick], home, bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) {
-        (void)hipGetLastError();
-        pick = 0;
-    }
-    (void)hipStreamSynchronize(h->stream);
-    for (int k = 0; k < n; ++k)
-        if (k != pick) (void)hipFree(cand[k]);
-    h->state = cand[pick];
-    a.basis = h->state + basis_off;
-    if (a.orient) a.orient = h->state + orient_off;
-    if (std::getenv("CVS_TUNE_VERBOSE"))
-        std::fprintf(stderr, "[cvsteer] placement search took %.1f ms\n",
-                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
-    return rc;
-}
 
 // Launch-order autotune.  Measured on ONE handle (one state allocation; tools/ab_same.py -- comparisons across
 // handles are confounded by where each state block happens to live, tools/alloc_modes.py): the odd XCDs run the G2
@@ -498,12 +419,10 @@ int search_placement(cvs_handle h, BasisArgs& a, float* scr, int variant)
 // CVS_OPT_BLOCK_ORDER >= 0 pins the order (CVS_OPT_XCD_WEIGHTS the weights) and switches the timing off.
 int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input);
 
-// launch configuration for the basis kernel about to run: order (tuned once per shape), then -- with that
-// configuration -- the placement search (once per state allocation)
+// launch configuration for the basis kernel about to run: order / strip height, tuned once per shape
 int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
 {
-    if (int rc = tune_launch(h, a, scr, variant, fresh_input)) return rc;
-    return search_placement(h, a, scr, variant);
+    return tune_launch(h, a, scr, variant, fresh_input);
 }
 
 int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input)
@@ -994,7 +913,7 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
         return CVS_E_NOMEM;
     }
     if (const char* e = std::getenv("CVS_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
-    if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::atoi(e) == 2 ? 2 : std::atoi(e) != 0;  // default for new handles (A/B tools switch it off)
+    if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::max(0, std::min(2, std::atoi(e)));  // default for new handles
     *out = h;
     return CVS_OK;
 }
@@ -1004,7 +923,7 @@ int cvs_destroy(cvs_handle h)
     if (!h) return CVS_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    if (h->state) pool_give(h->device, h->state, h->state_elems);  // the stream has drained: the block may be reused
+    if (h->state) pool_give(h->sb);  // the stream has drained: the block may be reused
     if (h->arena) (void)hipFree(h->arena);
     if (h->minmax) (void)hipFree(h->minmax);
     if (h->frame_tab) (void)hipFree(h->frame_tab);
@@ -1021,16 +940,16 @@ int cvs_destroy(cvs_handle h)
 
 int cvs_release_cached_memory(void)
 {
-    std::vector<PoolBlock> blocks;
+    std::vector<StateBlock> blocks;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         blocks.swap(g_pool);
     }
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
-    for (const PoolBlock& b : blocks) {
+    for (StateBlock& b : blocks) {
         (void)hipSetDevice(b.device);
-        (void)hipFree(b.p);
+        state_block_free(b);
     }
     if (have_cur) (void)hipSetDevice(cur);
     (void)hipGetLastError();

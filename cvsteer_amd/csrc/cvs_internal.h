@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace cvs {
 
 constexpr int kMaxWidth = 32;           // generic path: up to 65 taps
@@ -119,6 +121,24 @@ hipError_t launch_convert_u8(const float* src, size_t pitch, int rows, int cols,
                              size_t dst_step, hipStream_t s);
 hipError_t launch_u8_to_f32(const uint8_t* src, size_t sstep, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
+
+// ---- state blocks (cvs_state.cpp): a plain hipMalloc block, or one physical allocation per plane mapped back to back ----
+struct StateBlock {
+    float* base = nullptr;
+    size_t elems = 0;          // usable floats from base
+    int device = 0;
+    bool vmm = false;          // built with the virtual-memory API: piece_bytes per plane, pieces.size() planes
+    size_t piece_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> pieces;
+    void* va_base = nullptr;   // the reserved virtual range the planes are a window of (freed with the block)
+    size_t va_bytes = 0;
+};
+hipError_t state_block_alloc_plain(int device, size_t elems, StateBlock& b);
+hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b);
+void state_block_free(StateBlock& b);
+// streaming-store probe used by the placement search: writes `n` planes (<= 12) of rows x pitch floats in the basis
+// kernel's access shape (wave = 64-column strip of 19 rows, nontemporal dword stores)
+hipError_t launch_place_probe(float* const* planes, int n, int rows, size_t pitch, hipStream_t s);
 
 // host-side tap math (cvs_taps.cpp, no HIP)
 int host_num_basis(int kind);

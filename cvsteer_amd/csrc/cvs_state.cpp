@@ -1,0 +1,220 @@
+// cvs_state.cpp -- where a handle's state planes live in device memory.
+//
+// Round 1 found the many-plane kernels running at one of "two speeds" depending on the allocation, and sampled
+// whole blocks for a fast one.  Round 2 narrowed it down (tools/frag_probe*.hip, profiles/r02_placement_probes.txt):
+//   * physical pieces that the VRAM allocator hands out one after the other form runs.  Nine planes taken from ONE
+//     run stream at ~5.7 TB/s whatever their spacing, order or padding inside the run; nine planes MIXED from two
+//     runs stream at ~7.2 TB/s (1 plane from the second run: 6.3, 2: 6.9, >= 3: 7.2) -- reproducibly, at the same
+//     pieces on every pass, and with other writes in between (so it is HBM throughput, not the Infinity Cache
+//     keeping planes from one launch to the next);
+//   * a plain hipMalloc block is one run (or two at a seam of the buddy allocator), which is why padding, offsets and
+//     plane strides inside a block never changed anything in round 1;
+//   * where a run ends cannot be predicted from the API (sizes, order and gaps of the allocations do not move it),
+//     but it can be SEEN: a window of consecutive pieces that straddles a run boundary is fast.
+// So the state block of a large image is a window into a range of per-plane physical allocations (HIP virtual
+// memory API: hipMemCreate / hipMemAddressReserve / hipMemMap): three blocks' worth of plane-sized pieces are created
+// and mapped back to back ONCE, a streaming-store probe that writes exactly the plane sets the kernels write is slid
+// over the candidate windows (a few milliseconds, at allocation time only), and if some window straddles a run
+// boundary it becomes the state block; the pieces outside it are unmapped and released.  The kernels see an ordinary
+// block with a plane stride rounded up to 2 MiB.  If no window is faster than the rest, everything is released and
+// the block is a plain hipMalloc.  Nothing is ever mapped twice: on this runtime (ROCm 7.0/7.2) a piece that is
+// unmapped and mapped again at another address loses stores (tools/vmm_remap_check.hip).
+// Bounded: two extra blocks of transient memory and never more than 8 GiB, one search at a time per process, nothing
+// at all for states below 256 MiB (they live in the Infinity Cache), for frame batches and under stream capture.
+// CVS_OPT_PLACEMENT_SEARCH = 0 takes the plain block without looking.  Results never depend on any of this.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <mutex>
+#include <vector>
+
+#include "cvs_internal.h"
+
+namespace cvs {
+
+namespace {
+
+std::mutex g_place_mutex;
+
+hipMemAllocationProp device_prop(int device)
+{
+    hipMemAllocationProp p = {};
+    p.type = hipMemAllocationTypePinned;
+    p.location.type = hipMemLocationTypeDevice;
+    p.location.id = device;
+    return p;
+}
+
+}  // namespace
+
+void state_block_free(StateBlock& b)
+{
+    if (!b.base) return;
+    if (b.vmm) {
+        for (size_t p = 0; p < b.pieces.size(); ++p) {
+            (void)hipMemUnmap(reinterpret_cast<char*>(b.base) + p * b.piece_bytes, b.piece_bytes);
+            (void)hipMemRelease(b.pieces[p]);
+        }
+        (void)hipMemAddressFree(b.va_base, b.va_bytes);
+    } else {
+        (void)hipFree(b.base);
+    }
+    (void)hipGetLastError();
+    b = StateBlock();
+}
+
+hipError_t state_block_alloc_plain(int device, size_t elems, StateBlock& b)
+{
+    b = StateBlock();
+    b.device = device;
+    hipError_t e = hipMalloc(&b.base, elems * sizeof(float));
+    if (e == hipSuccess) b.elems = elems;
+    return e;
+}
+
+// `mode` 1 = look for a window that straddles a run boundary, else fall back to a plain block; 2 = always take the window
+// in the middle of the pool (tests).  Returns hipSuccess with b.vmm == false whenever the plain block was taken.
+hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b)
+{
+    b = StateBlock();
+    b.device = device;
+    const size_t plain_elems = (size_t)nplanes * ((pitch * rows + 63) / 64 * 64);
+    const hipMemAllocationProp prop = device_prop(device);
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
+        (void)hipGetLastError();
+        return state_block_alloc_plain(device, plain_elems, b);
+    }
+    gran = std::max<size_t>(gran, (size_t)2 << 20);  // planes start on 2 MiB boundaries
+    const size_t piece = (pitch * rows * sizeof(float) + gran - 1) / gran * gran;
+    const bool verbose = std::getenv("CVS_TUNE_VERBOSE") != nullptr;
+    // the pool: the block itself plus at most two more blocks' worth of pieces, and at most 8 GiB of spare memory
+    int pool_n = 3 * nplanes;
+    while (pool_n > nplanes && (size_t)(pool_n - nplanes) * piece > ((size_t)8 << 30)) pool_n -= nplanes / 2;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (size_t)pool_n * piece + ((size_t)4 << 30)) pool_n = nplanes;
+    std::unique_lock<std::mutex> lock(g_place_mutex, std::try_to_lock);
+    if (!lock.owns_lock()) pool_n = nplanes;  // another handle is searching right now: do not disturb its timing
+    if (pool_n <= nplanes && mode == 1) return state_block_alloc_plain(device, plain_elems, b);
+
+    std::vector<hipMemGenericAllocationHandle_t> pool;
+    std::vector<char> mapped;
+    void* pool_va = nullptr;
+    auto release_all = [&] {
+        for (size_t i = 0; i < pool.size(); ++i) {
+            if (i < mapped.size() && mapped[i]) (void)hipMemUnmap((char*)pool_va + i * piece, piece);
+            (void)hipMemRelease(pool[i]);
+        }
+        if (pool_va) (void)hipMemAddressFree(pool_va, piece * pool.size());
+        (void)hipGetLastError();
+    };
+    auto plain = [&] {
+        release_all();
+        return state_block_alloc_plain(device, plain_elems, b);
+    };
+    for (int i = 0; i < pool_n; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if ((int)pool.size() >= nplanes) break;  // enough for a smaller search
+            return plain();
+        }
+        pool.push_back(h);
+    }
+    pool_n = (int)pool.size();
+    if (hipMemAddressReserve(&pool_va, piece * pool_n, gran, nullptr, 0) != hipSuccess) {
+        pool_va = nullptr;
+        return plain();
+    }
+    mapped.assign(pool_n, 0);
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (int i = 0; i < pool_n; ++i) {
+        if (hipMemMap((char*)pool_va + (size_t)i * piece, piece, 0, pool[i], 0) != hipSuccess) return plain();
+        mapped[i] = 1;
+    }
+    if (hipMemSetAccess(pool_va, piece * pool_n, &acc, 1) != hipSuccess) return plain();
+
+    int window = -1;  // first piece of the chosen window
+    if (mode == 2) {
+        window = (pool_n - nplanes) / 2;
+    } else {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        auto measure = [&](int first, int n) {
+            float* planes[12];
+            for (int i = 0; i < n; ++i) planes[i] = reinterpret_cast<float*>((char*)pool_va + (size_t)(first + i) * piece);
+            float best = std::numeric_limits<float>::max();
+            for (int r = 0; r < 3 && ok; ++r) {  // r = 0 warms (first touch of fresh pages)
+                ok = hipEventRecord(e0, stream) == hipSuccess && launch_place_probe(planes, n, rows, pitch, stream) == hipSuccess &&
+                     hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+                float ms = 0.f;
+                if (ok) (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ok && r > 0) best = std::min(best, ms);
+            }
+            return best;
+        };
+        // the plane sets the kernels write: the 7 basis planes (+ caller planes) and the first 12 planes
+        const int n_small = std::min(7, nplanes), n_big = std::min(12, nplanes);
+        std::vector<int> first;
+        for (int k = 0; k + nplanes <= pool_n; k += 2) first.push_back(k);
+        std::vector<float> ts(first.size()), tb(first.size());
+        for (size_t c = 0; c < first.size() && ok; ++c) {
+            ts[c] = measure(first[c], n_small);
+            tb[c] = measure(first[c], n_big);
+        }
+        if (ok && !first.empty()) {
+            // what planes of ONE run take: the slow three quarters of the windows agree on it
+            std::vector<float> ss = ts, sb = tb;
+            std::sort(ss.begin(), ss.end());
+            std::sort(sb.begin(), sb.end());
+            const float ref_s = ss[ss.size() * 3 / 4], ref_b = sb[sb.size() * 3 / 4];
+            float best_score = std::numeric_limits<float>::max();
+            for (size_t c = 0; c < first.size(); ++c) {
+                // a window is worth taking if the many-plane set gains 10 % (a run boundary is worth 15-25 %, noise a few
+                // %) and the 7-plane set does not lose -- or if it is fast in absolute terms (a pool that mixes runs
+                // everywhere has no slow reference: one-run planes stream at 5.2-5.8 TB/s in this probe, mixed ones at 6.4-6.9)
+                const double tbps = (double)n_big * rows * pitch * sizeof(float) / (tb[c] * 1e-3) / 1e12;
+                const float score = ts[c] / ref_s + tb[c] / ref_b;
+                if (((tb[c] < 0.90f * ref_b && ts[c] < 1.02f * ref_s) || tbps >= 6.2) && score < best_score) {
+                    best_score = score;
+                    window = first[c];
+                }
+            }
+            if (verbose) {
+                std::fprintf(stderr, "[cvsteer] placement probe, %d pieces of %zu MiB; ms for %d / %d planes, windows starting at every 2nd piece:", pool_n,
+                             piece >> 20, n_small, n_big);
+                for (size_t c = 0; c < first.size(); ++c) std::fprintf(stderr, " %.4f/%.4f", ts[c], tb[c]);
+                if (window >= 0) std::fprintf(stderr, " -> window at piece %d\n", window);
+                else std::fprintf(stderr, " -> nothing to gain: plain block\n");
+            }
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (!ok) window = -1;
+        (void)hipStreamSynchronize(stream);
+    }
+    if (window < 0) return plain();
+    // the window stays, everything else goes back to the allocator (pieces are unmapped for good, never remapped)
+    for (int i = 0; i < pool_n; ++i) {
+        if (i >= window && i < window + nplanes) continue;
+        (void)hipMemUnmap((char*)pool_va + (size_t)i * piece, piece);
+        (void)hipMemRelease(pool[i]);
+        mapped[i] = 0;
+    }
+    (void)hipGetLastError();
+    b.vmm = true;
+    b.base = reinterpret_cast<float*>((char*)pool_va + (size_t)window * piece);
+    b.piece_bytes = piece;
+    b.elems = (size_t)nplanes * (piece / sizeof(float));
+    b.va_base = pool_va;
+    b.va_bytes = piece * pool_n;
+    b.pieces.assign(pool.begin() + window, pool.begin() + window + nplanes);
+    return hipSuccess;
+}
+
+}  // namespace cvs

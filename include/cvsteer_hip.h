@@ -80,12 +80,15 @@ enum {
                                  0 (default) = 4:3, or what the autotuner found (tuning) */
     CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the second launch of a shape times a few launch configurations and caches the
                                 winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
-    CVS_OPT_PLACEMENT_SEARCH = 11, /* 0 (default) = never.  1 = OPT-IN tuning aid: on its 8th launch of one kernel variant a
-                                      handle (state >= 256 MiB) allocates up to 12 more state blocks -- at most 8 GiB of
-                                      transient device memory in all -- times the launch on each and keeps the fastest.
-                                      Cost: tens of milliseconds, a stream synchronisation, device-wide hipMalloc/hipFree
-                                      stalls; one search at a time per process.  2 = always move to the last candidate
-                                      (tests).  Results never depend on it. */
+    CVS_OPT_PLACEMENT_SEARCH = 11, /* where the state planes of a large image (state >= 256 MiB) live.  1 (default): one physical
+                                      allocation per plane, mapped back to back (planes then start on 2 MiB boundaries); when the
+                                      block is allocated, once, twice as many pieces as planes are created, a streaming-store probe
+                                      is slid over them (a few milliseconds on the handle's stream) and, if it finds the end of a
+                                      run of the VRAM allocator, the planes are dealt from both sides of it (such planes stream at
+                                      ~7.2 instead of ~5.7 TB/s, see cvs_state.cpp); the spare pieces are released again.  Bounded:
+                                      at most one extra block of transient memory and never more than 8 GiB, one search at a time
+                                      per process, none under stream capture.  0 = a plain hipMalloc block, no probe.  2 = always
+                                      deal the planes from both halves of the pool (tests).  Results never depend on it. */
     CVS_OPT_HOST_OVERLAP = 13, /* cvs_setup / cvs_setup_steer / cvs_pipeline with HOST planes on images of 1 Mpix and more:
                                   1 (default) = the image goes up, is filtered and comes down in row bands, all three at once
                                   (full-duplex host link, a second host thread for the downloads); 0 = one after the other */

@@ -949,40 +949,73 @@ def test_overlapped_host_path_matches_device_path(cv):
         assert np.array_equal(f4.basis(p), r4.basis(p).cpu().numpy())
 
 
-def test_placement_search_keeps_results_and_state(cv):
-    """CVS_OPT_PLACEMENT_SEARCH: after a few launches of one shape the handle may move its state to another
-    allocation; outputs and state must be what a handle without the search produces, before and after"""
+def test_plane_placement_keeps_results(cv):
+    """CVS_OPT_PLACEMENT_SEARCH: states of 256 MiB and more get one physical allocation per plane (virtual-memory
+    API), dealt from both sides of a run boundary when the allocation-time probe finds one (mode 1) or always (mode 2,
+    the test mode).  The planes then start at 2 MiB boundaries instead of back to back -- results, state access,
+    later stages, the row-band entry and the state-block cache must not notice."""
+    import ctypes as C
     import torch
     from cvsteer_amd import _lib as L
-    img = torch.rand((4096, 2560), device="cuda")          # state = 12 x 40 MiB: above the 256 MiB threshold
+    img = torch.rand((4099, 2563), device="cuda")          # state = 12 x 40 MiB, plane size not a multiple of 2 MiB
     ref = cv.SteerableFiltersG2(None)
-    ref.set_option(L.OPT_PLACEMENT_SEARCH, 0)
+    ref.set_option(L.OPT_PLACEMENT_SEARCH, 0)               # plain hipMalloc block
     ref.setup(img)
-    want = [ref.basis(p).clone() for p in range(7)] + [ref.getDominantOrientationAngle().clone()]
-    f = cv.SteerableFiltersG2(None)
-    f.set_option(L.OPT_PLACEMENT_SEARCH, 2)                 # 2 = search and always move (1 moves only when it pays)
-    for it in range(12):                                    # the search runs on the 8th launch
-        f.setup(img)
-        if it in (0, 6, 7, 8, 11):
-            got = [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle()]
-            for a, b in zip(got, want):
-                assert torch.equal(a, b), it
-    g, h = f.steer(0.3)                                     # later stages read the (possibly moved) state
+    want = [ref.basis(p).clone() for p in range(7)] + [ref.getDominantOrientationAngle().clone(), ref.getDominantOrientationStrength().clone()]
     g0, h0 = ref.steer(0.3)
-    assert torch.equal(g, g0) and torch.equal(h, h0)
-    # frames handled one by one (host planes): the state of the frames before the 8th call must survive a move
-    import numpy as np
-    frames = np.random.default_rng(3).random((10, 1024, 2304), dtype=np.float32)   # 10 x 12 x 9 MiB of state
-    fb = cv.SteerableFiltersG2(None)
-    fb.set_option(L.OPT_PLACEMENT_SEARCH, 2)
-    out = fb.pipeline_batch(frames, outputs=(0,))
-    fr = cv.SteerableFiltersG2(None)
-    fr.set_option(L.OPT_PLACEMENT_SEARCH, 0)
-    for i in (0, 3, 6, 7, 9):
-        fb.select_frame(i)
-        fr.setup(frames[i])
-        assert np.array_equal(fb.basis(2), fr.basis(2)), i
-        assert np.array_equal(fb.getDominantOrientationAngle(), fr.getDominantOrientationAngle()), i
+    outs0 = ref.pipeline(img)
+    for mode in (2, 1):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_PLACEMENT_SEARCH, mode)
+        for it in range(3):
+            f.setup(img)
+            got = [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle(), f.getDominantOrientationStrength()]
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (mode, it)
+        g, h = f.steer(0.3)                                 # later stages read the per-plane state
+        assert torch.equal(g, g0) and torch.equal(h, h0)
+        for a, b in zip(f.pipeline(img), outs0):
+            assert torch.equal(a, b)
+        gs, hs = f.setup_steer(img, -0.8, flags=cv.SETUP_FULL)
+        gr, hr = ref.setup_steer(img, -0.8, flags=cv.SETUP_FULL)
+        assert torch.equal(gs, gr) and torch.equal(hs, hr)
+        # zero-copy views point into the mapped range, one piece per plane
+        p0, rows, cols, step = f.basis_view(0)
+        p1 = f.basis_view(1)[0]
+        assert (rows, cols) == (4099, 2563) and step == 2624 * 4
+        assert (p1 - p0) % (2 << 20) == 0 and p1 - p0 >= 4099 * 2624 * 4
+        # a smaller image afterwards (plain block), then the big one again
+        small = torch.rand((300, 400), device="cuda")
+        f.setup(small)
+        assert torch.equal(f.basis(3), cv.SteerableFiltersG2(small).basis(3))
+        f.setup(img)
+        assert torch.equal(f.basis(6), want[6])
+        # the row-band entry on a per-plane state
+        f2 = cv.SteerableFiltersG2(None)
+        f2.set_option(L.OPT_PLACEMENT_SEARCH, mode)
+        f2._like = img
+        f2._bind_stream(img)
+        pl = cv.api._plane(img)
+        f2._check(cv.lib().cvs_setup_rows(f2._h, C.byref(pl), cv.SETUP_FULL, 1000, 2500), "cvs_setup_rows")
+        assert torch.equal(f2.basis(5)[1000:2500], want[5][1000:2500])
+        del f, f2
+    # the cache of released blocks hands a per-plane block to the next handle of the same geometry
+    cv.lib().cvs_release_cached_memory()
+    fa = cv.SteerableFiltersG2(None); fa.set_option(L.OPT_PLACEMENT_SEARCH, 2); fa.setup(img)
+    addr = fa.basis_view(0)[0]
+    del fa
+    fb = cv.SteerableFiltersG2(None); fb.set_option(L.OPT_PLACEMENT_SEARCH, 2); fb.setup(img)
+    assert fb.basis_view(0)[0] == addr
+    assert torch.equal(fb.basis(1), want[1])
+    cv.lib().cvs_release_cached_memory()
+    # G4 (16 planes) through the same allocation path
+    f4 = cv.SteerableFiltersG4(None); f4.set_option(L.OPT_PLACEMENT_SEARCH, 2)
+    r4 = cv.SteerableFiltersG4(None); r4.set_option(L.OPT_PLACEMENT_SEARCH, 0)
+    a4, b4 = f4.setup_steer(img, 0.3)
+    c4, d4 = r4.setup_steer(img, 0.3)
+    assert torch.equal(a4, c4) and torch.equal(b4, d4)
+    for p in (0, 4, 10):
+        assert torch.equal(f4.basis(p), r4.basis(p))
 
 
 def test_hip_graph_capture_and_replay(cv):
