@@ -329,6 +329,41 @@ def main():
         del imgs8
 
         if ws == 1:
+            # (this leg runs before the legs that allocate multi-GiB states: on this runtime the device-to-host copy rate of
+            # a process drops from 56 to ~30 GB/s for a while after gigabytes of virtual-memory map / unmap traffic --
+            # tools/pcie_probe.hip shows it with plain HIP calls only)
+            # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in and out -- a
+            # stream of 8 different host images, 64 MiB up and 2 x 64 MiB down per image, pageable host memory.  The call
+            # overlaps upload, filtering and download band by band (cvs_api.cpp host_pipeline); `sequential` is the same
+            # with CVS_OPT_HOST_OVERLAP = 0.  Floor of the link: 128 MiB down at ~56 GB/s = 2.4 ms per image.
+            import numpy as np
+            himgs = [np.random.default_rng(500 + i).random((ROWS, COLS), dtype=np.float32) for i in range(8)]
+            hg, hh = np.empty_like(himgs[0]), np.empty_like(himgs[0])
+
+            fhs = {}
+            for overlap in (0, 1):
+                fhs[overlap] = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+                fhs[overlap].set_option(L.OPT_HOST_OVERLAP, overlap)
+                fhs[overlap].setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
+
+            def host_stream(overlap):
+                t0 = time.perf_counter()
+                for im in himgs:
+                    fhs[overlap].setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
+                return (time.perf_counter() - t0) / len(himgs)
+
+            # two interleaved passes, the better one of each mode (the first pass also pages the host arrays in)
+            dt_seq, dt_ovl = min(host_stream(0), host_stream(0)), min(host_stream(1), host_stream(1))
+            dt_seq, dt_ovl = min(dt_seq, host_stream(0)), min(dt_ovl, host_stream(1))
+            del fhs
+            extra["M2_host_planes_pcie_inclusive"] = {"Mpix/s": round(npix / dt_ovl / 1e6, 1), "ms": round(dt_ovl * 1e3, 3),
+                                                      "sequential_Mpix/s": round(npix / dt_seq / 1e6, 1), "sequential_ms": round(dt_seq * 1e3, 3),
+                                                      "note": "stream of 8 host f32 images in, g2/h2 out to host, bases stay on device; "
+                                                              "link floor = 128 MiB down per image"}
+            del himgs
+
+
+        if ws == 1:
             # throughput mode: consecutive images go to two handles on two HIP streams, so the tail of one launch
             # overlaps the start-up of the next (tools/two_streams.py)
             f2 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
@@ -473,35 +508,6 @@ def main():
                                                 "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                 "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix}
             del big, lv, hp, fp3
-            # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in and out -- a
-            # stream of 8 different host images, 64 MiB up and 2 x 64 MiB down per image, pageable host memory.  The call
-            # overlaps upload, filtering and download band by band (cvs_api.cpp host_pipeline); `sequential` is the same
-            # with CVS_OPT_HOST_OVERLAP = 0.  Floor of the link: 128 MiB down at ~56 GB/s = 2.4 ms per image.
-            import numpy as np
-            himgs = [np.random.default_rng(500 + i).random((ROWS, COLS), dtype=np.float32) for i in range(8)]
-            hg, hh = np.empty_like(himgs[0]), np.empty_like(himgs[0])
-
-            fhs = {}
-            for overlap in (0, 1):
-                fhs[overlap] = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-                fhs[overlap].set_option(L.OPT_HOST_OVERLAP, overlap)
-                fhs[overlap].setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
-
-            def host_stream(overlap):
-                t0 = time.perf_counter()
-                for im in himgs:
-                    fhs[overlap].setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
-                return (time.perf_counter() - t0) / len(himgs)
-
-            # two interleaved passes, the better one of each mode (the first pass also pages the host arrays in)
-            dt_seq, dt_ovl = min(host_stream(0), host_stream(0)), min(host_stream(1), host_stream(1))
-            dt_seq, dt_ovl = min(dt_seq, host_stream(0)), min(dt_ovl, host_stream(1))
-            del fhs
-            extra["M2_host_planes_pcie_inclusive"] = {"Mpix/s": round(npix / dt_ovl / 1e6, 1), "ms": round(dt_ovl * 1e3, 3),
-                                                      "sequential_Mpix/s": round(npix / dt_seq / 1e6, 1), "sequential_ms": round(dt_seq * 1e3, 3),
-                                                      "note": "stream of 8 host f32 images in, g2/h2 out to host, bases stay on device; "
-                                                              "link floor = 128 MiB down per image"}
-            del himgs
         out["extra"] = extra
 
     if rank == 0 and ws == 1 and not args.no_cpu:

@@ -19,6 +19,26 @@ int main()
     CK(hipMalloc(&d_in, P)); CK(hipMalloc(&d_out, 2 * P));
     hipStream_t su, sd;
     CK(hipStreamCreateWithFlags(&su, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sd, hipStreamNonBlocking));
+    for (int phase = 0; phase < 3; ++phase) {
+    if (phase == 1) {
+        // a storm of virtual-memory operations, as the placement search of an 8192^2 state makes them: 36 physical pieces of
+        // 256 MiB created, mapped into one range, unmapped and released
+        hipMemAllocationProp pr = {}; pr.type = hipMemAllocationTypePinned; pr.location.type = hipMemLocationTypeDevice;
+        hipMemAccessDesc acc = {}; acc.location.type = hipMemLocationTypeDevice; acc.flags = hipMemAccessFlagsProtReadWrite;
+        const size_t pb = 256ull << 20; const int np = 36;
+        std::vector<hipMemGenericAllocationHandle_t> hs(np);
+        void* va; CK(hipMemAddressReserve(&va, np * pb, 2ull << 20, nullptr, 0));
+        for (int i = 0; i < np; ++i) { CK(hipMemCreate(&hs[i], pb, &pr, 0)); CK(hipMemMap((char*)va + i * pb, pb, 0, hs[i], 0)); }
+        CK(hipMemSetAccess(va, np * pb, &acc, 1));
+        CK(hipMemset(va, 1, np * pb)); CK(hipDeviceSynchronize());
+        for (int i = 0; i < np; ++i) { CK(hipMemUnmap((char*)va + i * pb, pb)); CK(hipMemRelease(hs[i])); }
+        CK(hipMemAddressFree(va, np * pb));
+        printf("--- after 36 x 256 MiB of hipMemCreate / Map / Unmap / Release ---\n");
+    }
+    if (phase == 2) {
+        void* t; CK(hipMalloc(&t, 3ull << 30)); CK(hipMemset(t, 0, 3ull << 30)); CK(hipDeviceSynchronize()); CK(hipFree(t));
+        printf("--- after a 3 GiB hipMalloc / hipFree ---\n");
+    }
     for (int pinned = 0; pinned < 2; ++pinned) {
         char *h_in, *h_out;
         if (pinned) { CK(hipHostMalloc(&h_in, P)); CK(hipHostMalloc(&h_out, 2 * P)); }
@@ -62,6 +82,7 @@ int main()
             printf("CPU memcpy of 64 MiB into pinned memory, one thread: %.3f ms (%.1f GB/s)\n", best, P / best / 1e6);
             free(src);
         }
+    }
     }
     return 0;
 }
