@@ -329,9 +329,10 @@ def main():
         del imgs8
 
         if ws == 1:
-            # (this leg runs before the legs that allocate multi-GiB states: on this runtime the device-to-host copy rate of
-            # a process drops from 56 to ~30 GB/s for a while after gigabytes of virtual-memory map / unmap traffic --
-            # tools/pcie_probe.hip shows it with plain HIP calls only)
+            # (for a second or two after gigabytes of device memory have been released -- the spare pieces of a placement
+            # search, any large hipFree -- host-link copies of the process run at about half rate, 56 -> 30 GB/s both
+            # ways, tools/d2h_probe.hip with plain HIP calls; the handles below are created, searched and warmed first,
+            # then the leg waits that out)
             # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in and out -- a
             # stream of 8 different host images, 64 MiB up and 2 x 64 MiB down per image, pageable host memory.  The call
             # overlaps upload, filtering and download band by band (cvs_api.cpp host_pipeline); `sequential` is the same
@@ -345,6 +346,9 @@ def main():
                 fhs[overlap] = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
                 fhs[overlap].set_option(L.OPT_HOST_OVERLAP, overlap)
                 fhs[overlap].setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
+
+            torch.cuda.synchronize()
+            time.sleep(2.5)
 
             def host_stream(overlap):
                 t0 = time.perf_counter()

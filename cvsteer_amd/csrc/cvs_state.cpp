@@ -19,12 +19,21 @@
 // block with a plane stride rounded up to 2 MiB.  If no window is faster than the rest, everything is released and
 // the block is a plain hipMalloc.  Nothing is ever mapped twice: on this runtime (ROCm 7.0/7.2) a piece that is
 // unmapped and mapped again at another address loses stores (tools/vmm_remap_check.hip).
-// Bounded: two extra blocks of transient memory and never more than 8 GiB, one search at a time per process, nothing
+// New pieces mapped into a range that held other pieces before lose stores as well (tools/vmm_reuse_check.hip: up to
+// 8 % of the checked values wrong from the third generation on; a fresh range per generation: none).  So a reserved
+// virtual range is used ONCE and never freed: when a block goes, its pieces are unmapped and released (the memory is
+// back) and the addresses stay reserved.  That costs address space only -- 3.75 GiB per searched 4096^2 state out of
+// 128 TiB -- and is capped: after 4 TiB of such reservations in a process the engine stops searching and takes plain
+// blocks.  (Unrelated to correctness, but visible: for a second or two after gigabytes of device memory have been
+// released -- the spare pieces of a search, or any large hipFree -- host-link copies of the process run at about half
+// rate, 56 -> 30 GB/s in both directions, tools/d2h_probe.hip; two seconds later they are back.)
+// Bounded: four extra blocks of transient memory and never more than 8 GiB, one search at a time per process, nothing
 // at all for states below 256 MiB (they live in the Infinity Cache), for frame batches and under stream capture.
 // CVS_OPT_PLACEMENT_SEARCH = 0 takes the plain block without looking.  Results never depend on any of this.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
@@ -38,6 +47,8 @@ namespace cvs {
 namespace {
 
 std::mutex g_place_mutex;
+std::atomic<size_t> g_reserved_va{0};                  // bytes of virtual range reserved by searches so far (never freed)
+constexpr size_t kMaxReservedVa = (size_t)4 << 40;
 
 hipMemAllocationProp device_prop(int device)
 {
@@ -58,7 +69,7 @@ void state_block_free(StateBlock& b)
             (void)hipMemUnmap(reinterpret_cast<char*>(b.base) + p * b.piece_bytes, b.piece_bytes);
             (void)hipMemRelease(b.pieces[p]);
         }
-        (void)hipMemAddressFree(b.va_base, b.va_bytes);
+        // the virtual range stays reserved for the life of the process (see the header comment)
     } else {
         (void)hipFree(b.base);
     }
@@ -91,14 +102,15 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
     gran = std::max<size_t>(gran, (size_t)2 << 20);  // planes start on 2 MiB boundaries
     const size_t piece = (pitch * rows * sizeof(float) + gran - 1) / gran * gran;
     const bool verbose = std::getenv("CVS_TUNE_VERBOSE") != nullptr;
-    // the pool: the block itself plus at most two more blocks' worth of pieces, and at most 8 GiB of spare memory
-    int pool_n = 3 * nplanes;
+    // the pool: the block itself plus at most four more blocks' worth of pieces, and at most 8 GiB of spare memory
+    int pool_n = 5 * nplanes;
     while (pool_n > nplanes && (size_t)(pool_n - nplanes) * piece > ((size_t)8 << 30)) pool_n -= nplanes / 2;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (size_t)pool_n * piece + ((size_t)4 << 30)) pool_n = nplanes;
     std::unique_lock<std::mutex> lock(g_place_mutex, std::try_to_lock);
     if (!lock.owns_lock()) pool_n = nplanes;  // another handle is searching right now: do not disturb its timing
-    if (pool_n <= nplanes && mode == 1) return state_block_alloc_plain(device, plain_elems, b);
+    if (g_reserved_va.load() + (size_t)pool_n * piece > kMaxReservedVa) pool_n = nplanes;  // address-space budget spent
+    if (pool_n <= nplanes) return state_block_alloc_plain(device, plain_elems, b);
 
     std::vector<hipMemGenericAllocationHandle_t> pool;
     std::vector<char> mapped;
@@ -108,7 +120,7 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
             if (i < mapped.size() && mapped[i]) (void)hipMemUnmap((char*)pool_va + i * piece, piece);
             (void)hipMemRelease(pool[i]);
         }
-        if (pool_va) (void)hipMemAddressFree(pool_va, piece * pool.size());
+        // pool_va stays reserved: a range is never freed and never used twice (see the header comment)
         (void)hipGetLastError();
     };
     auto plain = [&] {
@@ -129,6 +141,7 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
         pool_va = nullptr;
         return plain();
     }
+    g_reserved_va += piece * pool_n;
     mapped.assign(pool_n, 0);
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
@@ -145,11 +158,11 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
     } else {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-        auto measure = [&](int first, int n) {
+        auto measure = [&](int first, int n, int timed) {
             float* planes[12];
             for (int i = 0; i < n; ++i) planes[i] = reinterpret_cast<float*>((char*)pool_va + (size_t)(first + i) * piece);
             float best = std::numeric_limits<float>::max();
-            for (int r = 0; r < 3 && ok; ++r) {  // r = 0 warms (first touch of fresh pages)
+            for (int r = 0; r <= timed && ok; ++r) {  // r = 0 warms (first touch of fresh pages)
                 ok = hipEventRecord(e0, stream) == hipSuccess && launch_place_probe(planes, n, rows, pitch, stream) == hipSuccess &&
                      hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
                 float ms = 0.f;
@@ -160,35 +173,51 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
         };
         // the plane sets the kernels write: the 7 basis planes (+ caller planes) and the first 12 planes
         const int n_small = std::min(7, nplanes), n_big = std::min(12, nplanes);
+        const int last = pool_n - nplanes;
+        // stage 1: every third window, the 12-plane set, one timed launch -- where is it fast at all?
         std::vector<int> first;
-        for (int k = 0; k + nplanes <= pool_n; k += 2) first.push_back(k);
-        std::vector<float> ts(first.size()), tb(first.size());
-        for (size_t c = 0; c < first.size() && ok; ++c) {
-            ts[c] = measure(first[c], n_small);
-            tb[c] = measure(first[c], n_big);
-        }
+        for (int k = 0; k <= last; k += 3) first.push_back(k);
+        std::vector<float> t1(first.size());
+        for (size_t c = 0; c < first.size() && ok; ++c) t1[c] = measure(first[c], n_big, 1);
         if (ok && !first.empty()) {
             // what planes of ONE run take: the slow three quarters of the windows agree on it
-            std::vector<float> ss = ts, sb = tb;
-            std::sort(ss.begin(), ss.end());
-            std::sort(sb.begin(), sb.end());
-            const float ref_s = ss[ss.size() * 3 / 4], ref_b = sb[sb.size() * 3 / 4];
-            float best_score = std::numeric_limits<float>::max();
-            for (size_t c = 0; c < first.size(); ++c) {
-                // a window is worth taking if the many-plane set gains 10 % (a run boundary is worth 15-25 %, noise a few
-                // %) and the 7-plane set does not lose -- or if it is fast in absolute terms (a pool that mixes runs
-                // everywhere has no slow reference: one-run planes stream at 5.2-5.8 TB/s in this probe, mixed ones at 6.4-6.9)
-                const double tbps = (double)n_big * rows * pitch * sizeof(float) / (tb[c] * 1e-3) / 1e12;
-                const float score = ts[c] / ref_s + tb[c] / ref_b;
-                if (((tb[c] < 0.90f * ref_b && ts[c] < 1.02f * ref_s) || tbps >= 6.2) && score < best_score) {
-                    best_score = score;
-                    window = first[c];
+            std::vector<float> sorted = t1;
+            std::sort(sorted.begin(), sorted.end());
+            const float ref_b = sorted[sorted.size() * 3 / 4];
+            const int c1 = (int)(std::min_element(t1.begin(), t1.end()) - t1.begin());
+            const double tbps1 = (double)n_big * rows * pitch * sizeof(float) / (t1[c1] * 1e-3) / 1e12;
+            std::vector<int> fine;
+            std::vector<float> ts, tb;
+            // a run boundary is worth 15-25 % (noise a few %); a pool that mixes runs everywhere has no slow reference,
+            // so a window that is fast in absolute terms counts too (one-run planes stream at 5.2-5.8 TB/s in this probe,
+            // mixed ones at 6.4-6.9)
+            if (t1[c1] < 0.92f * ref_b || tbps1 >= 6.2) {
+                // stage 2: the windows around the best one, both plane sets, two timed launches
+                // the 7-plane reference: a typical one-run window (the one with the median 12-plane time)
+                int cm = 0;
+                for (size_t c = 0; c < t1.size(); ++c)
+                    if (t1[c] == sorted[sorted.size() / 2]) cm = (int)c;
+                const float ref_s = measure(first[cm], n_small, 2);
+                float best_score = std::numeric_limits<float>::max();
+                for (int k = std::max(0, first[c1] - 2); k <= std::min(last, first[c1] + 2) && ok; ++k) {
+                    fine.push_back(k);
+                    ts.push_back(measure(k, n_small, 2));
+                    tb.push_back(measure(k, n_big, 2));
+                    const double tbps = (double)n_big * rows * pitch * sizeof(float) / (tb.back() * 1e-3) / 1e12;
+                    const float score = ts.back() / ref_s + tb.back() / ref_b;
+                    if (((tb.back() < 0.90f * ref_b && ts.back() < 1.03f * ref_s) || tbps >= 6.2) && score < best_score) {
+                        best_score = score;
+                        window = k;
+                    }
                 }
             }
             if (verbose) {
-                std::fprintf(stderr, "[cvsteer] placement probe, %d pieces of %zu MiB; ms for %d / %d planes, windows starting at every 2nd piece:", pool_n,
-                             piece >> 20, n_small, n_big);
-                for (size_t c = 0; c < first.size(); ++c) std::fprintf(stderr, " %.4f/%.4f", ts[c], tb[c]);
+                std::fprintf(stderr, "[cvsteer] placement probe, %d pieces of %zu MiB; %d-plane windows at every 3rd piece (ms):", pool_n, piece >> 20, n_big);
+                for (size_t c = 0; c < first.size(); ++c) std::fprintf(stderr, " %.4f", t1[c]);
+                if (!fine.empty()) {
+                    std::fprintf(stderr, "; around piece %d, %d / %d planes:", first[c1], n_small, n_big);
+                    for (size_t c = 0; c < fine.size(); ++c) std::fprintf(stderr, " %d:%.4f/%.4f", fine[c], ts[c], tb[c]);
+                }
                 if (window >= 0) std::fprintf(stderr, " -> window at piece %d\n", window);
                 else std::fprintf(stderr, " -> nothing to gain: plain block\n");
             }

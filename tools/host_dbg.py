@@ -17,24 +17,18 @@ def run(tag):
             for im in imgs: f.setup_steer(im, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
             best = min(best, (time.perf_counter() - t0) / len(imgs))
         res[overlap] = best * 1e3
-    print("%-60s sequential %.3f ms  overlapped %.3f ms" % (tag, res[0], res[1]), flush=True)
-run("fresh process")
-big = torch.rand((8192, 8192), device="cuda")
-fb = cv.SteerableFiltersG2(None); fb.set_option(L.OPT_PLACEMENT_SEARCH, 1); fb.setup(big, flags=cv.SETUP_BASIS); torch.cuda.synchronize()
-run("while a handle with a searched 8192^2 state is alive")
-del fb
-run("after that handle was destroyed (block in the cache)")
-cv.lib().cvs_release_cached_memory()
-run("after the block cache was emptied")
-frames = torch.rand((32, 1080, 1920), device="cuda"); fout = torch.empty((32, 8, 1080, 1920), device="cuda")
-ff = cv.SteerableFiltersG2(None)
-for _ in range(5): ff.pipeline_batch(frames, out=fout)
-torch.cuda.synchronize(); del ff, frames, fout
-run("after a 32-frame batch (3.2 GB plain state) came and went")
-lv = cv.SteerableFiltersG2(None).pyramid(big, 5)
-hp = [cv.SteerableFiltersG2(None) for _ in lv]
-for hnd, l in zip(hp, lv): hnd.setup(l, flags=cv.SETUP_BASIS)
-torch.cuda.synchronize()
-run("with five pyramid-level handles alive")
-del hp, lv
-run("after they were destroyed")
+    print("%-64s sequential %.3f ms  overlapped %.3f ms" % (tag, res[0], res[1]), flush=True)
+run("fresh process (plain states)")
+img = torch.rand((n, n), device="cuda")
+f0 = cv.SteerableFiltersG2(None); f0.set_option(L.OPT_PLACEMENT_SEARCH, 0); f0.setup(img); torch.cuda.synchronize()
+run("while a handle with a PLAIN 4096^2 state is alive")
+f1 = cv.SteerableFiltersG2(None); f1.set_option(L.OPT_PLACEMENT_SEARCH, 1); f1.setup(img); torch.cuda.synchronize()
+run("while a handle with a searched state is alive")
+time.sleep(2.0)
+run("... two seconds later")
+f1.set_option(L.OPT_PLACEMENT_SEARCH, 0); f1.setup(img); torch.cuda.synchronize()
+run("after that handle switched to a plain block (window unmapped + released)")
+f2 = cv.SteerableFiltersG2(None); f2.set_option(L.OPT_PLACEMENT_SEARCH, 2); f2.setup(img); torch.cuda.synchronize()
+run("while a handle with a forced window (mode 2) is alive")
+del f2
+run("after it was destroyed (parked in the cache)")
