@@ -12,7 +12,7 @@
 //   * where a run ends cannot be predicted from the API (sizes, order and gaps of the allocations do not move it),
 //     but it can be SEEN: a window of consecutive pieces that straddles a run boundary is fast.
 // So the state block of a large image is a window into a range of per-plane physical allocations (HIP virtual
-// memory API: hipMemCreate / hipMemAddressReserve / hipMemMap): three blocks' worth of plane-sized pieces are created
+// memory API: hipMemCreate / hipMemAddressReserve / hipMemMap): five blocks' worth of plane-sized pieces are created
 // and mapped back to back ONCE, a streaming-store probe that writes exactly the plane sets the kernels write is slid
 // over the candidate windows (a few milliseconds, at allocation time only), and if some window straddles a run
 // boundary it becomes the state block; the pieces outside it are unmapped and released.  The kernels see an ordinary

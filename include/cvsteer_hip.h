@@ -82,13 +82,16 @@ enum {
                                 winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
     CVS_OPT_PLACEMENT_SEARCH = 11, /* where the state planes of a large image (state >= 256 MiB) live.  1 (default): one physical
                                       allocation per plane, mapped back to back (planes then start on 2 MiB boundaries); when the
-                                      block is allocated, once, twice as many pieces as planes are created, a streaming-store probe
-                                      is slid over them (a few milliseconds on the handle's stream) and, if it finds the end of a
-                                      run of the VRAM allocator, the planes are dealt from both sides of it (such planes stream at
-                                      ~7.2 instead of ~5.7 TB/s, see cvs_state.cpp); the spare pieces are released again.  Bounded:
-                                      at most one extra block of transient memory and never more than 8 GiB, one search at a time
-                                      per process, none under stream capture.  0 = a plain hipMalloc block, no probe.  2 = always
-                                      deal the planes from both halves of the pool (tests).  Results never depend on it. */
+                                      block is allocated, once, five blocks' worth of pieces are created and mapped, a streaming-
+                                      store probe is slid over them (10-12 ms at 4096^2 on the handle's stream) and, if some window
+                                      of pieces straddles the end of a run of the VRAM allocator, that window becomes the block
+                                      (such planes stream at ~7.2 instead of ~5.7 TB/s, see cvs_state.cpp); the spare pieces are
+                                      released again, else everything is and the block is a plain hipMalloc.  Bounded: at most four
+                                      extra blocks of transient memory and never more than 8 GiB; one search at a time per
+                                      process; none under stream capture; each search keeps its virtual range reserved for the
+                                      life of the process (address space only, capped at 4 TiB).  0 = a plain hipMalloc block,
+                                      no probe.  2 = always take the window in the middle of the pool (tests).  Results never
+                                      depend on it. */
     CVS_OPT_HOST_OVERLAP = 13, /* cvs_setup / cvs_setup_steer / cvs_pipeline with HOST planes on images of 1 Mpix and more:
                                   1 (default) = the image goes up, is filtered and comes down in row bands, all three at once
                                   (full-duplex host link, a second host thread for the downloads); 0 = one after the other */
