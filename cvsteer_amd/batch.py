@@ -172,7 +172,11 @@ class NativeBatch:
         if h:
             _L.lib().cvs_batch_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: module globals may be gone already
+            pass
 
     def _check(self, rc, where):
         if rc:
