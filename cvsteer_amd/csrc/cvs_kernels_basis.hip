@@ -198,11 +198,14 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     if (x0 >= a.cols) return;  // wave-uniform; waves of a workgroup never rendezvous
 #ifdef CVS_DIAG_STAMPS
     unsigned long long* stamp = a.diag ? a.diag + ((size_t)(by * a.grid_x + bx) * WPB + wv) * 4 : nullptr;
-    bool stamped_first = false;
+    [[maybe_unused]] bool stamped_first = false;
     if (stamp && lane == 0) {
         stamp[0] = __builtin_amdgcn_s_memrealtime();
         stamp[3] = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]: the XCD this wave runs on
     }
+#ifdef CVS_DIAG_CLOCK
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();  // shader-clock ticks; stamp[1] then holds the ticks this wave lived
+#endif
 #endif
     // Planes of 2 GiB and more are filtered in row bands, one launch per band: the host shifts every plane
     // pointer down by row_base rows, so that the 32-bit buffer offsets of the band (halo included) stay
@@ -335,7 +338,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             const unsigned xbr = xb;
             if (row_ok) {
 #ifdef CVS_DIAG_STAMPS
+#ifndef CVS_DIAG_CLOCK
                 if (stamp && !stamped_first) { stamped_first = true; if (lane == 0) stamp[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 #endif
                 float b[NB];
 #pragma unroll
@@ -429,7 +434,13 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
         }
     }
 #ifdef CVS_DIAG_STAMPS
-    if (stamp && lane == 0) { __builtin_amdgcn_s_waitcnt(0); stamp[2] = __builtin_amdgcn_s_memrealtime(); }
+    if (stamp && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        stamp[2] = __builtin_amdgcn_s_memrealtime();
+#ifdef CVS_DIAG_CLOCK
+        stamp[1] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
+    }
 #endif
 }
 
