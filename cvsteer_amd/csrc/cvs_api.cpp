@@ -369,7 +369,7 @@ int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input = fals
     // strips whose (rows + 2W) is a multiple of the 2W+1-row unroll waste no loop iterations.
     // Measured on MI355X at 4096x4096 (tools/ab.py, tools/ab_g4.py; streaming stores): short strips
     // win -- 19 rows for the 7-plane G2 kernel (~14k waves keep every CU's store queues busy, the
-    // extra halo rows are cache hits), 27 rows for the G4 half banks run in one launch.
+    // extra halo rows are cache hits), 40 rows for the G4 half banks run in one launch.
     const int nt = 2 * h->width + 1, halo = 2 * h->width;
     const long strips_x = (cols + 63) / 64;
     const double ideal = (double)rows * (double)strips_x / 2048.0;
@@ -379,7 +379,9 @@ int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input = fals
     // ... and so do inputs that are not cache-resident: when consecutive calls bring DIFFERENT images, the
     // halo rows of vertically adjacent strips only hit in cache if those strips run close in time
     // (tools/ab_rot.py, 8 rotating 4096x4096 inputs: 10-row strips 66 %, 19-row strips 57 %)
-    const long kmax = (h->kind == CVS_KIND_G2 && (fresh_input || (size_t)rows * cols >= ((size_t)32 << 20))) ? 2 : 3;
+    // G4 half banks: 40-row strips (k = 4) filter 30 % more rows than they write, 27-row strips 44 %; the kernel is
+    // SIMD-bound, so the taller strip wins by 1-3 points (tools/ab_same.py AB_KIND=4 "2=27" "2=40" "2=53", round 2)
+    const long kmax = h->kind == CVS_KIND_G4 ? 4 : (fresh_input || (size_t)rows * cols >= ((size_t)32 << 20)) ? 2 : 3;
     if (k < 2) k = 2;
     if (k > kmax) k = kmax;
     return (int)(k * nt - halo);
@@ -492,6 +494,8 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     } else {
         if (free_order) list[ncand++] = {1, xw0, sr0, sp0};
         if (free_split) list[ncand++] = {o0, xw0, sr0, 0};  // one 11-plane kernel instead of the two half banks
+        const int sr_g4 = 3 * (2 * h->width + 1) - 2 * h->width;  // the shorter strip (27 rows at width 6)
+        if (free_strip && sr_g4 != sr0) list[ncand++] = {o0, xw0, sr_g4, sp0};
     }
     float tmin[6];
     for (float& t : tmin) t = std::numeric_limits<float>::max();
