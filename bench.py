@@ -490,6 +490,32 @@ def main():
                 del e2e_out
             except Exception as ex:   # a failing end-to-end leg must not take the headline down with it
                 extra["C4_e2e"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            # ---- the same from HOST planes (what example/steer.cpp holds): each rank uploads its own frames from host memory,
+            # launches, downloads its three maps -- chunked and overlapped inside the rank (cvs_batch_run, host planes).
+            # PCIe-inclusive; never `value`.
+            try:
+                import numpy as _np
+                hb = batch.NativeBatch.local((local_rank,))
+                hb.set_persist(False)
+                host_in = fsets[0].cpu().numpy()
+                host_out = _np.empty((nfr, 3) + shape, _np.float32)
+                time.sleep(2.0)   # host-link copies run at half rate for a moment after large device frees
+                best, tm_best = None, None
+                for rep in range(4):
+                    t0 = time.perf_counter()
+                    _, tm = hb.run(host_in, nfr, shape, outputs=(5, 6, 7), out=host_out)
+                    dt = time.perf_counter() - t0
+                    if rep and (best is None or dt < best):
+                        best, tm_best = dt, tm
+                (best,) = max_over_ranks(best)
+                extra["C4_e2e_host_planes"] = {"frames_per_gpu": nfr, "ms_wall": round(best * 1e3, 2), "ms": {"upload": round(tm_best["scatter"], 2), "download": round(tm_best["gather"], 2), "span": round(tm_best["compute"], 2)},
+                                               "end_to_end_Mpix/s": round(ws * nfr * 1080 * 1920 / best / 1e6, 1),
+                                               "link_floor_ms": round(nfr * 1080 * 1920 * 4 * 3 / 56e9 * 1e3, 2),
+                                               "note": "host f32 frames in, 3 host f32 maps out per frame; every rank moves its own shard over its own link; floor = the download at 56 GB/s"}
+                hb.close()
+                del host_in, host_out
+            except Exception as ex:
+                extra["C4_e2e_host_planes"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         del fsets, ff, all_frames
 
         if ws == 1:

@@ -193,14 +193,30 @@ class NativeBatch:
 
     # -- config 4 --
     def run(self, frames, n_frames, frame_shape, outputs=(5, 6, 7), out=None, root=0, gather=True, self_via_transport=False):
-        """frames: [n_frames, H, W] float32 CUDA tensor on the root (None elsewhere).  Returns
+        """frames: [n_frames, H, W] float32 CUDA tensor on the root (None elsewhere), or a numpy array of that shape
+        (host planes: every rank must be local to this process; each GPU pulls its frames over its own link).  Returns
         (out [n_frames, len(outputs), H, W] on the root or None, {'scatter','compute','gather'} milliseconds)."""
         rows, cols = (int(v) for v in frame_shape)
         sel = [int(k) for k in outputs]
         cfg = _L.BatchCfg(rows, cols, int(n_frames), sum(1 << k for k in sel), int(root), 1 if gather else 0, 1 if self_via_transport else 0)
         imgs = outs = None
         is_root = frames is not None
-        if is_root:
+        if is_root and isinstance(frames, _np.ndarray):
+            from .api import _PLANE_DTYPE
+            assert frames.dtype == _np.float32 and frames.shape == (n_frames, rows, cols) and frames.strides[2] == 4 and frames.strides[1] >= cols * 4
+            imgs = _np.zeros(n_frames, _PLANE_DTYPE)
+            imgs["data"] = frames.ctypes.data + _np.arange(n_frames, dtype=_np.uint64) * _np.uint64(frames.strides[0])
+            imgs["rows"], imgs["cols"], imgs["step"], imgs["mem"] = rows, cols, frames.strides[1], _L.MEM_HOST
+            if gather:
+                if out is None:
+                    out = _np.empty((n_frames, len(sel), rows, cols), _np.float32)
+                assert isinstance(out, _np.ndarray) and out.dtype == _np.float32 and out.flags.c_contiguous and out.shape == (n_frames, len(sel), rows, cols)
+                outs = _np.zeros((n_frames, 8), _PLANE_DTYPE)
+                off = _np.arange(n_frames, dtype=_np.uint64) * _np.uint64(len(sel) * rows * cols * 4)
+                for j, k in enumerate(sel):
+                    outs["data"][:, k] = out.ctypes.data + off + _np.uint64(j * rows * cols * 4)
+                    outs["rows"][:, k], outs["cols"][:, k], outs["step"][:, k], outs["mem"][:, k] = rows, cols, cols * 4, _L.MEM_HOST
+        elif is_root:
             assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and tuple(frames.shape) == (n_frames, rows, cols)
             from .api import _PLANE_DTYPE
             imgs = _np.zeros(n_frames, _PLANE_DTYPE)

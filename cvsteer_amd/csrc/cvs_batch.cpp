@@ -25,9 +25,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cvsteer_hip.h"
@@ -117,6 +119,7 @@ struct Slot {
     int last_n = 0, last_k = 0, last_rows = 0, last_cols = 0;  // layout of `out` after the last cvs_batch_run
     bool last_staged = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t up = nullptr, down = nullptr;  // host planes: upload / download streams beside `stream`
 };
 
 }  // namespace
@@ -281,6 +284,205 @@ bool dense_device(const cvs_plane* p, int rows, int cols)
     return p && p->data && p->mem == CVS_MEM_DEVICE && p->rows == rows && p->cols == cols && p->step == (size_t)cols * sizeof(float);
 }
 
+// is `p` a rows x cols f32 HOST plane (rows may be padded)?
+bool host_plane(const cvs_plane* p, int rows, int cols)
+{
+    return p && p->data && p->mem == CVS_MEM_HOST && p->rows == rows && p->cols == cols && p->step >= (size_t)cols * sizeof(float);
+}
+
+// Host planes (the reference's callers hold cv::Mat: example/steer.cpp:73-104).  Nothing goes through the root's GPU:
+// every rank pulls ITS frames from the caller's host planes over its own PCIe link and pushes its outputs back the
+// same way, all ranks at once.  Inside a rank the shard is cut into chunks of frames and three things overlap, as
+// in the single-image host path of cvs_api.cpp: the upload of chunk c+1 (stream `up`, this rank's worker thread),
+// the launch for chunk c (the rank's stream) and the download of chunk c-1 (stream `down`, a second thread --
+// copies from / to pageable memory hold the calling thread).  Needs every rank in this process.
+struct HostRun {
+    cvs_batch b;
+    const cvs_batch_cfg* cfg;
+    const cvs_plane *inputs, *outputs;
+    int sel[8], K;
+};
+
+int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
+{
+    cvs_batch b = R.b;
+    const int rows = R.cfg->rows, cols = R.cfg->cols, K = R.K;
+    const size_t plane = (size_t)rows * cols, rowb = (size_t)cols * sizeof(float);
+    int lo, hi;
+    shard_range(R.cfg->n_frames, b->world, s.rank, &lo, &hi);
+    const int n = hi - lo;
+    ms[0] = ms[1] = ms[2] = 0.0;
+    if (!n) return CVS_OK;
+#define H_TRY(expr)                                                                              \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e__); return e__ == hipErrorOutOfMemory ? CVS_E_NOMEM : CVS_E_HIP; } \
+    } while (0)
+    H_TRY(hipSetDevice(s.device));
+    if (!s.up) {
+        H_TRY(hipStreamCreateWithFlags(&s.up, hipStreamNonBlocking));
+        H_TRY(hipStreamCreateWithFlags(&s.down, hipStreamNonBlocking));
+    }
+    int persist = 1;
+    (void)cvs_get_option(s.h, CVS_OPT_PERSIST_STATE, &persist);
+    // with state kept, the handle's frames after the call must be the whole shard: one chunk
+    const int nchunks = persist ? 1 : std::min(n, 4);
+    std::vector<int> c0(nchunks + 1);
+    for (int c = 0; c <= nchunks; ++c) c0[c] = (int)((long long)n * c / nchunks);
+    std::vector<hipEvent_t> up_ev(nchunks), done_ev(nchunks);
+    hipEvent_t t[4];
+    for (hipEvent_t& e : t) H_TRY(hipEventCreate(&e));
+    for (int c = 0; c < nchunks; ++c) {
+        H_TRY(hipEventCreateWithFlags(&up_ev[c], hipEventDisableTiming));
+        H_TRY(hipEventCreateWithFlags(&done_ev[c], hipEventDisableTiming));
+    }
+    // the download thread: chunk c may start once its launch has been queued (counter) and has finished (event)
+    std::mutex mu;
+    std::condition_variable cv;
+    int queued = 0;
+    bool stop = false;
+    int drc = CVS_OK;
+    std::string derr;
+    std::thread down;
+    if (R.cfg->gather) {
+        down = std::thread([&]() {
+            if (hipSetDevice(s.device) != hipSuccess) { drc = CVS_E_HIP; derr = "hipSetDevice"; return; }
+            for (int c = 0; c < nchunks; ++c) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return queued > c || stop; });
+                    if (stop) return;
+                }
+                hipError_t e = hipStreamWaitEvent(s.down, done_ev[c], 0);
+                if (c == 0 && e == hipSuccess) e = hipEventRecord(t[2], s.down);
+                for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i)
+                    for (int j = 0; e == hipSuccess && j < K; ++j) {
+                        const cvs_plane& o = R.outputs[(size_t)(lo + i) * 8 + R.sel[j]];
+                        e = hipMemcpy2DAsync(o.data, o.step, s.out.p + ((size_t)i * K + j) * plane, rowb, rowb, rows, hipMemcpyDeviceToHost, s.down);
+                    }
+                if (e != hipSuccess) { drc = CVS_E_HIP; derr = std::string("download: ") + hipGetErrorString(e); return; }
+            }
+            hipError_t e = hipEventRecord(t[3], s.down);
+            if (e == hipSuccess) e = hipStreamSynchronize(s.down);
+            if (e != hipSuccess) { drc = CVS_E_HIP; derr = std::string("download: ") + hipGetErrorString(e); }
+        });
+    }
+    auto stop_down = [&](bool failed) {
+        if (down.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (failed) stop = true;
+            }
+            cv.notify_all();
+            down.join();
+        }
+    };
+    int rc = CVS_OK;
+    hipError_t e = hipEventRecord(t[0], s.up);
+    for (int c = 0; c < nchunks && e == hipSuccess && rc == CVS_OK; ++c) {
+        for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i) {
+            const cvs_plane& im = R.inputs[lo + i];
+            e = hipMemcpy2DAsync(s.in.p + (size_t)i * plane, rowb, im.data, im.step, rowb, rows, hipMemcpyHostToDevice, s.up);
+        }
+        if (e == hipSuccess) e = hipEventRecord(up_ev[c], s.up);
+        if (e == hipSuccess && c == nchunks - 1) e = hipEventRecord(t[1], s.up);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s.stream, up_ev[c], 0);
+        if (e != hipSuccess) break;
+        const int cn = c0[c + 1] - c0[c];
+        std::vector<cvs_plane> im(cn), ou((size_t)cn * 8);
+        std::memset(ou.data(), 0, ou.size() * sizeof(cvs_plane));
+        for (int i = 0; i < cn; ++i) {
+            im[i] = cvs_plane{s.in.p + (size_t)(c0[c] + i) * plane, rows, cols, rowb, CVS_MEM_DEVICE};
+            for (int j = 0; j < K; ++j)
+                ou[(size_t)i * 8 + R.sel[j]] = cvs_plane{s.out.p + ((size_t)(c0[c] + i) * K + j) * plane, rows, cols, rowb, CVS_MEM_DEVICE};
+        }
+        rc = cvs_pipeline_batch(s.h, im.data(), cn, ou.data());
+        if (rc != CVS_OK) { err = std::string("cvs_pipeline_batch: ") + cvs_last_error(s.h); break; }
+        e = hipEventRecord(done_ev[c], s.stream);
+        if (e == hipSuccess) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                queued = c + 1;
+            }
+            cv.notify_all();
+        }
+    }
+    const bool failed = e != hipSuccess || rc != CVS_OK;
+    if (e != hipSuccess) { err = std::string("upload: ") + hipGetErrorString(e); rc = CVS_E_HIP; }
+    stop_down(failed);
+    if (!failed && drc != CVS_OK) { rc = drc; err = derr; }
+    if (rc == CVS_OK) {
+        e = hipStreamSynchronize(s.stream);
+        if (e != hipSuccess) { err = hipGetErrorString(e); rc = CVS_E_HIP; }
+    }
+    if (rc == CVS_OK) {
+        float a = 0.f, g = 0.f, w = 0.f;
+        (void)hipEventElapsedTime(&a, t[0], t[1]);
+        ms[0] = a;
+        if (R.cfg->gather) {
+            (void)hipEventElapsedTime(&g, t[2], t[3]);
+            (void)hipEventElapsedTime(&w, t[0], t[3]);
+            ms[2] = g;
+            ms[1] = w;  // host planes: the middle figure is the rank's whole span, upload start to download end
+        }
+    } else {
+        (void)hipDeviceSynchronize();
+    }
+    for (hipEvent_t& ev : t) (void)hipEventDestroy(ev);
+    for (int c = 0; c < nchunks; ++c) { (void)hipEventDestroy(up_ev[c]); (void)hipEventDestroy(done_ev[c]); }
+    s.last_n = n;
+    s.last_k = K;
+    s.last_rows = rows;
+    s.last_cols = cols;
+    s.last_staged = true;
+#undef H_TRY
+    return rc;
+}
+
+int run_host(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, const cvs_plane* outputs, const int* sel, int K,
+             cvs_batch_timing* timing)
+{
+    const int rows = cfg->rows, cols = cfg->cols, F = cfg->n_frames;
+    if ((int)b->slots.size() != b->world)
+        return fail(b, CVS_E_UNSUPPORTED, "host planes need every rank in the calling process (each GPU pulls its frames over its own link)");
+    for (int f = 0; f < F; ++f) {
+        if (!host_plane(&inputs[f], rows, cols)) return fail(b, CVS_E_SIZE, "input frames must be all host or all dense device f32 planes of rows x cols");
+        for (int j = 0; cfg->gather && j < K; ++j)
+            if (!host_plane(&outputs[(size_t)f * 8 + sel[j]], rows, cols))
+                return fail(b, CVS_E_SIZE, "with host input frames the requested output planes must be host f32 planes of rows x cols");
+    }
+    const size_t plane = (size_t)rows * cols;
+    int rc;
+    for (Slot& s : b->slots) {
+        int lo, hi;
+        shard_range(F, b->world, s.rank, &lo, &hi);
+        const size_t n = (size_t)(hi - lo);
+        if (n && (rc = reserve(b, s, s.in, n * plane))) return rc;
+        if (n && (rc = reserve(b, s, s.out, n * K * plane))) return rc;
+    }
+    HostRun R{b, cfg, inputs, outputs, {0}, K};
+    for (int j = 0; j < K; ++j) R.sel[j] = sel[j];
+    const size_t nl = b->slots.size();
+    std::vector<int> rcs(nl, CVS_OK);
+    std::vector<std::string> errs(nl);
+    std::vector<double> ms(nl * 3, 0.0);
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nl; ++i) th.emplace_back([&, i]() { rcs[i] = host_rank(R, b->slots[i], errs[i], &ms[i * 3]); });
+    rcs[0] = host_rank(R, b->slots[0], errs[0], &ms[0]);
+    for (std::thread& t : th) t.join();
+    for (size_t i = 0; i < nl; ++i)
+        if (rcs[i] != CVS_OK) return fail(b, rcs[i], "rank " + std::to_string(b->slots[i].rank) + ": " + errs[i]);
+    if (timing) {
+        timing->scatter_ms = timing->compute_ms = timing->gather_ms = 0.0;
+        for (size_t i = 0; i < nl; ++i) {
+            timing->scatter_ms = std::max(timing->scatter_ms, ms[i * 3]);
+            timing->compute_ms = std::max(timing->compute_ms, ms[i * 3 + 1]);
+            timing->gather_ms = std::max(timing->gather_ms, ms[i * 3 + 2]);
+        }
+    }
+    return CVS_OK;
+}
+
 int create_common(int kind, int width, float spacing, cvs_batch* out, cvs_batch* made)
 {
     if (!out) return CVS_E_BADARG;
@@ -395,6 +597,8 @@ int cvs_batch_destroy(cvs_batch b)
         for (hipEvent_t e : s.ev)
             if (e) (void)hipEventDestroy(e);
         if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.up) (void)hipStreamDestroy(s.up);
+        if (s.down) (void)hipStreamDestroy(s.down);
     }
     delete b;
     return CVS_OK;
@@ -435,6 +639,7 @@ int cvs_batch_run(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs
     if (rs) {
         if (!inputs) return fail(b, CVS_E_BADARG, "the root rank needs the input frames");
         if (cfg->gather && !outputs) return fail(b, CVS_E_BADARG, "the root rank needs output planes to gather into");
+        if (inputs[0].mem == CVS_MEM_HOST) return run_host(b, cfg, inputs, outputs, sel, K, timing);
         for (int f = 0; f < F; ++f) {
             if (!dense_device(&inputs[f], rows, cols)) return fail(b, CVS_E_SIZE, "input frames must be dense f32 device planes of rows x cols");
             for (int j = 0; cfg->gather && j < K; ++j)

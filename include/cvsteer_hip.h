@@ -272,7 +272,12 @@ int cvs_batch_set_option(cvs_batch b, int option, int value);
 /* BASELINE config 4 -- the loop of example/steer.cpp:169 over the node: inputs = n_frames dense f32 device planes on the
  * root, outputs = n_frames * 8 planes on the root, frame-major, order of cvs_pipeline (entries not selected by
  * cfg->outputs are ignored).  scatter (grouped ncclSend/ncclRecv) -> one cvs_pipeline_batch launch per rank ->
- * gather (grouped ncclSend/ncclRecv).  The root's own block is processed in place. */
+ * gather (grouped ncclSend/ncclRecv).  The root's own block is processed in place.
+ * HOST planes (what the example holds: cv::Mat, steer.cpp:73-104; rows may be padded): inputs and requested outputs all
+ * CVS_MEM_HOST.  Nothing passes through the root's GPU then -- every rank uploads ITS frames from the caller's planes over
+ * its own host link and downloads its outputs the same way, all ranks at once, upload / launch / download overlapped
+ * chunk by chunk inside a rank.  Needs every rank in the calling process (cvs_batch_create_local, or a world of 1);
+ * CVS_E_UNSUPPORTED otherwise.  timing: scatter = upload, gather = download, compute = the slowest rank's whole span. */
 int cvs_batch_run(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, const cvs_plane* outputs, cvs_batch_timing* timing);
 /* after a run with gather = 0 (or on a non-root rank): this rank's block, [n_frames][n_planes][rows][cols] dense */
 int cvs_batch_local_result(cvs_batch b, int rank, float** data, int* n_frames, int* n_planes, int* rows, int* cols);

@@ -90,6 +90,53 @@ def test_rehearsal_world_sharded_equals_unsharded(cv, world, n_frames):
     nb.close()
 
 
+@pytest.mark.parametrize("world,n_frames,persist", [(1, 6, False), (1, 3, True), (3, 11, False), (4, 2, False), (2, 9, True)])
+def test_host_planes_every_rank_pulls_its_own_frames(cv, world, n_frames, persist):
+    """cvs_batch_run with HOST planes (example/steer.cpp:73-104 holds cv::Mat): ranks upload their frames themselves,
+    chunked and overlapped with the launches and the downloads; padded host rows; results bit-identical"""
+    import torch
+    from cvsteer_amd import batch
+    rows, cols = 90, 333
+    frames = _frames(n_frames, rows, cols, 17)
+    want = _reference(cv, frames, (0, 4, 5, 6, 7)).cpu().numpy()
+    padded = np.full((n_frames, rows, cols + 13), np.nan, np.float32)   # host rows with padding behind them
+    padded[:, :, :cols] = frames.cpu().numpy()
+    host = padded[:, :, :cols]
+    nb = batch.NativeBatch.local((0,) * world)
+    nb.set_persist(persist)
+    got, t = nb.run(host, n_frames, (rows, cols), outputs=(0, 4, 5, 6, 7))
+    assert isinstance(got, np.ndarray) and np.array_equal(got, want)
+    assert t["scatter"] > 0 and t["gather"] > 0 and t["compute"] >= t["gather"]
+    # again into a caller-owned array, other selection
+    out = np.zeros((n_frames, 2, rows, cols), np.float32)
+    got2, _ = nb.run(host, n_frames, (rows, cols), outputs=(5, 7), out=out)
+    assert got2 is out and np.array_equal(out[:, 0], want[:, 2]) and np.array_equal(out[:, 1], want[:, 4])
+    # host in, device out is not a defined mix
+    dev_out = torch.empty((n_frames, 3, rows, cols), device="cuda")
+    with pytest.raises(AssertionError):
+        nb.run(host, n_frames, (rows, cols), out=dev_out)
+    nb.close()
+
+
+def test_host_planes_mixed_with_device_planes_rejected(cv):
+    import ctypes as C
+    from cvsteer_amd import _lib as L
+    lib = L.lib()
+    h = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert lib.cvs_batch_create_local(L.KIND_G2, 4, C.c_float(0.67), 1, devs, C.byref(h)) == 0
+    import torch
+    img = np.random.default_rng(0).random((40, 64), dtype=np.float32)
+    dev = torch.zeros((40, 64), device="cuda")
+    ins = (L.Plane * 1)(L.Plane(img.ctypes.data, 40, 64, 64 * 4, L.MEM_HOST))
+    outs = (L.Plane * 8)()
+    outs[5] = L.Plane(dev.data_ptr(), 40, 64, 64 * 4, L.MEM_DEVICE)
+    cfg = L.BatchCfg(40, 64, 1, 1 << 5, 0, 1, 0)
+    rc = lib.cvs_batch_run(h, C.byref(cfg), ins, outs, None)
+    assert rc == L.E_SIZE and b"host" in lib.cvs_batch_last_error(h)
+    lib.cvs_batch_destroy(h)
+
+
 def test_batch_argument_errors(cv):
     import torch
     from cvsteer_amd import batch
