@@ -312,7 +312,11 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
     shard_range(R.cfg->n_frames, b->world, s.rank, &lo, &hi);
     const int n = hi - lo;
     ms[0] = ms[1] = ms[2] = 0.0;
-    if (!n) return CVS_OK;
+    if (!n) {
+        s.last_n = 0;
+        s.last_staged = true;
+        return CVS_OK;
+    }
 #define H_TRY(expr)                                                                              \
     do {                                                                                         \
         hipError_t e__ = (expr);                                                                 \
@@ -680,7 +684,11 @@ int cvs_batch_run(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs
         int lo, hi;
         shard_range(F, b->world, s.rank, &lo, &hi);
         const int n = hi - lo;
-        if (!n) continue;
+        if (!n) {
+            s.last_n = 0;  // cvs_batch_local_result: an empty block, not the previous run's
+            s.last_staged = true;
+            continue;
+        }
         const bool in_place = s.rank == root && !via;
         const bool out_in_place = s.rank == root && cfg->gather && !via;
         std::vector<cvs_plane> im(n), ou((size_t)n * 8);

@@ -1,0 +1,286 @@
+// cvsteer_run.cpp -- `cvsteer-run` for MI355X: the reference's batch driver (example/steer.cpp:59-173) in C++ over
+// the C ABI (include/cvsteer_hip.h).  Host side only: no HIP call is made here.
+//
+//   cvsteer-run --input <image | list.txt> --output <dir> [--gain G] [--gpus N | --devices a,b,..] [--ext .pgm|.npy] [--verbose]
+//
+// Per image the reference's per-file body (steer.cpp:69-124): gray f32 (unscaled 0..255) -> SteerableFiltersG2(gray, 4,
+// 0.67) -> steer at the dominant orientation -> findEdges / findDarkLines / findBrightLines on the magnitude -> 8-bit
+// via normalize(0, 255, MINMAX) or convertTo(gain) -> <base>_edges, <base>_lines_dark, <base>_lines_bright.
+// Where the reference runs cv::parallel_for_ over the files (steer.cpp:169), this driver hands runs of equally sized
+// images to cvs_batch_run as HOST planes: every GPU uploads its own block of frames over its own link, filters it in
+// one fused launch, keeps the three feature maps on the device, and only their 8-bit versions (cvs_normalize_u8 /
+// cvs_convert_u8, on the GPU) come back -- 1 byte per pixel and map instead of 4.
+// OpenCV's imgcodecs are not available: inputs are binary PGM (P5, maxval <= 255) or .npy (2-D, |u1 or <f4, C order),
+// outputs PGM or .npy.  Differences from the reference, on purpose: --gain is honoured (steer.cpp:167-168 passes
+// `verbose` as the gain); single-channel inputs work (steer.cpp:79-82 leaves `gray` empty for them); unreadable files
+// are reported and make the exit status non-zero.
+#include <cvsteer_hip.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Image {
+    std::string path;
+    int rows = 0, cols = 0;
+    std::vector<float> pix;  // gray, unscaled (Mat1f(gray), steer.cpp:84)
+};
+
+std::string base_name(const std::string& path)
+{
+    const size_t slash = path.find_last_of('/');
+    std::string name = slash == std::string::npos ? path : path.substr(slash + 1);
+    const size_t dot = name.find_last_of('.');
+    return dot == std::string::npos ? name : name.substr(0, dot);
+}
+
+std::string lower_ext(const std::string& path)
+{
+    const size_t dot = path.find_last_of('.');
+    std::string e = dot == std::string::npos ? "" : path.substr(dot);
+    for (char& c : e) c = (char)std::tolower((unsigned char)c);
+    return e;
+}
+
+std::string slurp(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error(path + ": cannot open");
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+// binary PGM: "P5" ws width ws height ws maxval single-ws raster ('#' comments allowed in the header)
+Image read_pgm(const std::string& path)
+{
+    const std::string d = slurp(path);
+    size_t pos = 0;
+    auto token = [&]() {
+        for (;;) {
+            while (pos < d.size() && std::isspace((unsigned char)d[pos])) ++pos;
+            if (pos < d.size() && d[pos] == '#') {
+                while (pos < d.size() && d[pos] != '\n') ++pos;
+                continue;
+            }
+            break;
+        }
+        const size_t b = pos;
+        while (pos < d.size() && !std::isspace((unsigned char)d[pos])) ++pos;
+        return d.substr(b, pos - b);
+    };
+    if (token() != "P5") throw std::runtime_error(path + ": not a binary PGM (P5)");
+    Image im;
+    im.path = path;
+    im.cols = std::atoi(token().c_str());
+    im.rows = std::atoi(token().c_str());
+    const int maxval = std::atoi(token().c_str());
+    ++pos;  // the single whitespace byte after maxval
+    if (im.rows <= 0 || im.cols <= 0 || maxval <= 0 || maxval > 255) throw std::runtime_error(path + ": unsupported PGM header");
+    const size_t n = (size_t)im.rows * im.cols;
+    if (d.size() < pos + n) throw std::runtime_error(path + ": truncated raster");
+    im.pix.resize(n);
+    for (size_t i = 0; i < n; ++i) im.pix[i] = (float)(unsigned char)d[pos + i];
+    return im;
+}
+
+// NumPy .npy version 1.x / 2.x, 2-D, '|u1' or '<f4', fortran_order False
+Image read_npy(const std::string& path)
+{
+    const std::string d = slurp(path);
+    if (d.size() < 12 || std::memcmp(d.data(), "\x93NUMPY", 6) != 0) throw std::runtime_error(path + ": not an .npy file");
+    const int major = (unsigned char)d[6];
+    size_t hlen, off;
+    if (major == 1) { hlen = (unsigned char)d[8] | ((size_t)(unsigned char)d[9] << 8); off = 10; }
+    else { hlen = (unsigned char)d[8] | ((size_t)(unsigned char)d[9] << 8) | ((size_t)(unsigned char)d[10] << 16) | ((size_t)(unsigned char)d[11] << 24); off = 12; }
+    if (d.size() < off + hlen) throw std::runtime_error(path + ": truncated header");
+    const std::string h = d.substr(off, hlen);
+    const bool u1 = h.find("'|u1'") != std::string::npos, f4 = h.find("'<f4'") != std::string::npos;
+    if (!u1 && !f4) throw std::runtime_error(path + ": dtype must be uint8 or little-endian float32");
+    if (h.find("'fortran_order': False") == std::string::npos) throw std::runtime_error(path + ": fortran order is not supported");
+    const size_t sp = h.find("'shape': (");
+    if (sp == std::string::npos) throw std::runtime_error(path + ": no shape");
+    int r = 0, c = 0;
+    if (std::sscanf(h.c_str() + sp + 10, "%d, %d", &r, &c) != 2 || r <= 0 || c <= 0) throw std::runtime_error(path + ": expected a 2-D array");
+    Image im;
+    im.path = path;
+    im.rows = r;
+    im.cols = c;
+    const size_t n = (size_t)r * c, data = off + hlen;
+    if (d.size() < data + n * (u1 ? 1 : 4)) throw std::runtime_error(path + ": truncated data");
+    im.pix.resize(n);
+    if (u1) for (size_t i = 0; i < n; ++i) im.pix[i] = (float)(unsigned char)d[data + i];
+    else std::memcpy(im.pix.data(), d.data() + data, n * 4);
+    return im;
+}
+
+Image read_gray(const std::string& path)
+{
+    const std::string e = lower_ext(path);
+    if (e == ".npy") return read_npy(path);
+    if (e == ".pgm") return read_pgm(path);
+    throw std::runtime_error(path + ": unsupported format (binary PGM or .npy; no imgcodecs in this build)");
+}
+
+void write_u8(const std::string& path, const std::vector<uint8_t>& u8, int rows, int cols)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error(path + ": cannot create");
+    if (lower_ext(path) == ".npy") {
+        std::string dict = "{'descr': '|u1', 'fortran_order': False, 'shape': (" + std::to_string(rows) + ", " + std::to_string(cols) + "), }";
+        while ((10 + dict.size() + 1) % 64) dict += ' ';
+        dict += '\n';
+        const char head[10] = {'\x93', 'N', 'U', 'M', 'P', 'Y', 1, 0, (char)(dict.size() & 0xff), (char)(dict.size() >> 8)};
+        f.write(head, 10);
+        f.write(dict.data(), (std::streamsize)dict.size());
+    } else {
+        const std::string head = "P5\n" + std::to_string(cols) + " " + std::to_string(rows) + "\n255\n";
+        f.write(head.data(), (std::streamsize)head.size());
+    }
+    f.write(reinterpret_cast<const char*>(u8.data()), (std::streamsize)u8.size());
+    if (!f) throw std::runtime_error(path + ": write failed");
+}
+
+// steer.cpp:156-165: a .txt file (or a name without extension) is a list of files, else one image
+std::vector<std::string> input_list(const std::string& arg)
+{
+    const std::string name = arg.substr(arg.find_last_of('/') == std::string::npos ? 0 : arg.find_last_of('/') + 1);
+    if (lower_ext(arg) != ".txt" && name.find('.') != std::string::npos) return {arg};
+    std::ifstream f(arg);
+    if (!f) throw std::runtime_error(arg + ": cannot open the file list");
+    std::vector<std::string> out;
+    std::string ln;
+    while (std::getline(f, ln)) {
+        while (!ln.empty() && std::isspace((unsigned char)ln.back())) ln.pop_back();
+        size_t b = 0;
+        while (b < ln.size() && std::isspace((unsigned char)ln[b])) ++b;
+        if (b < ln.size()) out.push_back(ln.substr(b));
+    }
+    return out;
+}
+
+void check(int rc, const char* what, const char* detail)
+{
+    if (rc != CVS_OK) throw std::runtime_error(std::string(what) + ": " + cvs_status_string(rc) + (detail && *detail ? std::string(" -- ") + detail : ""));
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::string input, output, ext = ".pgm";
+    float gain = 0.f;
+    int gpus = 1, max_batch = 64;
+    std::vector<int> device_list;
+    bool verbose = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", a.c_str()); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "--input" || a == "-i") input = val();
+        else if (a == "--output" || a == "-o") output = val();
+        else if (a == "--gain" || a == "-g") gain = (float)std::atof(val().c_str());
+        else if (a == "--gpus") gpus = std::atoi(val().c_str());
+        else if (a == "--devices") {  // explicit list, e.g. 0,1,2,3; a device listed twice = rehearsal of a larger world on a smaller box
+            device_list.clear();
+            std::stringstream ss(val());
+            std::string tok;
+            while (std::getline(ss, tok, ',')) device_list.push_back(std::atoi(tok.c_str()));
+            gpus = (int)device_list.size();
+        }
+        else if (a == "--ext") ext = val();
+        else if (a == "--max-batch") max_batch = std::max(1, std::atoi(val().c_str()));
+        else if (a == "--verbose" || a == "-v") verbose = true;
+        else if (a == "--help" || a == "-h") {
+            std::printf("usage: cvsteer-run --input <image | list.txt> --output <dir> [--gain G] [--gpus N | --devices a,b,..] [--ext .pgm|.npy] [--verbose]\n");
+            return 0;
+        } else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (input.empty() || output.empty() || gpus < 1) { std::fprintf(stderr, "cvsteer-run: --input and --output are required\n"); return 2; }
+    int failures = 0;
+    cvs_batch batch = nullptr;
+    std::vector<cvs_handle> conv;  // one plain handle per device for the 8-bit conversion
+    try {
+        const std::vector<std::string> files = input_list(input);
+        std::vector<int> devices(gpus);
+        for (int d = 0; d < gpus; ++d) devices[d] = device_list.empty() ? d : device_list[d];
+        check(cvs_batch_create_local(CVS_KIND_G2, 4, 0.67f, gpus, devices.data(), &batch), "cvs_batch_create_local", cvs_batch_last_error(batch));
+        check(cvs_batch_set_option(batch, CVS_OPT_PERSIST_STATE, 0), "cvs_batch_set_option", cvs_batch_last_error(batch));  // only the three maps are kept
+        conv.resize(gpus, nullptr);
+        for (int d = 0; d < gpus; ++d) check(cvs_create(CVS_KIND_G2, 4, 0.67f, devices[d], &conv[d]), "cvs_create", "");
+
+        size_t next = 0;
+        while (next < files.size()) {
+            // a run of consecutive images of one size = one batch (frames of a batch share their geometry)
+            std::vector<Image> run;
+            while (next < files.size() && (int)run.size() < max_batch) {
+                Image im;
+                try {
+                    im = read_gray(files[next]);
+                } catch (const std::exception& e) {
+                    std::fprintf(stderr, "cvsteer-run: %s\n", e.what());
+                    ++failures;
+                    ++next;
+                    continue;
+                }
+                if (!run.empty() && (im.rows != run[0].rows || im.cols != run[0].cols)) break;  // starts the next run
+                run.push_back(std::move(im));
+                ++next;
+            }
+            if (run.empty()) continue;
+            const int rows = run[0].rows, cols = run[0].cols, n = (int)run.size();
+            std::vector<cvs_plane> in(n);
+            for (int f = 0; f < n; ++f) in[f] = cvs_plane{run[f].pix.data(), rows, cols, (size_t)cols * sizeof(float), CVS_MEM_HOST};
+            cvs_batch_cfg cfg;
+            std::memset(&cfg, 0, sizeof cfg);
+            cfg.rows = rows;
+            cfg.cols = cols;
+            cfg.n_frames = n;
+            cfg.outputs = (1u << 5) | (1u << 6) | (1u << 7);  // edges, dark lines, bright lines
+            cfg.root = 0;
+            cfg.gather = 0;  // the maps stay on the GPUs: only their 8-bit versions are downloaded
+            cvs_batch_timing t;
+            check(cvs_batch_run(batch, &cfg, in.data(), nullptr, &t), "cvs_batch_run", cvs_batch_last_error(batch));
+            if (verbose) std::printf("batch of %d x %dx%d: upload %.2f ms, span %.2f ms\n", n, rows, cols, t.scatter_ms, t.compute_ms);
+            static const char* suffix[3] = {"_edges", "_lines_dark", "_lines_bright"};
+            std::vector<uint8_t> u8((size_t)rows * cols);
+            int frame = 0;
+            for (int r = 0; r < gpus; ++r) {
+                float* block = nullptr;
+                int nf = 0, np = 0, br = 0, bc = 0;
+                check(cvs_batch_local_result(batch, r, &block, &nf, &np, &br, &bc), "cvs_batch_local_result", cvs_batch_last_error(batch));
+                for (int i = 0; i < nf; ++i, ++frame) {
+                    for (int j = 0; j < 3; ++j) {
+                        cvs_plane map{block + ((size_t)i * np + j) * rows * cols, rows, cols, (size_t)cols * sizeof(float), CVS_MEM_DEVICE};
+                        if (gain > 0.f) check(cvs_convert_u8(conv[r], &map, gain, 0.f, u8.data(), (size_t)cols, CVS_MEM_HOST), "cvs_convert_u8", cvs_last_error(conv[r]));
+                        else check(cvs_normalize_u8(conv[r], &map, u8.data(), (size_t)cols, CVS_MEM_HOST), "cvs_normalize_u8", cvs_last_error(conv[r]));
+                        check(cvs_sync(conv[r]), "cvs_sync", cvs_last_error(conv[r]));
+                        const std::string dst = output + "/" + base_name(run[frame].path) + suffix[j] + ext;
+                        write_u8(dst, u8, rows, cols);
+                        if (verbose) std::printf("%s\n", dst.c_str());
+                    }
+                }
+            }
+            if (frame != n) throw std::runtime_error("internal: the ranks returned " + std::to_string(frame) + " frames of " + std::to_string(n));
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "cvsteer-run: %s\n", e.what());
+        failures = failures ? failures : 1;
+    }
+    for (cvs_handle h : conv)
+        if (h) cvs_destroy(h);
+    if (batch) cvs_batch_destroy(batch);
+    return failures ? 1 : 0;
+}
