@@ -512,8 +512,23 @@ def main():
                                                "end_to_end_Mpix/s": round(ws * nfr * 1080 * 1920 / best / 1e6, 1),
                                                "link_floor_ms": round(nfr * 1080 * 1920 * 4 * 3 / 56e9 * 1e3, 2),
                                                "note": "host f32 frames in, 3 host f32 maps out per frame; every rank moves its own shard over its own link; floor = the download at 56 GB/s"}
+                # ... and the example's real flow: 8-bit images in, three 8-bit maps per image out (steer.cpp:73-122).  Bytes up,
+                # maps kept on the GPU, normalize(0, 255, MINMAX) there (one launch pair per block), bytes down.
+                host_u8 = (fsets[0] * 255.0).to(torch.uint8).cpu().numpy()
+                bbest = None
+                q8 = _np.zeros((nfr, 3) + shape, _np.uint8)
+                for rep in range(4):
+                    t0 = time.perf_counter()
+                    hb.run_to_u8(host_u8, out=q8)
+                    dt = time.perf_counter() - t0
+                    if rep and (bbest is None or dt < bbest):
+                        bbest = dt
+                (bbest,) = max_over_ranks(bbest)
+                extra["C4_e2e_bytes"] = {"frames_per_gpu": nfr, "ms_wall": round(bbest * 1e3, 2), "end_to_end_Mpix/s": round(ws * nfr * 1080 * 1920 / bbest / 1e6, 1),
+                                         "link_floor_ms": round(nfr * 1080 * 1920 * 3 / 56e9 * 1e3, 2),
+                                         "note": "8-bit frames in, 3 normalised 8-bit maps per frame out (example/steer.cpp flow); floor = the download at 56 GB/s"}
                 hb.close()
-                del host_in, host_out
+                del host_in, host_out, host_u8, q8
             except Exception as ex:
                 extra["C4_e2e_host_planes"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         del fsets, ff, all_frames

@@ -131,8 +131,10 @@ class NativeBatch:
                                              (already initialised) carries the 128 bytes to the other ranks
     """
 
-    def __init__(self, handle, world, rank, device):
+    def __init__(self, handle, world, rank, device, devices=None):
         self._b, self.world, self.rank, self.device = handle, world, rank, device
+        self.devices = list(devices) if devices is not None else [device]   # local ranks' devices, rank order
+        self._conv = {}
 
     # -- construction --
     @classmethod
@@ -140,7 +142,9 @@ class NativeBatch:
         devs = (_C.c_int * len(devices))(*[int(d) for d in devices])
         h = _C.c_void_p()
         rc = _L.lib().cvs_batch_create_local(kind, width, spacing, len(devices), devs, _C.byref(h))
-        return cls._made(rc, h, len(devices), 0, int(devices[0]), "cvs_batch_create_local")
+        nb = cls._made(rc, h, len(devices), 0, int(devices[0]), "cvs_batch_create_local")
+        nb.devices = [int(d) for d in devices]
+        return nb
 
     @classmethod
     def from_torch_distributed(cls, device, kind=_L.KIND_G2, width=4, spacing=0.67, group=None):
@@ -203,10 +207,12 @@ class NativeBatch:
         is_root = frames is not None
         if is_root and isinstance(frames, _np.ndarray):
             from .api import _PLANE_DTYPE
-            assert frames.dtype == _np.float32 and frames.shape == (n_frames, rows, cols) and frames.strides[2] == 4 and frames.strides[1] >= cols * 4
+            item = frames.dtype.itemsize
+            assert frames.dtype in (_np.float32, _np.uint8) and frames.shape == (n_frames, rows, cols) and frames.strides[2] == item and frames.strides[1] >= cols * item
             imgs = _np.zeros(n_frames, _PLANE_DTYPE)
             imgs["data"] = frames.ctypes.data + _np.arange(n_frames, dtype=_np.uint64) * _np.uint64(frames.strides[0])
-            imgs["rows"], imgs["cols"], imgs["step"], imgs["mem"] = rows, cols, frames.strides[1], _L.MEM_HOST
+            imgs["rows"], imgs["cols"], imgs["step"] = rows, cols, frames.strides[1]
+            imgs["mem"] = _L.MEM_HOST | (_L.DEPTH_U8 if frames.dtype == _np.uint8 else 0)   # 8-bit frames cross the link as bytes
             if gather:
                 if out is None:
                     out = _np.empty((n_frames, len(sel), rows, cols), _np.float32)
@@ -237,6 +243,45 @@ class NativeBatch:
                                     outs.ctypes.data_as(_L._PP) if outs is not None else None, _C.byref(t))
         self._check(rc, "cvs_batch_run")
         return (out if (is_root and gather) else None), {"scatter": t.scatter_ms, "compute": t.compute_ms, "gather": t.gather_ms}
+
+    def run_to_u8(self, frames, outputs=(5, 6, 7), gain=0.0, out=None):
+        """The flow of example/steer.cpp:69-122 for one batch of equally sized HOST images (numpy [n, H, W], uint8 or
+        float32), every rank local to this process: host planes -> cvs_batch_run with the maps kept on the GPUs ->
+        normalize(0, 255, MINMAX) or convertTo(gain) on each GPU (cvs_*_u8_batch: one launch pair and one sync per rank)
+        -> numpy uint8 [n, len(outputs), H, W].  Only bytes cross the host link on the way back."""
+        n, rows, cols = (int(v) for v in frames.shape)
+        sel = [int(k) for k in outputs]
+        _, t = self.run(frames, n, (rows, cols), outputs=sel, gather=False)
+        if out is None:
+            out = _np.empty((n, len(sel), rows, cols), _np.uint8)
+        assert isinstance(out, _np.ndarray) and out.dtype == _np.uint8 and out.flags.c_contiguous and out.shape == (n, len(sel), rows, cols)
+        lib = _L.lib()
+        f0 = 0
+        for r, dev in enumerate(self.devices):
+            data, nf, npl, rr, cc = _L._FP(), _C.c_int(), _C.c_int(), _C.c_int(), _C.c_int()
+            self._check(lib.cvs_batch_local_result(self._b, r, _C.byref(data), _C.byref(nf), _C.byref(npl), _C.byref(rr), _C.byref(cc)), "cvs_batch_local_result")
+            m = nf.value * npl.value
+            if not m:
+                continue
+            base = _C.cast(data, _C.c_void_p).value
+            if r not in self._conv:
+                from .api import SteerableFiltersG2
+                self._conv[r] = SteerableFiltersG2(None, 4, 0.67, device=dev)
+            h = self._conv[r]._h
+            planes = (_L.Plane * m)()
+            dst = (_C.c_void_p * m)()
+            for i in range(m):
+                planes[i] = _L.Plane(base + i * rows * cols * 4, rows, cols, cols * 4, _L.MEM_DEVICE)
+                dst[i] = out.ctypes.data + (f0 * len(sel) + i) * rows * cols
+            if gain > 0:
+                rc = lib.cvs_convert_u8_batch(h, planes, m, float(gain), 0.0, dst, cols, _L.MEM_HOST)
+            else:
+                rc = lib.cvs_normalize_u8_batch(h, planes, m, dst, cols, _L.MEM_HOST)
+            if rc:
+                raise _CvsError(rc, "cvs_*_u8_batch", lib.cvs_last_error(h).decode())
+            f0 += nf.value
+        assert f0 == n
+        return out, t
 
     # -- config 3 --
     def pyramid_setup(self, image, rows, cols, levels, flags=1, root=0):

@@ -52,6 +52,8 @@ struct cvs_context {
     float* arena = nullptr;
     size_t arena_elems = 0, arena_used = 0;
     float* minmax = nullptr;
+    float* widen = nullptr;       // f32 copy of a block of 8-bit frames (cvs_pipeline_batch)
+    size_t widen_elems = 0;
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
@@ -930,6 +932,7 @@ int cvs_destroy(cvs_handle h)
     if (h->state) pool_give(h->sb);  // the stream has drained: the block may be reused
     if (h->arena) (void)hipFree(h->arena);
     if (h->minmax) (void)hipFree(h->minmax);
+    if (h->widen) (void)hipFree(h->widen);
     if (h->frame_tab) (void)hipFree(h->frame_tab);
     if (h->point_out) (void)hipFree(h->point_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1299,6 +1302,39 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
             max_bytes = std::max(max_bytes, (size_t)rows * o->step);
         }
     }
+    // 8-bit frames that lie back to back on the device (a driver's upload of a block of byte images): widened by ONE
+    // launch into an f32 block of the handle, which then takes the one-launch path below like any f32 batch
+    std::vector<cvs_plane> widened;
+    {
+        bool u8_block = n >= 1 && images[0].mem == (CVS_MEM_DEVICE | CVS_DEPTH_U8);
+        const uint8_t* b0 = reinterpret_cast<const uint8_t*>(images[0].data);
+        for (int i = 0; i < n && u8_block; ++i)
+            u8_block = images[i].mem == images[0].mem && images[i].step == images[0].step &&
+                       reinterpret_cast<const uint8_t*>(images[i].data) == b0 + (size_t)i * rows * images[0].step;
+        if (u8_block && (size_t)n * rows < ((size_t)1 << 31)) {
+            HIP_TRY(h, hipSetDevice(h->device));
+            const size_t wp = round_up((size_t)cols, 64), elems = wp * rows * n;
+            if (elems > h->widen_elems) {
+                if (h->widen) {
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                    HIP_TRY(h, hipFree(h->widen));
+                    h->widen = nullptr;
+                    h->widen_elems = 0;
+                }
+                HIP_TRY(h, hipMalloc(&h->widen, elems * sizeof(float)));
+                h->widen_elems = elems;
+            }
+            HIP_TRY(h, launch_u8_to_f32(b0, images[0].step, rows * n, cols, h->widen, wp, h->stream));
+            widened.resize(n);
+            for (int i = 0; i < n; ++i) widened[i] = cvs_plane{h->widen + (size_t)i * rows * wp, rows, cols, wp * sizeof(float), CVS_MEM_DEVICE};
+            images = widened.data();
+            all_dev = true;
+            for (int i = 0; i < n && all_dev; ++i)
+                for (int k = 0; outs && k < 8 && all_dev; ++k)
+                    if (outs[(size_t)i * 8 + k].data) all_dev = outs[(size_t)i * 8 + k].mem == CVS_MEM_DEVICE;
+            max_bytes = std::max(max_bytes, (size_t)rows * wp * sizeof(float));
+        }
+    }
     const size_t pitch = round_up((size_t)cols, 64);
     // one launch over grid.z needs every plane below 2 GiB (huge frames are filtered in row bands, frame by frame)
     const bool small_planes = std::max(max_bytes, (size_t)rows * pitch * sizeof(float)) <= (size_t)0x7ffffff0;
@@ -1462,6 +1498,79 @@ static int to_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_st
     HIP_TRY(h, hipMemcpy2DAsync(dst, dst_step, d, dstep, (size_t)src->cols, src->rows, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CVS_OK;
+}
+
+// n planes at once: one min/max launch, one quantise launch, the copies to the host queued behind them and ONE
+// synchronisation -- what a driver wants that turns a rank's whole block of feature maps into files (per plane, the
+// launch + copy + sync of the single-plane call costs more than the work).  Planes that are not equally sized device
+// planes at a constant stride go one by one.
+static int to_u8_batch(cvs_handle h, const cvs_plane* src, int n, uint8_t* const* dst, size_t dst_step, int dst_mem, bool minmax, float alpha, float beta)
+{
+    if (!h || !src || !dst || n < 1) return CVS_E_BADARG;
+    if (dst_mem != CVS_MEM_HOST && dst_mem != CVS_MEM_DEVICE) return fail(h, CVS_E_BADARG, "dst_mem");
+    int rc;
+    bool regular = true;
+    const ptrdiff_t stride = n > 1 ? src[1].data - src[0].data : 0;
+    for (int i = 0; i < n; ++i) {
+        if ((rc = check_plane(h, &src[i], "src"))) return rc;
+        if (!dst[i]) return fail(h, CVS_E_BADARG, "dst");
+        regular = regular && src[i].mem == CVS_MEM_DEVICE && src[i].rows == src[0].rows && src[i].cols == src[0].cols && src[i].step == src[0].step &&
+                  src[i].data - src[0].data == stride * i;
+    }
+    if (dst_step < (size_t)src[0].cols) return fail(h, CVS_E_SIZE, "dst_step");
+    regular = regular && stride >= 0 && (size_t)src[0].rows * src[0].step <= (size_t)0x7ffffff0;
+    if (!regular) {
+        for (int i = 0; i < n; ++i)
+            if ((rc = to_u8(h, &src[i], dst[i], dst_step, dst_mem, minmax, alpha, beta))) return rc;
+        return CVS_OK;
+    }
+    const int rows = src[0].rows, cols = src[0].cols;
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->used = true;
+    // scratch: 2n floats of min / max, and (host destinations) n staged byte planes
+    // host destinations that lie back to back ([n][rows][dst_step], the usual block) are staged in exactly that layout
+    // and come down as ONE linear copy (a pitched 2-D copy of the same bytes runs at a third of the link rate)
+    bool packed = dst_mem == CVS_MEM_HOST && dst_step == (size_t)cols;  // padded rows keep their padding: copied row by row
+    for (int i = 1; i < n && packed; ++i) packed = dst[i] == dst[0] + (size_t)i * rows * dst_step;
+    const size_t dpitch = packed ? dst_step : round_up((size_t)cols, 256), plane_b = dpitch * rows;
+    const size_t mm_elems = round_up((size_t)2 * n, 64);
+    const size_t stage_elems = dst_mem == CVS_MEM_HOST ? round_up(plane_b * n / 4 + 64, 64) : 0;
+    if ((rc = arena_reserve(h, mm_elems + stage_elems))) return rc;
+    h->arena_used = 0;
+    float* mm = arena_take(h, mm_elems);
+    if (dst_mem == CVS_MEM_HOST) {
+        uint8_t* stage = reinterpret_cast<uint8_t*>(arena_take(h, stage_elems));
+        HIP_TRY(h, launch_to_u8_n(src[0].data, (size_t)stride, src[0].step / sizeof(float), rows, cols, n, minmax, mm, alpha, beta, stage, plane_b, dpitch, h->stream));
+        if (packed) {
+            HIP_TRY(h, hipMemcpyAsync(dst[0], stage, plane_b * n, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            for (int i = 0; i < n; ++i)
+                HIP_TRY(h, hipMemcpy2DAsync(dst[i], dst_step, stage + (size_t)i * plane_b, dpitch, (size_t)cols, rows, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return CVS_OK;
+    }
+    // device destinations: regular too?  then straight into them, else plane by plane
+    const ptrdiff_t dstride = n > 1 ? dst[1] - dst[0] : 0;
+    bool dreg = dstride >= 0;
+    for (int i = 0; i < n && dreg; ++i) dreg = dst[i] - dst[0] == dstride * i;
+    if (dreg) {
+        HIP_TRY(h, launch_to_u8_n(src[0].data, (size_t)stride, src[0].step / sizeof(float), rows, cols, n, minmax, mm, alpha, beta, dst[0], (size_t)dstride, dst_step, h->stream));
+        return CVS_OK;
+    }
+    for (int i = 0; i < n; ++i)
+        if ((rc = to_u8(h, &src[i], dst[i], dst_step, dst_mem, minmax, alpha, beta))) return rc;
+    return CVS_OK;
+}
+
+int cvs_normalize_u8_batch(cvs_handle h, const cvs_plane* src, int n, uint8_t* const* dst, size_t dst_step, int dst_mem)
+{
+    return to_u8_batch(h, src, n, dst, dst_step, dst_mem, true, 0.f, 0.f);
+}
+
+int cvs_convert_u8_batch(cvs_handle h, const cvs_plane* src, int n, float alpha, float beta, uint8_t* const* dst, size_t dst_step, int dst_mem)
+{
+    return to_u8_batch(h, src, n, dst, dst_step, dst_mem, false, alpha, beta);
 }
 
 int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem)

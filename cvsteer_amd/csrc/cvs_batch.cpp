@@ -285,9 +285,10 @@ bool dense_device(const cvs_plane* p, int rows, int cols)
 }
 
 // is `p` a rows x cols f32 HOST plane (rows may be padded)?
-bool host_plane(const cvs_plane* p, int rows, int cols)
+bool host_plane(const cvs_plane* p, int rows, int cols, bool u8 = false)
 {
-    return p && p->data && p->mem == CVS_MEM_HOST && p->rows == rows && p->cols == cols && p->step >= (size_t)cols * sizeof(float);
+    return p && p->data && p->mem == (u8 ? (CVS_MEM_HOST | CVS_DEPTH_U8) : CVS_MEM_HOST) && p->rows == rows && p->cols == cols &&
+           p->step >= (size_t)cols * (u8 ? 1 : sizeof(float));
 }
 
 // Host planes (the reference's callers hold cv::Mat: example/steer.cpp:73-104).  Nothing goes through the root's GPU:
@@ -301,6 +302,7 @@ struct HostRun {
     const cvs_batch_cfg* cfg;
     const cvs_plane *inputs, *outputs;
     int sel[8], K;
+    bool u8;  // 8-bit input frames: bytes cross the link, the engine widens them on the device
 };
 
 int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
@@ -386,7 +388,8 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
     for (int c = 0; c < nchunks && e == hipSuccess && rc == CVS_OK; ++c) {
         for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i) {
             const cvs_plane& im = R.inputs[lo + i];
-            e = hipMemcpy2DAsync(s.in.p + (size_t)i * plane, rowb, im.data, im.step, rowb, rows, hipMemcpyHostToDevice, s.up);
+            if (R.u8) e = hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(s.in.p) + (size_t)i * plane, (size_t)cols, im.data, im.step, (size_t)cols, rows, hipMemcpyHostToDevice, s.up);
+            else e = hipMemcpy2DAsync(s.in.p + (size_t)i * plane, rowb, im.data, im.step, rowb, rows, hipMemcpyHostToDevice, s.up);
         }
         if (e == hipSuccess) e = hipEventRecord(up_ev[c], s.up);
         if (e == hipSuccess && c == nchunks - 1) e = hipEventRecord(t[1], s.up);
@@ -396,7 +399,8 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
         std::vector<cvs_plane> im(cn), ou((size_t)cn * 8);
         std::memset(ou.data(), 0, ou.size() * sizeof(cvs_plane));
         for (int i = 0; i < cn; ++i) {
-            im[i] = cvs_plane{s.in.p + (size_t)(c0[c] + i) * plane, rows, cols, rowb, CVS_MEM_DEVICE};
+            if (R.u8) im[i] = cvs_plane{reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(s.in.p) + (size_t)(c0[c] + i) * plane), rows, cols, (size_t)cols, CVS_MEM_DEVICE | CVS_DEPTH_U8};
+            else im[i] = cvs_plane{s.in.p + (size_t)(c0[c] + i) * plane, rows, cols, rowb, CVS_MEM_DEVICE};
             for (int j = 0; j < K; ++j)
                 ou[(size_t)i * 8 + R.sel[j]] = cvs_plane{s.out.p + ((size_t)(c0[c] + i) * K + j) * plane, rows, cols, rowb, CVS_MEM_DEVICE};
         }
@@ -449,8 +453,9 @@ int run_host(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, con
     const int rows = cfg->rows, cols = cfg->cols, F = cfg->n_frames;
     if ((int)b->slots.size() != b->world)
         return fail(b, CVS_E_UNSUPPORTED, "host planes need every rank in the calling process (each GPU pulls its frames over its own link)");
+    const bool u8 = (inputs[0].mem & CVS_DEPTH_U8) != 0;
     for (int f = 0; f < F; ++f) {
-        if (!host_plane(&inputs[f], rows, cols)) return fail(b, CVS_E_SIZE, "input frames must be all host or all dense device f32 planes of rows x cols");
+        if (!host_plane(&inputs[f], rows, cols, u8)) return fail(b, CVS_E_SIZE, "input frames must be all host (all f32 or all 8-bit) or all dense device f32 planes of rows x cols");
         for (int j = 0; cfg->gather && j < K; ++j)
             if (!host_plane(&outputs[(size_t)f * 8 + sel[j]], rows, cols))
                 return fail(b, CVS_E_SIZE, "with host input frames the requested output planes must be host f32 planes of rows x cols");
@@ -464,7 +469,7 @@ int run_host(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, con
         if (n && (rc = reserve(b, s, s.in, n * plane))) return rc;
         if (n && (rc = reserve(b, s, s.out, n * K * plane))) return rc;
     }
-    HostRun R{b, cfg, inputs, outputs, {0}, K};
+    HostRun R{b, cfg, inputs, outputs, {0}, K, u8};
     for (int j = 0; j < K; ++j) R.sel[j] = sel[j];
     const size_t nl = b->slots.size();
     std::vector<int> rcs(nl, CVS_OK);
@@ -643,7 +648,7 @@ int cvs_batch_run(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs
     if (rs) {
         if (!inputs) return fail(b, CVS_E_BADARG, "the root rank needs the input frames");
         if (cfg->gather && !outputs) return fail(b, CVS_E_BADARG, "the root rank needs output planes to gather into");
-        if (inputs[0].mem == CVS_MEM_HOST) return run_host(b, cfg, inputs, outputs, sel, K, timing);
+        if ((inputs[0].mem & 0xff) == CVS_MEM_HOST) return run_host(b, cfg, inputs, outputs, sel, K, timing);
         for (int f = 0; f < F; ++f) {
             if (!dense_device(&inputs[f], rows, cols)) return fail(b, CVS_E_SIZE, "input frames must be dense f32 device planes of rows x cols");
             for (int j = 0; cfg->gather && j < K; ++j)

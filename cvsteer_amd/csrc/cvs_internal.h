@@ -114,6 +114,10 @@ hipError_t launch_steer_point(const float* state, size_t plane_stride, size_t of
 
 // per-image min/max + 8-bit quantise (cv::normalize NORM_MINMAX -> CV_8UC1)
 hipError_t launch_minmax(const float* src, size_t pitch, int rows, int cols, float* minmax2, hipStream_t s);
+// n equally sized planes at a constant stride, one launch: min / max per plane (minmax = true, minmax2n = 2n floats of
+// scratch) or convertTo(alpha, beta), 8-bit results at dst + z * dst_plane_stride
+hipError_t launch_to_u8_n(const float* src, size_t plane_stride, size_t pitch, int rows, int cols, int n, bool minmax, float* minmax2n,
+                          float alpha, float beta, uint8_t* dst, size_t dst_plane_stride, size_t dst_step, hipStream_t s);
 hipError_t launch_quantize_u8(const float* src, size_t pitch, int rows, int cols, const float* minmax2,
                               uint8_t* dst, size_t dst_step, hipStream_t s);
 

@@ -243,7 +243,16 @@ __global__ __launch_bounds__(256) void k_minmax(const float* src, size_t pitch, 
         lo = fminf(lo, __shfl_xor(lo, off));
         hi = fmaxf(hi, __shfl_xor(hi, off));
     }
+    // one atomic pair per workgroup (all of them land on one cache line)
+    __shared__ float wlo[4], whi[4];
     if ((threadIdx.x & 63) == 0) {
+        wlo[threadIdx.x >> 6] = lo;
+        whi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(wlo[0], wlo[1]), fminf(wlo[2], wlo[3]));
+        hi = fmaxf(fmaxf(whi[0], whi[1]), fmaxf(whi[2], whi[3]));
         atomicMin(&mm[0], float_key(lo));
         atomicMax(&mm[1], float_key(hi));
     }
@@ -415,6 +424,90 @@ hipError_t launch_convert_u8(const float* src, size_t pitch, int rows, int cols,
     int gx = (cols + 255) / 256; if (gx > 16) gx = 16;
     int gy = rows > 256 ? 256 : rows;
     hipLaunchKernelGGL(k_convert_u8, dim3(gx, gy), dim3(256), 0, s, src, pitch, rows, cols, alpha, beta, dst, dst_step);
+    return hipGetLastError();
+}
+
+// ---- the same for n equally sized planes at a constant stride: blockIdx.z = plane, one launch for all of them ----
+__global__ void k_minmax_init_n(int* mm, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        mm[2 * i] = 0x7fffffff;
+        mm[2 * i + 1] = (int)0x80000000;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_minmax_n(const float* src, size_t plane_stride, size_t pitch, int rows, int cols, int* mm)
+{
+    src += (size_t)blockIdx.z * plane_stride;
+    mm += 2 * blockIdx.z;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+            const float v = src[(size_t)row * pitch + c];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    // one atomic pair per workgroup: with hundreds of planes in one launch the per-wave atomics of the single-plane
+    // kernel (thousands on one cache line) would cost more than the reads
+    __shared__ float wlo[4], whi[4];
+    if ((threadIdx.x & 63) == 0) {
+        wlo[threadIdx.x >> 6] = lo;
+        whi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(wlo[0], wlo[1]), fminf(wlo[2], wlo[3]));
+        hi = fmaxf(fmaxf(whi[0], whi[1]), fmaxf(whi[2], whi[3]));
+        atomicMin(&mm[0], float_key(lo));
+        atomicMax(&mm[1], float_key(hi));
+    }
+}
+
+// mm == nullptr: convertTo(alpha, beta); else normalize with plane z's own min / max (same arithmetic as k_quantize_u8)
+__global__ __launch_bounds__(256) void k_to_u8_n(const float* src, size_t plane_stride, size_t pitch, int rows, int cols, const int* mm,
+                                                  float alpha, float beta, uint8_t* dst, size_t dst_plane_stride, size_t dst_step)
+{
+    src += (size_t)blockIdx.z * plane_stride;
+    dst += (size_t)blockIdx.z * dst_plane_stride;
+    float scale = alpha, shift = beta;
+    if (mm) {
+        const float lo = key_float(mm[2 * blockIdx.z]), hi = key_float(mm[2 * blockIdx.z + 1]);
+        const double d = (double)hi - (double)lo;
+        const double scale_d = d > 2.2204460492503131e-16 ? 255.0 / d : 0.0;
+        scale = (float)scale_d;
+        shift = (float)(-(double)lo * scale_d);
+    }
+    for (int row = blockIdx.y; row < rows; row += gridDim.y)
+        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+            int q = __float2int_rn(__fadd_rn(__fmul_rn(src[(size_t)row * pitch + c], scale), shift));  // cvRound: half to even
+            q = q < 0 ? 0 : q > 255 ? 255 : q;
+            dst[(size_t)row * dst_step + c] = (uint8_t)q;
+        }
+}
+
+hipError_t launch_to_u8_n(const float* src, size_t plane_stride, size_t pitch, int rows, int cols, int n, bool minmax, float* minmax2n,
+                          float alpha, float beta, uint8_t* dst, size_t dst_plane_stride, size_t dst_step, hipStream_t s)
+{
+    int gx = (cols + 255) / 256; if (gx > 16) gx = 16;
+    int gy = rows > 256 ? 256 : rows;
+    if (n >= 8 && gy > 32) gy = 32;  // plenty of workgroups from the planes alone; fewer atomics per plane
+    int* mm = reinterpret_cast<int*>(minmax2n);
+    for (int z0 = 0; z0 < n; z0 += 65535) {  // grid.z limit
+        const int nz = n - z0 < 65535 ? n - z0 : 65535;
+        const float* sp = src + (size_t)z0 * plane_stride;
+        if (minmax) {
+            hipLaunchKernelGGL(k_minmax_init_n, dim3((nz + 255) / 256), dim3(256), 0, s, mm + 2 * z0, nz);
+            hipLaunchKernelGGL(k_minmax_n, dim3(gx, gy, nz), dim3(256), 0, s, sp, plane_stride, pitch, rows, cols, mm + 2 * z0);
+        }
+        hipLaunchKernelGGL(k_to_u8_n, dim3(gx, gy, nz), dim3(256), 0, s, sp, plane_stride, pitch, rows, cols, minmax ? mm + 2 * z0 : nullptr, alpha, beta,
+                           dst + (size_t)z0 * dst_plane_stride, dst_plane_stride, dst_step);
+    }
     return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -33,7 +34,9 @@ namespace {
 struct Image {
     std::string path;
     int rows = 0, cols = 0;
-    std::vector<float> pix;  // gray, unscaled (Mat1f(gray), steer.cpp:84)
+    bool u8 = true;              // 8-bit sources stay bytes: they cross the host link as bytes and are widened on the GPU
+    std::vector<uint8_t> bytes;  // gray, 0..255
+    std::vector<float> pix;      // gray, unscaled (Mat1f(gray), steer.cpp:84) -- float sources only
 };
 
 std::string base_name(const std::string& path)
@@ -89,8 +92,7 @@ Image read_pgm(const std::string& path)
     if (im.rows <= 0 || im.cols <= 0 || maxval <= 0 || maxval > 255) throw std::runtime_error(path + ": unsupported PGM header");
     const size_t n = (size_t)im.rows * im.cols;
     if (d.size() < pos + n) throw std::runtime_error(path + ": truncated raster");
-    im.pix.resize(n);
-    for (size_t i = 0; i < n; ++i) im.pix[i] = (float)(unsigned char)d[pos + i];
+    im.bytes.assign(reinterpret_cast<const uint8_t*>(d.data()) + pos, reinterpret_cast<const uint8_t*>(d.data()) + pos + n);
     return im;
 }
 
@@ -118,9 +120,12 @@ Image read_npy(const std::string& path)
     im.cols = c;
     const size_t n = (size_t)r * c, data = off + hlen;
     if (d.size() < data + n * (u1 ? 1 : 4)) throw std::runtime_error(path + ": truncated data");
-    im.pix.resize(n);
-    if (u1) for (size_t i = 0; i < n; ++i) im.pix[i] = (float)(unsigned char)d[data + i];
-    else std::memcpy(im.pix.data(), d.data() + data, n * 4);
+    im.u8 = u1;
+    if (u1) im.bytes.assign(reinterpret_cast<const uint8_t*>(d.data()) + data, reinterpret_cast<const uint8_t*>(d.data()) + data + n);
+    else {
+        im.pix.resize(n);
+        std::memcpy(im.pix.data(), d.data() + data, n * 4);
+    }
     return im;
 }
 
@@ -235,14 +240,16 @@ int main(int argc, char** argv)
                     ++next;
                     continue;
                 }
-                if (!run.empty() && (im.rows != run[0].rows || im.cols != run[0].cols)) break;  // starts the next run
+                if (!run.empty() && (im.rows != run[0].rows || im.cols != run[0].cols || im.u8 != run[0].u8)) break;  // starts the next run
                 run.push_back(std::move(im));
                 ++next;
             }
             if (run.empty()) continue;
             const int rows = run[0].rows, cols = run[0].cols, n = (int)run.size();
             std::vector<cvs_plane> in(n);
-            for (int f = 0; f < n; ++f) in[f] = cvs_plane{run[f].pix.data(), rows, cols, (size_t)cols * sizeof(float), CVS_MEM_HOST};
+            for (int f = 0; f < n; ++f)
+                in[f] = run[f].u8 ? cvs_plane{reinterpret_cast<float*>(run[f].bytes.data()), rows, cols, (size_t)cols, CVS_MEM_HOST | CVS_DEPTH_U8}
+                                  : cvs_plane{run[f].pix.data(), rows, cols, (size_t)cols * sizeof(float), CVS_MEM_HOST};
             cvs_batch_cfg cfg;
             std::memset(&cfg, 0, sizeof cfg);
             cfg.rows = rows;
@@ -255,24 +262,45 @@ int main(int argc, char** argv)
             check(cvs_batch_run(batch, &cfg, in.data(), nullptr, &t), "cvs_batch_run", cvs_batch_last_error(batch));
             if (verbose) std::printf("batch of %d x %dx%d: upload %.2f ms, span %.2f ms\n", n, rows, cols, t.scatter_ms, t.compute_ms);
             static const char* suffix[3] = {"_edges", "_lines_dark", "_lines_bright"};
-            std::vector<uint8_t> u8((size_t)rows * cols);
-            int frame = 0;
+            // every rank's block of maps -> 8 bits on its GPU (one min/max launch, one quantise launch, one sync for the
+            // whole block) -> host; the ranks work side by side, each over its own link
+            const size_t plane = (size_t)rows * cols;
+            std::vector<uint8_t> u8((size_t)n * 3 * plane);
+            std::vector<int> first(gpus + 1, 0), rcs(gpus, CVS_OK);
+            std::vector<float*> blocks(gpus, nullptr);
+            std::vector<int> counts(gpus, 0);
             for (int r = 0; r < gpus; ++r) {
-                float* block = nullptr;
-                int nf = 0, np = 0, br = 0, bc = 0;
-                check(cvs_batch_local_result(batch, r, &block, &nf, &np, &br, &bc), "cvs_batch_local_result", cvs_batch_last_error(batch));
-                for (int i = 0; i < nf; ++i, ++frame) {
-                    for (int j = 0; j < 3; ++j) {
-                        cvs_plane map{block + ((size_t)i * np + j) * rows * cols, rows, cols, (size_t)cols * sizeof(float), CVS_MEM_DEVICE};
-                        if (gain > 0.f) check(cvs_convert_u8(conv[r], &map, gain, 0.f, u8.data(), (size_t)cols, CVS_MEM_HOST), "cvs_convert_u8", cvs_last_error(conv[r]));
-                        else check(cvs_normalize_u8(conv[r], &map, u8.data(), (size_t)cols, CVS_MEM_HOST), "cvs_normalize_u8", cvs_last_error(conv[r]));
-                        check(cvs_sync(conv[r]), "cvs_sync", cvs_last_error(conv[r]));
-                        const std::string dst = output + "/" + base_name(run[frame].path) + suffix[j] + ext;
-                        write_u8(dst, u8, rows, cols);
-                        if (verbose) std::printf("%s\n", dst.c_str());
-                    }
-                }
+                int np = 0, br = 0, bc = 0;
+                check(cvs_batch_local_result(batch, r, &blocks[r], &counts[r], &np, &br, &bc), "cvs_batch_local_result", cvs_batch_last_error(batch));
+                if (counts[r] && np != 3) throw std::runtime_error("internal: expected 3 maps per frame");
+                first[r + 1] = first[r] + counts[r];
             }
+            int frame = first[gpus];
+            auto convert = [&](int r) {
+                const int m = counts[r] * 3;
+                if (!m) return;
+                std::vector<cvs_plane> maps(m);
+                std::vector<uint8_t*> dst(m);
+                for (int i = 0; i < m; ++i) {
+                    maps[i] = cvs_plane{blocks[r] + (size_t)i * plane, rows, cols, (size_t)cols * sizeof(float), CVS_MEM_DEVICE};
+                    dst[i] = u8.data() + ((size_t)first[r] * 3 + i) * plane;
+                }
+                rcs[r] = gain > 0.f ? cvs_convert_u8_batch(conv[r], maps.data(), m, gain, 0.f, dst.data(), (size_t)cols, CVS_MEM_HOST)
+                                    : cvs_normalize_u8_batch(conv[r], maps.data(), m, dst.data(), (size_t)cols, CVS_MEM_HOST);
+            };
+            std::vector<std::thread> workers;
+            for (int r = 1; r < gpus; ++r) workers.emplace_back(convert, r);
+            convert(0);
+            for (std::thread& w : workers) w.join();
+            for (int r = 0; r < gpus; ++r) check(rcs[r], "cvs_*_u8_batch", cvs_last_error(conv[r]));
+            std::vector<uint8_t> one(plane);
+            for (int f = 0; f < frame; ++f)
+                for (int j = 0; j < 3; ++j) {
+                    const std::string dst = output + "/" + base_name(run[f].path) + suffix[j] + ext;
+                    one.assign(u8.begin() + ((size_t)f * 3 + j) * plane, u8.begin() + ((size_t)f * 3 + j + 1) * plane);
+                    write_u8(dst, one, rows, cols);
+                    if (verbose) std::printf("%s\n", dst.c_str());
+                }
             if (frame != n) throw std::runtime_error("internal: the ranks returned " + std::to_string(frame) + " frames of " + std::to_string(n));
         }
     } catch (const std::exception& e) {

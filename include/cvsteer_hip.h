@@ -234,6 +234,11 @@ int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst);
 int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem);
 /* Mat::convertTo(dst, CV_8UC1, alpha, beta) -- the `--gain` branch of example/steer.cpp:92-97 */
 int cvs_convert_u8(cvs_handle h, const cvs_plane* src, float alpha, float beta, uint8_t* dst, size_t dst_step, int dst_mem);
+/* the same for n planes in one go (a driver turning a whole block of feature maps into 8-bit files, steer.cpp:92-122 per
+ * file): equally sized device planes at a constant stride take one min/max launch, one quantise launch and one
+ * synchronisation for all of them; anything else goes plane by plane.  dst[i] receives plane i. */
+int cvs_normalize_u8_batch(cvs_handle h, const cvs_plane* src, int n, uint8_t* const* dst, size_t dst_step, int dst_mem);
+int cvs_convert_u8_batch(cvs_handle h, const cvs_plane* src, int n, float alpha, float beta, uint8_t* const* dst, size_t dst_step, int dst_mem);
 
 /* ---------------- the batch axis over the GPUs of one node (cvs_batch.cpp) ----------------
  * example/steer.cpp:169 runs cv::parallel_for_(Range(0, N), body): one independent SteerableFiltersG2 pipeline per
@@ -274,7 +279,7 @@ int cvs_batch_set_option(cvs_batch b, int option, int value);
  * cfg->outputs are ignored).  scatter (grouped ncclSend/ncclRecv) -> one cvs_pipeline_batch launch per rank ->
  * gather (grouped ncclSend/ncclRecv).  The root's own block is processed in place.
  * HOST planes (what the example holds: cv::Mat, steer.cpp:73-104; rows may be padded): inputs and requested outputs all
- * CVS_MEM_HOST.  Nothing passes through the root's GPU then -- every rank uploads ITS frames from the caller's planes over
+ * CVS_MEM_HOST; the inputs may be 8-bit (all of them CVS_MEM_HOST | CVS_DEPTH_U8, step in bytes: a quarter of the upload).  Nothing passes through the root's GPU then -- every rank uploads ITS frames from the caller's planes over
  * its own host link and downloads its outputs the same way, all ranks at once, upload / launch / download overlapped
  * chunk by chunk inside a rank.  Needs every rank in the calling process (cvs_batch_create_local, or a world of 1);
  * CVS_E_UNSUPPORTED otherwise.  timing: scatter = upload, gather = download, compute = the slowest rank's whole span. */

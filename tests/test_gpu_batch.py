@@ -118,6 +118,97 @@ def test_host_planes_every_rank_pulls_its_own_frames(cv, world, n_frames, persis
     nb.close()
 
 
+def test_to_u8_batch_equals_plane_by_plane(cv):
+    """cvs_normalize_u8_batch / cvs_convert_u8_batch (steer.cpp:92-98 for a whole block of maps): one launch pair and one
+    sync for n planes, bit-identical to the single-plane calls; irregular plane lists fall back to plane by plane"""
+    import ctypes as C
+    import torch
+    from cvsteer_amd import _lib as L
+    lib = L.lib()
+    eng = cv.SteerableFiltersG2(None)
+    n, rows, cols = 7, 61, 300
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    block = (torch.rand((n, rows, cols), device="cuda", generator=gen) - 0.3) * torch.arange(1, n + 1, device="cuda").view(n, 1, 1) * 40.0
+    block[3] = 5.0                                     # a constant plane: max == min
+    want_n = torch.stack([eng.normalize_u8(block[i]) for i in range(n)]).cpu().numpy()
+    want_c = torch.stack([eng.convert_u8(block[i], 1.7) for i in range(n)]).cpu().numpy()
+
+    def planes_of(t):
+        arr = (L.Plane * len(t))()
+        for i, x in enumerate(t):
+            arr[i] = L.Plane(x.data_ptr(), rows, cols, x.stride(0) * 4, L.MEM_DEVICE)
+        return arr
+
+    scattered = [block[i].clone() if i % 2 else block[i] for i in range(n)]                # kept alive for the calls below
+    for src in (planes_of([block[i] for i in range(n)]),                                   # regular: one launch pair
+                planes_of(scattered)):                                                     # irregular: fallback
+        host = np.zeros((n, rows, cols + 5), np.uint8)
+        dst = (C.c_void_p * n)(*[host[i].ctypes.data for i in range(n)])
+        assert lib.cvs_normalize_u8_batch(eng._h, src, n, dst, cols + 5, L.MEM_HOST) == 0
+        assert np.array_equal(host[:, :, :cols], want_n) and not host[:, :, cols:].any()
+        assert lib.cvs_convert_u8_batch(eng._h, src, n, C.c_float(1.7), C.c_float(0.0), dst, cols + 5, L.MEM_HOST) == 0
+        assert np.array_equal(host[:, :, :cols], want_c)
+        dev = torch.zeros((n, rows, cols), dtype=torch.uint8, device="cuda")
+        ddst = (C.c_void_p * n)(*[dev[i].data_ptr() for i in range(n)])
+        assert lib.cvs_normalize_u8_batch(eng._h, src, n, ddst, cols, L.MEM_DEVICE) == 0
+        lib.cvs_sync(eng._h)
+        assert np.array_equal(dev.cpu().numpy(), want_n)
+    assert lib.cvs_normalize_u8_batch(eng._h, src, 0, dst, cols, L.MEM_HOST) == L.E_BADARG
+
+
+def test_pipeline_batch_widens_a_block_of_byte_frames_in_one_launch(cv):
+    """8-bit frames lying back to back on the device (a driver's upload) take the one-launch path: same results as f32"""
+    import ctypes as C
+    import torch
+    from cvsteer_amd import _lib as L
+    lib = L.lib()
+    n, rows, cols = 5, 130, 257
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    u8 = (torch.rand((n, rows, cols), device="cuda", generator=gen) * 255).to(torch.uint8).contiguous()
+    want = cv.SteerableFiltersG2(None).pipeline_batch(u8.to(torch.float32), outputs=(3, 4, 5, 6, 7))
+    eng = cv.SteerableFiltersG2(None)
+    out = torch.zeros((n, 5, rows, cols), device="cuda")
+    ims = (L.Plane * n)()
+    outs = (L.Plane * (n * 8))()
+    for i in range(n):
+        ims[i] = L.Plane(u8[i].data_ptr(), rows, cols, cols, L.MEM_DEVICE | L.DEPTH_U8)
+        for j, k in enumerate((3, 4, 5, 6, 7)):
+            outs[i * 8 + k] = L.Plane(out[i, j].data_ptr(), rows, cols, cols * 4, L.MEM_DEVICE)
+    assert lib.cvs_pipeline_batch(eng._h, ims, n, outs) == 0
+    lib.cvs_sync(eng._h)
+    assert torch.equal(out, want)
+    eng.select_frame(n - 1)                     # state of every frame is there, as after an f32 batch
+    single = cv.SteerableFiltersG2(u8[n - 1].to(torch.float32))
+    eng._like = out                                # results as CUDA tensors (the raw ctypes call above did not say)
+    assert torch.equal(eng.basis(2), single.basis(2))
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_byte_frames_from_host_and_the_whole_driver_flow(cv, world):
+    """uint8 host frames through cvs_batch_run (bytes cross the link) == float frames; NativeBatch.run_to_u8 (maps kept on the
+    GPUs, converted there, only bytes come back) == the single-engine pipeline + normalize_u8 / convert_u8 per plane"""
+    import torch
+    from cvsteer_amd import batch
+    n, rows, cols = 7, 75, 210
+    rng = np.random.default_rng(11)
+    u8 = rng.integers(0, 256, (n, rows, cols), dtype=np.uint8)
+    nb = batch.NativeBatch.local((0,) * world)
+    nb.set_persist(False)
+    got_b, _ = nb.run(u8, n, (rows, cols), outputs=(5, 6, 7))
+    got_f, _ = nb.run(u8.astype(np.float32), n, (rows, cols), outputs=(5, 6, 7))
+    assert np.array_equal(got_b, got_f)
+    eng = cv.SteerableFiltersG2(None)
+    ref = eng.pipeline_batch(torch.from_numpy(u8.astype(np.float32)).cuda(), outputs=(5, 6, 7))
+    assert np.array_equal(got_b, ref.cpu().numpy())
+    q, _ = nb.run_to_u8(u8)
+    want = torch.stack([torch.stack([eng.normalize_u8(ref[i, j]) for j in range(3)]) for i in range(n)]).cpu().numpy()
+    assert q.dtype == np.uint8 and np.array_equal(q, want)
+    q2, _ = nb.run_to_u8(u8.astype(np.float32), gain=3.0)
+    want2 = torch.stack([torch.stack([eng.convert_u8(ref[i, j], 3.0) for j in range(3)]) for i in range(n)]).cpu().numpy()
+    assert np.array_equal(q2, want2)
+    nb.close()
+
+
 def test_host_planes_mixed_with_device_planes_rejected(cv):
     import ctypes as C
     from cvsteer_amd import _lib as L
