@@ -1074,3 +1074,50 @@ def test_g4_bank_layouts_never_change_results(cv):
                     ref = cur
                 for a, b in zip(cur, ref):
                     assert torch.equal(a, b), (shape, split, order)
+
+
+def test_one_object_per_image_per_worker_thread(cv):
+    """The reference's usage model (example/steer.cpp:69-71,86: cv::parallel_for_ over files, one SteerableFiltersG2
+    per image inside the body): eight host threads, each constructing short-lived objects on its own images --
+    device planes and host planes, two sizes (one large enough for the allocation-time placement probe and the
+    launch tuner) -- while the others do the same.  Everything process-wide (state-block cache, tuner memory,
+    placement probe, address-space budget) is shared; results must equal the serial ones bit for bit."""
+    import threading
+    import torch
+    shapes = [(200, 333), (2112, 4096)]
+    rng = np.random.default_rng(77)
+    images = [[torch.from_numpy(rng.random(s, dtype=np.float32)).cuda() for _ in range(3)] for s in shapes]
+    serial = [[[o.clone() for o in cv.SteerableFiltersG2(im).pipeline(im)] for im in group] for group in images]
+    host_in = images[0][1].cpu().numpy()
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(6):
+                g = (tid + it) % 2
+                k = (tid * 7 + it) % 3
+                im = images[g][k]
+                f = cv.SteerableFiltersG2(im)                      # ctor = setup (G2.cpp:57)
+                outs = f.pipeline(im)
+                for a_, b_ in zip(outs, serial[g][k]):
+                    if not torch.equal(a_, b_):
+                        errors.append(("device", tid, it, g, k))
+                        return
+                if it % 3 == 0:                                      # the cv::Mat way: host in, host out
+                    fh = cv.SteerableFiltersG2(None)
+                    houts = fh.pipeline(host_in)
+                    for a_, b_ in zip(houts, serial[0][1]):
+                        if not np.array_equal(np.asarray(a_), b_.cpu().numpy()):
+                            errors.append(("host", tid, it))
+                            return
+                del f
+        except Exception as ex:   # noqa: BLE001 -- reported below
+            errors.append(("exception", tid, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a worker thread hangs"
+    assert not errors, errors[:3]
