@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/ab_build.py -- A/B of two BUILDS of libcvsteer_hip.so (tools/ablibs/<name>.so), each run in fresh processes,
 alternating, with the allocation-time placement probe and the launch autotuner off (plain hipMalloc state, default launch
-configuration), so that what differs is the kernel code.  usage: ab_build.py base new [more ...] [rounds]"""
+configuration), so that what differs is the kernel code.  tools/make_probe_libs.sh builds the probe variants.
+usage: ab_build.py cur NOSTORE [more ...] [rounds]"""
 import os, subprocess, sys, re, statistics
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
