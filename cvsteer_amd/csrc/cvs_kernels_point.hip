@@ -437,17 +437,29 @@ __global__ void k_minmax_init_n(int* mm, int n)
     }
 }
 
+// VEC: rows are 16-byte aligned and cols % 4 == 0 -- four pixels per lane and access
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_minmax_n(const float* src, size_t plane_stride, size_t pitch, int rows, int cols, int* mm)
 {
     src += (size_t)blockIdx.z * plane_stride;
     mm += 2 * blockIdx.z;
     float lo = INFINITY, hi = -INFINITY;
-    for (int row = blockIdx.y; row < rows; row += gridDim.y)
-        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
-            const float v = src[(size_t)row * pitch + c];
-            lo = fminf(lo, v);
-            hi = fmaxf(hi, v);
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        if constexpr (VEC) {
+            const float4* r4 = reinterpret_cast<const float4*>(src + (size_t)row * pitch);
+            for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols / 4; c += gridDim.x * blockDim.x) {
+                const float4 v = r4[c];
+                lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
+                hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+            }
+        } else {
+            for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+                const float v = src[(size_t)row * pitch + c];
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+            }
         }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, off));
@@ -470,6 +482,7 @@ __global__ __launch_bounds__(256) void k_minmax_n(const float* src, size_t plane
 }
 
 // mm == nullptr: convertTo(alpha, beta); else normalize with plane z's own min / max (same arithmetic as k_quantize_u8)
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_to_u8_n(const float* src, size_t plane_stride, size_t pitch, int rows, int cols, const int* mm,
                                                   float alpha, float beta, uint8_t* dst, size_t dst_plane_stride, size_t dst_step)
 {
@@ -483,18 +496,33 @@ __global__ __launch_bounds__(256) void k_to_u8_n(const float* src, size_t plane_
         scale = (float)scale_d;
         shift = (float)(-(double)lo * scale_d);
     }
-    for (int row = blockIdx.y; row < rows; row += gridDim.y)
-        for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
-            int q = __float2int_rn(__fadd_rn(__fmul_rn(src[(size_t)row * pitch + c], scale), shift));  // cvRound: half to even
-            q = q < 0 ? 0 : q > 255 ? 255 : q;
-            dst[(size_t)row * dst_step + c] = (uint8_t)q;
+    auto quant = [&](float v) {
+        int q = __float2int_rn(__fadd_rn(__fmul_rn(v, scale), shift));  // cvRound: half to even
+        return (unsigned)(q < 0 ? 0 : q > 255 ? 255 : q);
+    };
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        if constexpr (VEC) {  // four pixels per lane: one 16-byte load, one 4-byte store
+            const float4* r4 = reinterpret_cast<const float4*>(src + (size_t)row * pitch);
+            unsigned* d4 = reinterpret_cast<unsigned*>(dst + (size_t)row * dst_step);
+            for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols / 4; c += gridDim.x * blockDim.x) {
+                const float4 v = r4[c];
+                d4[c] = quant(v.x) | (quant(v.y) << 8) | (quant(v.z) << 16) | (quant(v.w) << 24);
+            }
+        } else {
+            for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x)
+                dst[(size_t)row * dst_step + c] = (uint8_t)quant(src[(size_t)row * pitch + c]);
         }
+    }
 }
 
 hipError_t launch_to_u8_n(const float* src, size_t plane_stride, size_t pitch, int rows, int cols, int n, bool minmax, float* minmax2n,
                           float alpha, float beta, uint8_t* dst, size_t dst_plane_stride, size_t dst_step, hipStream_t s)
 {
-    int gx = (cols + 255) / 256; if (gx > 16) gx = 16;
+    // four pixels per lane where every row of source and destination allows it
+    const bool vec = cols % 4 == 0 && pitch % 4 == 0 && plane_stride % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
+                     dst_step % 4 == 0 && dst_plane_stride % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0;
+    const int lanes = vec ? cols / 4 : cols;
+    int gx = (lanes + 255) / 256; if (gx > 16) gx = 16;
     int gy = rows > 256 ? 256 : rows;
     if (n >= 8 && gy > 32) gy = 32;  // plenty of workgroups from the planes alone; fewer atomics per plane
     int* mm = reinterpret_cast<int*>(minmax2n);
@@ -503,10 +531,13 @@ hipError_t launch_to_u8_n(const float* src, size_t plane_stride, size_t pitch, i
         const float* sp = src + (size_t)z0 * plane_stride;
         if (minmax) {
             hipLaunchKernelGGL(k_minmax_init_n, dim3((nz + 255) / 256), dim3(256), 0, s, mm + 2 * z0, nz);
-            hipLaunchKernelGGL(k_minmax_n, dim3(gx, gy, nz), dim3(256), 0, s, sp, plane_stride, pitch, rows, cols, mm + 2 * z0);
+            if (vec) hipLaunchKernelGGL(k_minmax_n<true>, dim3(gx, gy, nz), dim3(256), 0, s, sp, plane_stride, pitch, rows, cols, mm + 2 * z0);
+            else hipLaunchKernelGGL(k_minmax_n<false>, dim3(gx, gy, nz), dim3(256), 0, s, sp, plane_stride, pitch, rows, cols, mm + 2 * z0);
         }
-        hipLaunchKernelGGL(k_to_u8_n, dim3(gx, gy, nz), dim3(256), 0, s, sp, plane_stride, pitch, rows, cols, minmax ? mm + 2 * z0 : nullptr, alpha, beta,
-                           dst + (size_t)z0 * dst_plane_stride, dst_plane_stride, dst_step);
+        if (vec) hipLaunchKernelGGL(k_to_u8_n<true>, dim3(gx, gy, nz), dim3(256), 0, s, sp, plane_stride, pitch, rows, cols, minmax ? mm + 2 * z0 : nullptr, alpha, beta,
+                                    dst + (size_t)z0 * dst_plane_stride, dst_plane_stride, dst_step);
+        else hipLaunchKernelGGL(k_to_u8_n<false>, dim3(gx, gy, nz), dim3(256), 0, s, sp, plane_stride, pitch, rows, cols, minmax ? mm + 2 * z0 : nullptr, alpha, beta,
+                                dst + (size_t)z0 * dst_plane_stride, dst_plane_stride, dst_step);
     }
     return hipGetLastError();
 }
