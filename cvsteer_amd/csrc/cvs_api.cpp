@@ -1408,6 +1408,33 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
         a.in_frame_stride = (size_t)d_in;
         a.out_frame_stride = (size_t)d_out;
         for (int k = 0; k < 8; ++k) a.pipe_out[k] = tab[0].out[k];
+        // one buffer resource per frame for all outputs, if frame 0's outputs share a pitch and lie within 2 GiB
+        float* lo = nullptr;
+        size_t opitch = 0;
+        bool one = true;
+        for (int k = 0; k < 8; ++k) {
+            if (!tab[0].out[k].p) continue;
+            if (!lo || tab[0].out[k].p < lo) lo = tab[0].out[k].p;
+            if (!opitch) opitch = tab[0].out[k].pitch;
+            one = one && tab[0].out[k].pitch == opitch;
+        }
+        size_t span = 0;
+        for (int k = 0; k < 8 && one; ++k) {
+            if (!tab[0].out[k].p) continue;
+            const size_t off = (size_t)(tab[0].out[k].p - lo) * sizeof(float);
+            span = std::max(span, off + (size_t)rows * opitch * sizeof(float));
+            one = span <= (size_t)0x7ffffff0;
+            a.out_off[k] = (unsigned)off;
+            a.out_mask |= 1u << k;
+        }
+        if (one) {
+            a.out_one = 1;
+            a.out_base = lo;
+            a.out_pitch = opitch;
+            a.out_bytes = span;
+        } else {
+            a.out_mask = 0;
+        }
     }
     a.basis = h->state;
     a.pitch = h->pitch;

@@ -62,6 +62,16 @@ struct BasisArgs {
     // pipe_out[k].p + z*out_frame_stride -- pointers from kernel arguments only, no table, no upload
     int batch_regular;
     size_t in_frame_stride, out_frame_stride;  // elements
+    // regular batch whose outputs of one frame share a pitch and lie within 2 GiB of each other (one [K, H, W] block per
+    // frame, the usual case): ONE buffer resource per frame for all of them -- out_base + z*out_frame_stride, out_bytes
+    // long -- and output k at byte offset out_off[k]; out_mask = which outputs exist.  Keeps 8 pointers + 8 pitches out
+    // of the scalar registers (the batched pipeline kernel spilled ~290 SGPR lane moves per row without this).
+    int out_one;
+    unsigned out_mask;
+    unsigned out_off[8];
+    float* out_base;
+    size_t out_pitch;   // elements
+    size_t out_bytes;
     size_t frame_stride;       // elements between the state blocks of consecutive frames
     // diagnostic builds only (-DCVS_DIAG_STAMPS, tools/k1_timeline.py): per-wave {start, first store, end}
     // 100 MHz real-time stamps; never read by the product, nullptr in normal builds

@@ -155,7 +155,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 // `zframe` = frame index of a batched launch.
 // WPB = waves (adjacent 64-column strips of one row band) per workgroup.  Always 4: 8-wave workgroups were built
 // and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones.
-template <class B, int FLAGS, bool STREAM, bool BATCH, bool ONE, int WPB>
+template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB>
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe)
 {
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
@@ -234,7 +234,13 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     float* basis_p = a.basis;
     float* orient_p = a.orient;
     PlaneRef pipe_out[8];
-    if constexpr (BATCH) {
+    [[maybe_unused]] rsrc_t r_out = plane_rsrc(nullptr, 0);
+    if constexpr (BATCH == 2) {  // regular frames, one output resource per frame: nothing but three 64-bit bases depends on the frame
+        basis_p += (size_t)zframe * a.frame_stride;
+        orient_p += (size_t)zframe * a.frame_stride;
+        in_p += (size_t)zframe * a.in_frame_stride;
+        r_out = plane_rsrc(a.out_base + (size_t)zframe * a.out_frame_stride, a.out_bytes);
+    } else if constexpr (BATCH == 1) {
         basis_p += (size_t)zframe * a.frame_stride;
         orient_p += (size_t)zframe * a.frame_stride;
         if (a.frames) {  // per-frame pointers from the device table
@@ -373,7 +379,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 }
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
                     // stateless pipeline: the oriented energy (and with it C1) is evaluated only when asked for
-                    const bool need_e = (FLAGS & F_NOSTATE) == 0 || pipe_out[2].p != nullptr || a.find_on_e != 0;  // wave-uniform
+                    const bool want_e = BATCH == 2 ? (a.out_mask & 4u) != 0 : pipe_out[2].p != nullptr;
+                    const bool need_e = (FLAGS & F_NOSTATE) == 0 || want_e || a.find_on_e != 0;  // wave-uniform
                     float c1, c2, c3, th, st;
                     g2_orientation(b, a.atan_mode, c1, c2, c3, th, st, need_e);
                     if constexpr ((FLAGS & F_NOSTATE) == 0) {
@@ -400,11 +407,18 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         q[5] = __fmul_rn(en, phase_lambda<true>(q[4], kHalfPiF, false));
                         q[6] = __fmul_rn(en, phase_lambda<true>(q[4], 0.f, true));
                         q[7] = __fmul_rn(en, phase_lambda<true>(q[4], kPiF, true));
+                        if constexpr (BATCH == 2) {
+                            const unsigned orow_out = yo * (unsigned)(a.out_pitch * sizeof(float));
 #pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if (pipe_out[k].p)
-                                bst<STREAM>(plane_rsrc(pipe_out[k].p, (size_t)(a.rows - rbase) * pipe_out[k].pitch * sizeof(float)), xbr,
-                                            yo * (unsigned)(pipe_out[k].pitch * sizeof(float)), q[k]);
+                            for (int k = 0; k < 8; ++k)
+                                if (a.out_mask & (1u << k)) bst<STREAM>(r_out, xbr, orow_out + a.out_off[k], q[k]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                if (pipe_out[k].p)
+                                    bst<STREAM>(plane_rsrc(pipe_out[k].p, (size_t)(a.rows - rbase) * pipe_out[k].pitch * sizeof(float)), xbr,
+                                                yo * (unsigned)(pipe_out[k].pitch * sizeof(float)), q[k]);
+                        }
                     }
                 }
                 if constexpr ((FLAGS & F_STEER) != 0) {
@@ -444,7 +458,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #endif
 }
 
-template <class B, int FLAGS, bool STREAM, bool BATCH = false, bool ONE = false, int WPB = 4>
+template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
     __shared__ float lds[WPB][64 + 2 * B::W + 4];
@@ -590,12 +604,17 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
         }                                                                                                          \
     } while (0)
 #define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 4)
-#define CVS_LAUNCH(FL) CVS_LAUNCH_B(FL, false)
+#define CVS_LAUNCH(FL) CVS_LAUNCH_B(FL, 0)
     if (a.frames || a.batch_regular) {  // batched caller pipeline: one launch, grid.z = frames (G2 only)
         if constexpr (B::KIND == 2 && B::HALF == 0) {
             grid.z = a.batch;
-            if (a.no_state) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE, true);
-            else CVS_LAUNCH_B(F_ORIENT | F_PIPE, true);
+            if (a.batch_regular && a.out_one) {
+                if (a.no_state) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE, 2);
+                else CVS_LAUNCH_B(F_ORIENT | F_PIPE, 2);
+            } else {
+                if (a.no_state) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE, 1);
+                else CVS_LAUNCH_B(F_ORIENT | F_PIPE, 1);
+            }
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
