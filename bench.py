@@ -423,7 +423,18 @@ def main():
             bsteps = max(5, args.steps // 4)
             leg("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
             leg("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
-            del big2, fb, gb, hb
+            # ... and with two images taking turns: the two legs above re-filter ONE 256 MiB image, most of which is still in
+            # the 256 MiB Infinity Cache when the next step starts (the streaming stores do not displace it); any launch in
+            # between that touches 64 MiB ends that (tools/c3_between.py), and so does a second image
+            big3 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
+            flipb = {"i": 0}
+
+            def step_big_rot():
+                flipb["i"] ^= 1
+                fb.setup_steer(big3 if flipb["i"] else big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb))
+
+            leg("M2_filter_steer_8192_rotating_2_inputs", step_big_rot, 40, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
+            del big2, big3, fb, gb, hb
 
         # ---- BASELINE config 4: 1080 x 1920 frames, the callers' whole pipeline per frame, 32 frames per GPU ----
         # Two frame sets alternate so that every launch reads frames the previous launch did not touch (2 x 265 MB
@@ -535,24 +546,48 @@ def main():
 
         if ws == 1:
             # BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image (pyrDown is this
-            # build's own component -- the reference has no pyramid code)
-            big = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
+            # build's own component -- the reference has no pyramid code).  `whole_*` = the configuration as a user
+            # runs it: build the pyramid AND filter every level, with the filter launch of level k writing level k+1
+            # (cvs_setup_pyr: the image is read once per level); two 8192^2 images alternate, so that no input is a
+            # leftover of the previous step in the Infinity Cache.  `filter_*` = the five filter launches alone on a
+            # pyramid built beforehand (round 1's figure), `pyramid_build_ms` = the four stand-alone pyrDown launches.
+            bigs = [torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32) for _ in range(2)]
             fp3 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-            lv = fp3.pyramid(big, 5)
+            lv = fp3.pyramid(bigs[0], 5)
             ppix = sum(l.shape[0] * l.shape[1] for l in lv)
             hp = [cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank) for _ in lv]
+            flip3 = {"i": 0}
 
             def pyr_filter():
                 for hnd, l in zip(hp, lv):
                     hnd.setup(l, flags=cv.SETUP_BASIS)
 
-            c3 = max(5, args.steps // 10)
+            def pyr_whole():
+                flip3["i"] ^= 1
+                cur = bigs[flip3["i"]]
+                for k, hnd in enumerate(hp):
+                    if k + 1 < len(hp):
+                        hnd.setup_pyr(cur, flags=cv.SETUP_BASIS, out=lv[k + 1])
+                        cur = lv[k + 1]
+                    else:
+                        hnd.setup(cur, flags=cv.SETUP_BASIS)
+
+            c3 = max(10, args.steps // 10)
             w_, e_ = _time_steps(torch, pyr_filter, c3, WARM_NEW, barrier)
-            w2_, e2_ = _time_steps(torch, lambda: fp3.pyramid(big, 5), c3, 2, barrier)
-            extra["C3_pyramid_8192_5_levels"] = {"filter_Mpix/s": round(ppix / (e_ / c3 * 1e-3) / 1e6, 1), "filter_ms": round(e_ / c3, 4),
+            w2_, e2_ = _time_steps(torch, lambda: fp3.pyramid(bigs[0], 5), c3, 2, barrier)
+            w3_, e3_ = _time_steps(torch, pyr_whole, c3, WARM_NEW, barrier)
+            # algorithmic bytes of the whole configuration: 4 B read + 28 B written per pixel of every level, plus the
+            # 4 B written per pixel of every level that is made here (levels 1..4)
+            whole_bytes = 32 * ppix + 4 * (ppix - lv[0].shape[0] * lv[0].shape[1])
+            extra["C3_pyramid_8192_5_levels"] = {"whole_ms": round(e3_ / c3, 4), "whole_Mpix/s": round(ppix / (e3_ / c3 * 1e-3) / 1e6, 1),
+                                                "whole_frac_hbm": round(whole_bytes / (e3_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                "whole_algorithmic_bytes": whole_bytes, "launches": len(hp),
+                                                "filter_Mpix/s": round(ppix / (e_ / c3 * 1e-3) / 1e6, 1), "filter_ms": round(e_ / c3, 4),
                                                 "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix}
-            del big, lv, hp, fp3
+                                                "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix, "timed_steps": c3,
+                                                "note": "whole = build + filter, level k+1 written by the filter launch of level k, two alternating images; "
+                                                        "filter = five filter launches on a prebuilt pyramid; separate build + filter = filter_ms + pyramid_build_ms"}
+            del bigs, lv, hp, fp3
         out["extra"] = extra
 
     if rank == 0 and ws == 1 and not args.no_cpu:

@@ -260,6 +260,25 @@ class SteerableFilters:
             out.append(self.pyrDown(out[-1]))
         return out
 
+    def setup_pyr(self, image, flags=None, out=None):
+        """setup(image) and pyrDown(image) in one pass over the image -> the next pyramid level"""
+        image = _as_input(image)
+        if flags is None:
+            flags = self._setup_flags if self._setup_flags is not None else self._DEFAULT_FLAGS
+        shape = ((image.shape[0] + 1) // 2, (image.shape[1] + 1) // 2)
+        if out is not None:
+            dst = out
+        elif _is_torch(image):
+            dst = torch.empty(shape, dtype=torch.float32, device=image.device)
+        else:
+            dst = np.empty(shape, np.float32)
+        self._like = image
+        self._bind_stream(image, dst)
+        self._image_keepalive = image
+        ps, pd = _plane(image), _plane(dst)
+        self._check(lib().cvs_setup_pyr(self._h, C.byref(ps), flags, C.byref(pd)), "cvs_setup_pyr")
+        return dst
+
 
 class SteerableFiltersG2(SteerableFilters):
     """fa::SteerableFiltersG2 (SteerableFiltersG2.h:35-67)."""

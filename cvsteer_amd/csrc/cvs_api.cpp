@@ -679,11 +679,15 @@ int host_pipeline(cvs_handle h, Call& c, BasisArgs& a, float* scr)
 
 int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, float theta, const cvs_plane* g,
              const cvs_plane* hq, const cvs_plane* const* pipe_outs = nullptr, int nframes = 1, int frame = 0,
-             int out_row_lo = 0, int out_row_hi = 0)
+             int out_row_lo = 0, int out_row_hi = 0, const cvs_plane* pyr = nullptr)
 {
     if (!h) return CVS_E_BADARG;
     int rc = check_plane(h, image, "image", true);
     if (rc) return rc;
+    if (pyr) {  // the next pyramid level, written by the same pass (cvs_setup_pyr)
+        if ((rc = check_plane(h, pyr, "next_level")) || (rc = check_same(h, pyr, (image->rows + 1) / 2, (image->cols + 1) / 2))) return rc;
+        if (pyr->data == image->data) return fail(h, CVS_E_BADARG, "an output plane aliases the input image");
+    }
     if (!(flags & CVS_SETUP_BASIS)) flags |= CVS_SETUP_BASIS;
     if ((flags & CVS_SETUP_ORIENT) && h->kind != CVS_KIND_G2 && !h->g4_ext)
         return fail(h, CVS_E_UNSUPPORTED, "the reference computes no orientation for G4 (G4.cpp:67-81); see CVS_OPT_G4_EXTENSIONS");
@@ -711,7 +715,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     const cvs_plane* po[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (pipe_outs)
         for (int k = 0; k < 8; ++k) po[k] = pipe_outs[k];
-    rc = begin(h, c, {image, steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7]}, scratch);
+    rc = begin(h, c, {image, steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7], pyr}, scratch);
     if (rc) return rc;
     // host planes on the fast path of a large enough image: upload, filtering and download overlap band by band
     // (it pays when a sizeable upload can hide behind the downloads: an f32 host image with host outputs -- measured
@@ -723,7 +727,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     any_host = any_host && mem_of(image) == CVS_MEM_HOST && !is_u8(image);
     hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(h->stream, &cap_st);
-    const bool overlap = h->host_overlap && any_host && !may_generic && nframes == 1 && out_row_hi <= out_row_lo &&
+    const bool overlap = h->host_overlap && any_host && !may_generic && nframes == 1 && out_row_hi <= out_row_lo && !pyr &&
                          cap_st == hipStreamCaptureStatusNone && (size_t)image->rows * image->cols >= ((size_t)1 << 20) &&
                          image->rows >= 16 * (2 * h->width + 1) && !(h->kind == CVS_KIND_G4 && (flags & CVS_SETUP_ORIENT));
     c.defer = overlap;
@@ -770,6 +774,12 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         a.find_on_e = h->find_on;
         for (int k = 0; k < 8; ++k)
             if ((rc = out_ref(c, po[k], a.pipe_out[k]))) return rc;
+    }
+    if (pyr) {
+        PlaneRef rp;
+        if ((rc = out_ref(c, pyr, rp))) return rc;
+        a.pyr_out = rp.p;
+        a.pyr_pitch = rp.pitch;
     }
     float* scr = scratch ? arena_take(h, scratch) : nullptr;
     if (overlap) {
@@ -1103,6 +1113,13 @@ int cvs_setup(cvs_handle h, const cvs_plane* image, unsigned flags)
 int cvs_setup_steer(cvs_handle h, const cvs_plane* image, unsigned flags, float theta, const cvs_plane* g, const cvs_plane* hq)
 {
     return do_setup(h, image, flags, true, theta, g, hq);
+}
+
+int cvs_setup_pyr(cvs_handle h, const cvs_plane* image, unsigned flags, const cvs_plane* next_level)
+{
+    if (!h) return CVS_E_BADARG;
+    if (!next_level) return fail(h, CVS_E_BADARG, "next_level");
+    return do_setup(h, image, flags, false, 0.f, nullptr, nullptr, nullptr, 1, 0, 0, 0, next_level);
 }
 
 int cvs_setup_rows(cvs_handle h, const cvs_plane* image, unsigned flags, int row_lo, int row_hi)

@@ -73,6 +73,12 @@ struct BasisArgs {
     size_t out_pitch;   // elements
     size_t out_bytes;
     size_t frame_stride;       // elements between the state blocks of consecutive frames
+    // fused pyramid level (BASELINE config 3): the same launch also writes cv::pyrDown(image) -- ((rows+1)/2) x ((cols+1)/2),
+    // 5-tap [1 4 6 4 1]/16 blur + 2x decimation from the rows the wave has staged anyway -- so that the image is read once
+    // for "filter this level and make the next one".  nullptr = off.  G2 bank, un-banded single-image launches only; the
+    // API layer runs the stand-alone k_pyr_down otherwise (identical values).
+    float* pyr_out;
+    size_t pyr_pitch;          // elements
     // diagnostic builds only (-DCVS_DIAG_STAMPS, tools/k1_timeline.py): per-wave {start, first store, end}
     // 100 MHz real-time stamps; never read by the product, nullptr in normal builds
     unsigned long long* diag;
@@ -85,6 +91,9 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
 size_t basis_scratch_elems(int kind, int width, int rows, size_t pitch);
 bool basis_fast_path(int kind, int width, const float (*taps)[kMaxTaps]);
 bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], int rows, int cols, size_t max_pitch);
+// true when a.pyr_out (the next pyramid level) is written by the filter launch itself; otherwise launch_basis adds a
+// k_pyr_down launch behind it (same values either way)
+bool basis_fuses_pyr(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a);
 
 // ---- pointwise kernels ("K2..K5") ----
 enum PointOp {

@@ -94,7 +94,8 @@ struct Folded {
     float od[B::NO][B::W];
 };
 
-enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8 };  // F_PIPE implies F_ORIENT; F_NOSTATE: outputs only
+enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8, F_PYR = 16 };  // F_PIPE implies F_ORIENT; F_NOSTATE: outputs only;
+                                                                            // F_PYR: also emit cv::pyrDown(image) (next pyramid level)
 
 // LDS hand-off inside ONE wave: DS ops of a wave execute in issue order, so only the compiler
 // must be kept from moving them across this point.
@@ -279,6 +280,16 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 
     float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
     float pre[NT], preh[NT];  // prefetched input rows (main lane value, halo-lane value)
+    // F_PYR: the last five horizontally blurred rows ([1 4 6 4 1] at this lane's column); even lanes of even centre
+    // rows make one pixel of the next pyramid level each (launch_pyr_down's arithmetic, op for op)
+    [[maybe_unused]] float hw0 = 0.f, hw1 = 0.f, hw2 = 0.f, hw3 = 0.f, hw4 = 0.f;
+    [[maybe_unused]] rsrc_t r_pyr = plane_rsrc(nullptr, 0);
+    [[maybe_unused]] unsigned xpb = kLaneOff, pyr_pitch_b = 0;
+    if constexpr ((FLAGS & F_PYR) != 0) {
+        r_pyr = plane_rsrc(a.pyr_out, (size_t)((a.rows + 1) / 2) * a.pyr_pitch * sizeof(float));
+        pyr_pitch_b = (unsigned)(a.pyr_pitch * sizeof(float));
+        xpb = (xin && (x & 1) == 0) ? (unsigned)(x >> 1) * 4u : kLaneOff;
+    }
 
     const int nrows_in = (yend - y0) + 2 * W;
     const int ngroups = (nrows_in + NT - 1) / NT;
@@ -315,6 +326,18 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             for (int k = 0; k < NT; ++k) s[k] = line[lane + k];
             wave_lds_fence();
 
+            if constexpr ((FLAGS & F_PYR) != 0) {
+                static_assert(W >= 2, "the pyramid level needs two columns / rows of halo");
+                hw0 = hw1; hw1 = hw2; hw2 = hw3; hw3 = hw4;
+                hw4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(s[W], 6.0f), __fmul_rn(__fadd_rn(s[W - 1], s[W + 1]), 4.0f)), s[W - 2]), s[W + 2]);
+                // newest staged row = y0 - W + i (reflected like the image rows themselves); it completes the 5-row window of
+                // centre row c = y0 + i - W - 2.  This strip owns the even centre rows in [y0, yend).
+                const int ci = g * NT + j - W - 2;  // centre row relative to y0, wave-uniform
+                if (ci >= 0 && ci < yend - y0 && ((y0 + ci) & 1) == 0) {
+                    const float v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(hw2, 6.0f), __fmul_rn(__fadd_rn(hw1, hw3), 4.0f)), hw0), hw4);
+                    bst<false>(r_pyr, xpb, (unsigned)((y0 + ci) >> 1) * pyr_pitch_b, __fmul_rn(v, 1.0f / 256.0f));
+                }
+            }
             float sum[W + 1], dif[W + 1];
 #pragma unroll
             for (int i = 1; i <= W; ++i) {
@@ -622,6 +645,16 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     }
     const bool pipe = orient && a.pipe;
     const int flags = pipe ? (F_ORIENT | F_PIPE) : ((orient ? F_ORIENT : 0) | (steer ? F_STEER : 0));
+    if (a.pyr_out) {  // filter this pyramid level and write the next one (launch_basis has checked that the launch qualifies)
+        if constexpr (B::KIND == 2 && B::HALF == 0) {
+            if (banded || pipe || steer) return hipErrorInvalidValue;
+            if (orient) CVS_LAUNCH(F_ORIENT | F_PYR);
+            else CVS_LAUNCH(F_PYR);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if constexpr (B::KIND == 2) {
         switch (flags) {
             case 0: CVS_LAUNCH(0); break;
@@ -748,6 +781,16 @@ static int band_rows(const BasisArgs& a, int width)
     return room >= a.strip_rows ? room / a.strip_rows * a.strip_rows : room;  // very wide rows: one short strip per band
 }
 
+// true when launch_basis can emit the next pyramid level from inside the filter launch (a.pyr_out): the G2 bank at its
+// default width, one un-banded launch over the whole image, no fused steer / pipeline epilogue
+bool basis_fuses_pyr(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a)
+{
+    if (kind != 2 || width != BankG2::W || !basis_fast_path(kind, width, taps)) return false;
+    if (!fast_geometry_ok(a, width) || band_rows(a, width) < a.rows) return false;
+    if (a.out_row_hi > a.out_row_lo || a.frames || a.batch_regular || a.pipe || (a.steer_g && a.steer_h)) return false;
+    return (size_t)((a.rows + 1) / 2) * a.pyr_pitch * sizeof(float) <= kMaxPlaneBytes;
+}
+
 // launch `fn(args)` once per row band, with the plane pointers shifted to the band's first halo row
 template <class F>
 static hipError_t for_each_band(const BasisArgs& a_in, int width, F&& fn)
@@ -788,6 +831,12 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
         b.row_lo = b.row_base = 0;
         b.row_hi = b.rows;
         return launch_fast<BankG2>(b, f, s);
+    }
+    if (a.pyr_out && !basis_fuses_pyr(kind, width, taps, a)) {  // not a launch the fused form covers: two launches, same values
+        BasisArgs b = a;
+        b.pyr_out = nullptr;
+        const hipError_t e = launch_basis(kind, width, taps, b, scratch, s);
+        return e != hipSuccess ? e : launch_pyr_down(a.in, a.in_pitch, a.rows, a.cols, a.pyr_out, a.pyr_pitch, s);
     }
     if (!fast_geometry_ok(a, width) || band_rows(a, width) == 0) return launch_generic(kind, width, taps, a, scratch, s);
     if (kind == 2 && width == BankG2::W) {

@@ -228,6 +228,12 @@ int cvs_num_frames(cvs_handle h, int* n);
  * semantics -- 5-tap [1 4 6 4 1]/16 separable blur, BORDER_REFLECT_101, every second pixel.
  * dst must be ((rows+1)/2) x ((cols+1)/2). */
 int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst);
+/* cvs_setup(h, image, flags) and cvs_pyr_down(h, image, next_level) in ONE pass over the image ("filter this
+ * pyramid level and make the next one", BASELINE config 3): the basis kernel emits the decimated level from
+ * the rows it has staged for SteerableFiltersG2::setup (G2.cpp:62-68) anyway, so the image is read once instead
+ * of twice.  Values are identical to the two separate calls; G4 handles, non-default widths, host planes and
+ * planes of 2 GiB and more take the two launches internally. */
+int cvs_setup_pyr(cvs_handle h, const cvs_plane* image, unsigned flags, const cvs_plane* next_level);
 
 /* per-image min/max (cv::normalize NORM_MINMAX, test.cpp:92-94 / steer.cpp:96-98) and the
  * 8-bit quantise that follows; dst is rows*cols bytes with dst_step bytes per row. */

@@ -436,6 +436,62 @@ def test_pyr_down_matches_oracle(cv, ora, shape):
     assert np.array_equal(got, ora.pyr_down(img))  # same op order, contraction off: bit-identical
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (5, 5), (13, 5), (14, 6), (37, 51), (64, 64), (185, 256), (200, 301), (1080, 1920)])
+@pytest.mark.parametrize("flags", ["basis", "full"])
+def test_setup_pyr_equals_setup_plus_pyr_down(cv, ora, shape, flags):
+    """cvs_setup_pyr: filter this pyramid level and emit the next one in ONE pass (config 3).  The emitted level is
+    bit-identical to cvs_pyr_down / the oracle, the state bit-identical to a plain setup; shapes under the fast
+    path's minimum (13 x 5) and G4 handles take the two launches internally."""
+    img = rand_image(*shape, seed=23)
+    fl = cv.SETUP_BASIS if flags == "basis" else cv.SETUP_FULL
+    want_next = ora.pyr_down(img)
+    for strips in (0, 1, 10, 19, 37):
+        f = cv.SteerableFiltersG2(None)
+        if strips:
+            f.set_strip_rows(strips)
+        got = f.setup_pyr(img, flags=fl)
+        assert got.shape == want_next.shape
+        assert np.array_equal(got, want_next), (shape, strips)
+        ref = cv.SteerableFiltersG2(None)
+        if strips:
+            ref.set_strip_rows(strips)
+        ref.setup(img, flags=fl)
+        for p_ in range(7):
+            assert np.array_equal(f.basis(p_), ref.basis(p_))
+        if flags == "full":
+            assert np.array_equal(f.getDominantOrientationAngle(), ref.getDominantOrientationAngle())
+            assert np.array_equal(f.getDominantOrientationStrength(), ref.getDominantOrientationStrength())
+    f4 = cv.SteerableFiltersG4(None)
+    got4 = f4.setup_pyr(img, flags=cv.SETUP_BASIS)
+    assert np.array_equal(got4, want_next)
+    assert np.abs(np.stack([f4.basis(p_) for p_ in range(11)]) - ora.basis(4, img, 6, 0.5, f64=True)).max() <= TOL
+
+
+def test_setup_pyr_device_planes_and_chain(cv, ora):
+    """device planes, a padded destination pitch, the second call on the same handle, and a chain of fused levels
+    equal to pyramid() level by level"""
+    import torch
+    x = torch.rand((1111, 1503), generator=torch.Generator(device="cuda").manual_seed(5), device="cuda")
+    f = cv.SteerableFiltersG2(None)
+    want = f.pyramid(x, 5)
+    hs = [cv.SteerableFiltersG2(None) for _ in range(5)]
+    lv = [x]
+    for k in range(4):
+        lv.append(hs[k].setup_pyr(lv[k], flags=cv.SETUP_BASIS))
+    hs[4].setup(lv[4], flags=cv.SETUP_BASIS)
+    for a_, b_ in zip(lv, want):
+        assert torch.equal(a_, b_)
+    big = torch.full((556, 800), -7.0, device="cuda")
+    view = big[:, 3:755]   # a padded (and 4-byte-aligned only) destination
+    hs[0].setup_pyr(x, flags=cv.SETUP_BASIS, out=view)
+    assert torch.equal(view, want[1])
+    assert float(big[:, :3].max()) == -7.0 and float(big[:, 755:].max()) == -7.0
+    ref = cv.SteerableFiltersG2(None)
+    ref.setup(x, flags=cv.SETUP_BASIS)
+    for p_ in (0, 4, 6):
+        assert torch.equal(hs[0].basis(p_), ref.basis(p_))
+
+
 def test_pyramid_5_levels_8192(cv, ora):
     """BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image"""
     import torch
