@@ -103,6 +103,7 @@ SIGNATURES.update({
     "cvs_batch_last_error": (C.c_char_p, [C.c_void_p]),
     "cvs_batch_info": (C.c_int, [C.c_void_p, _IP, _IP, _IP]),
     "cvs_batch_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cvs_batch_set_u8_gain": (C.c_int, [C.c_void_p, C.c_float]),
     "cvs_batch_run": (C.c_int, [C.c_void_p, C.POINTER(BatchCfg), _PP, _PP, C.POINTER(BatchTiming)]),
     "cvs_batch_local_result": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(_FP), _IP, _IP, _IP, _IP]),
     "cvs_batch_pyramid_setup": (C.c_int, [C.c_void_p, _PP, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(BatchTiming)]),

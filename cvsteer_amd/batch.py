@@ -216,12 +216,15 @@ class NativeBatch:
             if gather:
                 if out is None:
                     out = _np.empty((n_frames, len(sel), rows, cols), _np.float32)
-                assert isinstance(out, _np.ndarray) and out.dtype == _np.float32 and out.flags.c_contiguous and out.shape == (n_frames, len(sel), rows, cols)
+                # a uint8 `out` asks for the maps as bytes (normalised / converted on the GPUs, cvs_batch_set_u8_gain)
+                assert isinstance(out, _np.ndarray) and out.dtype in (_np.float32, _np.uint8) and out.flags.c_contiguous and out.shape == (n_frames, len(sel), rows, cols)
+                osz = out.dtype.itemsize
                 outs = _np.zeros((n_frames, 8), _PLANE_DTYPE)
-                off = _np.arange(n_frames, dtype=_np.uint64) * _np.uint64(len(sel) * rows * cols * 4)
+                off = _np.arange(n_frames, dtype=_np.uint64) * _np.uint64(len(sel) * rows * cols * osz)
                 for j, k in enumerate(sel):
-                    outs["data"][:, k] = out.ctypes.data + off + _np.uint64(j * rows * cols * 4)
-                    outs["rows"][:, k], outs["cols"][:, k], outs["step"][:, k], outs["mem"][:, k] = rows, cols, cols * 4, _L.MEM_HOST
+                    outs["data"][:, k] = out.ctypes.data + off + _np.uint64(j * rows * cols * osz)
+                    outs["rows"][:, k], outs["cols"][:, k], outs["step"][:, k] = rows, cols, cols * osz
+                    outs["mem"][:, k] = _L.MEM_HOST | (_L.DEPTH_U8 if osz == 1 else 0)
         elif is_root:
             assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and tuple(frames.shape) == (n_frames, rows, cols)
             from .api import _PLANE_DTYPE
@@ -246,9 +249,21 @@ class NativeBatch:
 
     def run_to_u8(self, frames, outputs=(5, 6, 7), gain=0.0, out=None):
         """The flow of example/steer.cpp:69-122 for one batch of equally sized HOST images (numpy [n, H, W], uint8 or
-        float32), every rank local to this process: host planes -> cvs_batch_run with the maps kept on the GPUs ->
-        normalize(0, 255, MINMAX) or convertTo(gain) on each GPU (cvs_*_u8_batch: one launch pair and one sync per rank)
-        -> numpy uint8 [n, len(outputs), H, W].  Only bytes cross the host link on the way back."""
+        float32), every rank local to this process, as ONE native call: host planes up, the caller pipeline, every map
+        normalised (gain = 0: normalize(0, 255, MINMAX)) or converted (convertTo(gain)) on its GPU, bytes down --
+        chunk by chunk, the upload and launches of chunk c+1 overlapping the download of chunk c.
+        -> numpy uint8 [n, len(outputs), H, W]."""
+        n, rows, cols = (int(v) for v in frames.shape)
+        sel = [int(k) for k in outputs]
+        if out is None:
+            out = _np.empty((n, len(sel), rows, cols), _np.uint8)
+        assert isinstance(out, _np.ndarray) and out.dtype == _np.uint8
+        self._check(_L.lib().cvs_batch_set_u8_gain(self._b, float(gain)), "cvs_batch_set_u8_gain")
+        return self.run(frames, n, (rows, cols), outputs=sel, out=out)
+
+    def run_to_u8_two_step(self, frames, outputs=(5, 6, 7), gain=0.0, out=None):
+        """the same result in two steps (round 2's first form, kept as the reference of the one-call flow): cvs_batch_run
+        with the maps kept on the GPUs, then cvs_*_u8_batch on each GPU (one launch pair, one copy, one sync per rank)"""
         n, rows, cols = (int(v) for v in frames.shape)
         sel = [int(k) for k in outputs]
         _, t = self.run(frames, n, (rows, cols), outputs=sel, gather=False)

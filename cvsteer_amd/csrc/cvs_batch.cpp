@@ -116,6 +116,7 @@ struct Slot {
     std::vector<DevBuf> level_img;          // pyramid: levels 1.. (level 0 = the broadcast image)
     ncclComm_t comm = nullptr;
     DevBuf in, out, image;                  // staging: input frames / output planes of this rank's shard; broadcast image
+    DevBuf out8;                            // host 8-bit outputs: the shard's maps as bytes, ready to go down
     int last_n = 0, last_k = 0, last_rows = 0, last_cols = 0;  // layout of `out` after the last cvs_batch_run
     bool last_staged = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -127,6 +128,7 @@ struct Slot {
 struct cvs_batch_context {
     int kind = 0, width = 0, world = 0, transport = TRANSPORT_NONE;
     float spacing = 0.f;
+    float u8_gain = 0.f;      // 8-bit host outputs: 0 = normalize(0, 255, MINMAX) per map, > 0 = convertTo(CV_8U, gain)
     std::vector<Slot> slots;  // local ranks, ascending
     // pyramid state of the last cvs_batch_pyramid_setup
     int pyr_levels = 0, pyr_root = 0;
@@ -303,6 +305,7 @@ struct HostRun {
     const cvs_plane *inputs, *outputs;
     int sel[8], K;
     bool u8;  // 8-bit input frames: bytes cross the link, the engine widens them on the device
+    bool out8;  // 8-bit host output planes: the maps are normalised / converted on the device, bytes come back
 };
 
 int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
@@ -361,6 +364,32 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
                 }
                 hipError_t e = hipStreamWaitEvent(s.down, done_ev[c], 0);
                 if (c == 0 && e == hipSuccess) e = hipEventRecord(t[2], s.down);
+                if (R.out8) {
+                    // bytes: dense planes that lie back to back on the host (the usual [n][K][rows][cols] block) leave as
+                    // ONE linear copy per run -- a pitched 2-D copy of the same bytes runs at a third of the link rate
+                    const uint8_t* dev8 = reinterpret_cast<const uint8_t*>(s.out8.p);
+                    size_t first = (size_t)c0[c] * K, count = 0;
+                    uint8_t* run_dst = nullptr;
+                    auto flush = [&]() {
+                        if (count && e == hipSuccess) e = hipMemcpyAsync(run_dst, dev8 + first * plane, count * plane, hipMemcpyDeviceToHost, s.down);
+                        count = 0;
+                    };
+                    for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i)
+                        for (int j = 0; e == hipSuccess && j < K; ++j) {
+                            const cvs_plane& o = R.outputs[(size_t)(lo + i) * 8 + R.sel[j]];
+                            uint8_t* dst = reinterpret_cast<uint8_t*>(o.data);
+                            const size_t idx = (size_t)i * K + j;
+                            if (o.step != (size_t)cols) {  // padded rows: a 2-D copy of this plane alone
+                                flush();
+                                if (e == hipSuccess) e = hipMemcpy2DAsync(dst, o.step, dev8 + idx * plane, (size_t)cols, (size_t)cols, rows, hipMemcpyDeviceToHost, s.down);
+                                continue;
+                            }
+                            if (count && dst == run_dst + count * plane) { ++count; continue; }
+                            flush();
+                            first = idx; run_dst = dst; count = 1;
+                        }
+                    flush();
+                } else
                 for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i)
                     for (int j = 0; e == hipSuccess && j < K; ++j) {
                         const cvs_plane& o = R.outputs[(size_t)(lo + i) * 8 + R.sel[j]];
@@ -406,6 +435,18 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
         }
         rc = cvs_pipeline_batch(s.h, im.data(), cn, ou.data());
         if (rc != CVS_OK) { err = std::string("cvs_pipeline_batch: ") + cvs_last_error(s.h); break; }
+        if (R.out8) {  // the chunk's maps -> bytes on the device (one min/max + one quantise launch, queued behind the pipeline launch)
+            const size_t m = (size_t)cn * K;
+            std::vector<cvs_plane> src(m);
+            std::vector<uint8_t*> dst(m);
+            for (size_t q = 0; q < m; ++q) {
+                src[q] = cvs_plane{s.out.p + ((size_t)c0[c] * K + q) * plane, rows, cols, rowb, CVS_MEM_DEVICE};
+                dst[q] = reinterpret_cast<uint8_t*>(s.out8.p) + ((size_t)c0[c] * K + q) * plane;
+            }
+            rc = b->u8_gain > 0.f ? cvs_convert_u8_batch(s.h, src.data(), (int)m, b->u8_gain, 0.f, dst.data(), (size_t)cols, CVS_MEM_DEVICE)
+                                  : cvs_normalize_u8_batch(s.h, src.data(), (int)m, dst.data(), (size_t)cols, CVS_MEM_DEVICE);
+            if (rc != CVS_OK) { err = std::string("cvs_*_u8_batch: ") + cvs_last_error(s.h); break; }
+        }
         e = hipEventRecord(done_ev[c], s.stream);
         if (e == hipSuccess) {
             {
@@ -454,11 +495,14 @@ int run_host(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, con
     if ((int)b->slots.size() != b->world)
         return fail(b, CVS_E_UNSUPPORTED, "host planes need every rank in the calling process (each GPU pulls its frames over its own link)");
     const bool u8 = (inputs[0].mem & CVS_DEPTH_U8) != 0;
+    // host outputs may be 8-bit planes too (what the example writes, steer.cpp:92-122): the maps are then normalised /
+    // converted on the device chunk by chunk and only bytes come back, overlapped with the uploads and launches of the next chunk
+    const bool out8 = cfg->gather && outputs && (outputs[sel[0]].mem & CVS_DEPTH_U8) != 0;
     for (int f = 0; f < F; ++f) {
         if (!host_plane(&inputs[f], rows, cols, u8)) return fail(b, CVS_E_SIZE, "input frames must be all host (all f32 or all 8-bit) or all dense device f32 planes of rows x cols");
         for (int j = 0; cfg->gather && j < K; ++j)
-            if (!host_plane(&outputs[(size_t)f * 8 + sel[j]], rows, cols))
-                return fail(b, CVS_E_SIZE, "with host input frames the requested output planes must be host f32 planes of rows x cols");
+            if (!host_plane(&outputs[(size_t)f * 8 + sel[j]], rows, cols, out8))
+                return fail(b, CVS_E_SIZE, "with host input frames the requested output planes must be host planes of rows x cols, all f32 or all 8-bit");
     }
     const size_t plane = (size_t)rows * cols;
     int rc;
@@ -468,8 +512,9 @@ int run_host(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, con
         const size_t n = (size_t)(hi - lo);
         if (n && (rc = reserve(b, s, s.in, n * plane))) return rc;
         if (n && (rc = reserve(b, s, s.out, n * K * plane))) return rc;
+        if (n && out8 && (rc = reserve(b, s, s.out8, (n * K * plane + 3) / 4 + 64))) return rc;
     }
-    HostRun R{b, cfg, inputs, outputs, {0}, K, u8};
+    HostRun R{b, cfg, inputs, outputs, {0}, K, u8, out8};
     for (int j = 0; j < K; ++j) R.sel[j] = sel[j];
     const size_t nl = b->slots.size();
     std::vector<int> rcs(nl, CVS_OK);
@@ -601,7 +646,7 @@ int cvs_batch_destroy(cvs_batch b)
             if (h) (void)cvs_destroy(h);
         for (DevBuf& d : s.level_img)
             if (d.p) (void)hipFree(d.p);
-        for (DevBuf* d : {&s.in, &s.out, &s.image})
+        for (DevBuf* d : {&s.in, &s.out, &s.image, &s.out8})
             if (d->p) (void)hipFree(d->p);
         for (hipEvent_t e : s.ev)
             if (e) (void)hipEventDestroy(e);
@@ -621,6 +666,14 @@ int cvs_batch_info(cvs_batch b, int* world, int* nlocal, int* transport)
     if (world) *world = b->world;
     if (nlocal) *nlocal = (int)b->slots.size();
     if (transport) *transport = b->transport;
+    return CVS_OK;
+}
+
+int cvs_batch_set_u8_gain(cvs_batch b, float gain)
+{
+    if (!b) return CVS_E_BADARG;
+    if (!(gain >= 0.f)) return fail(b, CVS_E_BADARG, "gain");
+    b->u8_gain = gain;
     return CVS_OK;
 }
 

@@ -288,8 +288,15 @@ int cvs_batch_set_option(cvs_batch b, int option, int value);
  * CVS_MEM_HOST; the inputs may be 8-bit (all of them CVS_MEM_HOST | CVS_DEPTH_U8, step in bytes: a quarter of the upload).  Nothing passes through the root's GPU then -- every rank uploads ITS frames from the caller's planes over
  * its own host link and downloads its outputs the same way, all ranks at once, upload / launch / download overlapped
  * chunk by chunk inside a rank.  Needs every rank in the calling process (cvs_batch_create_local, or a world of 1);
- * CVS_E_UNSUPPORTED otherwise.  timing: scatter = upload, gather = download, compute = the slowest rank's whole span. */
+ * CVS_E_UNSUPPORTED otherwise.  timing: scatter = upload, gather = download, compute = the slowest rank's whole span.
+ * The requested HOST outputs may be 8-bit planes as well (all of them CVS_MEM_HOST | CVS_DEPTH_U8, step in bytes) -- what the
+ * example writes (steer.cpp:92-122): every map is then turned into bytes on the device, normalize(0, 255, NORM_MINMAX,
+ * CV_8UC1) per map (steer.cpp:98-104) or convertTo(CV_8UC1, gain) (steer.cpp:92-97) as set by cvs_batch_set_u8_gain, chunk by
+ * chunk behind the pipeline launch, and only bytes come back while the next chunk is uploaded and filtered. */
 int cvs_batch_run(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs, const cvs_plane* outputs, cvs_batch_timing* timing);
+/* 8-bit host outputs of cvs_batch_run: gain = 0 (default) normalises every map to its own min / max (the example without
+ * --gain, steer.cpp:98-104), gain > 0 is Mat::convertTo(CV_8UC1, gain) (steer.cpp:92-97) */
+int cvs_batch_set_u8_gain(cvs_batch b, float gain);
 /* after a run with gather = 0 (or on a non-root rank): this rank's block, [n_frames][n_planes][rows][cols] dense */
 int cvs_batch_local_result(cvs_batch b, int rank, float** data, int* n_frames, int* n_planes, int* rows, int* cols);
 /* BASELINE config 3 -- one large image and its Gaussian pyramid split over the ranks by rows: ncclBroadcast of the

@@ -206,6 +206,16 @@ def test_byte_frames_from_host_and_the_whole_driver_flow(cv, world):
     q2, _ = nb.run_to_u8(u8.astype(np.float32), gain=3.0)
     want2 = torch.stack([torch.stack([eng.convert_u8(ref[i, j], 3.0) for j in range(3)]) for i in range(n)]).cpu().numpy()
     assert np.array_equal(q2, want2)
+    # the one-call flow (8-bit host output planes of cvs_batch_run, chunks overlapped) == the two-step flow, with the
+    # state kept (one chunk) and without, and for a single requested map
+    for persist in (False, True):
+        nb.set_persist(persist)
+        a1, _ = nb.run_to_u8(u8)
+        a2, _ = nb.run_to_u8_two_step(u8)
+        assert np.array_equal(a1, want) and np.array_equal(a2, want)
+        b1, _ = nb.run_to_u8(u8, outputs=(6,), gain=1.5)
+        b2, _ = nb.run_to_u8_two_step(u8, outputs=(6,), gain=1.5)
+        assert np.array_equal(b1, b2)
     nb.close()
 
 
