@@ -8,8 +8,8 @@
 // via normalize(0, 255, MINMAX) or convertTo(gain) -> <base>_edges, <base>_lines_dark, <base>_lines_bright.
 // Where the reference runs cv::parallel_for_ over the files (steer.cpp:169), this driver hands runs of equally sized
 // images to cvs_batch_run as HOST planes: every GPU uploads its own block of frames over its own link, filters it in
-// one fused launch, keeps the three feature maps on the device, and only their 8-bit versions (cvs_normalize_u8 /
-// cvs_convert_u8, on the GPU) come back -- 1 byte per pixel and map instead of 4.
+// one fused launch per chunk, turns the three feature maps into bytes on the device (8-bit host output planes of
+// cvs_batch_run), and only those come back -- 1 byte per pixel and map instead of 4 -- while the next chunk goes up.
 // OpenCV's imgcodecs are not available: inputs are binary PGM (P5, maxval <= 255) or .npy (2-D, |u1 or <f4, C order),
 // outputs PGM or .npy.  Differences from the reference, on purpose: --gain is honoured (steer.cpp:167-168 passes
 // `verbose` as the gain); single-channel inputs work (steer.cpp:79-82 leaves `gray` empty for them); unreadable files
@@ -216,15 +216,12 @@ int main(int argc, char** argv)
     if (input.empty() || output.empty() || gpus < 1) { std::fprintf(stderr, "cvsteer-run: --input and --output are required\n"); return 2; }
     int failures = 0;
     cvs_batch batch = nullptr;
-    std::vector<cvs_handle> conv;  // one plain handle per device for the 8-bit conversion
     try {
         const std::vector<std::string> files = input_list(input);
         std::vector<int> devices(gpus);
         for (int d = 0; d < gpus; ++d) devices[d] = device_list.empty() ? d : device_list[d];
         check(cvs_batch_create_local(CVS_KIND_G2, 4, 0.67f, gpus, devices.data(), &batch), "cvs_batch_create_local", cvs_batch_last_error(batch));
         check(cvs_batch_set_option(batch, CVS_OPT_PERSIST_STATE, 0), "cvs_batch_set_option", cvs_batch_last_error(batch));  // only the three maps are kept
-        conv.resize(gpus, nullptr);
-        for (int d = 0; d < gpus; ++d) check(cvs_create(CVS_KIND_G2, 4, 0.67f, devices[d], &conv[d]), "cvs_create", "");
 
         size_t next = 0;
         while (next < files.size()) {
@@ -257,42 +254,24 @@ int main(int argc, char** argv)
             cfg.n_frames = n;
             cfg.outputs = (1u << 5) | (1u << 6) | (1u << 7);  // edges, dark lines, bright lines
             cfg.root = 0;
-            cfg.gather = 0;  // the maps stay on the GPUs: only their 8-bit versions are downloaded
-            cvs_batch_timing t;
-            check(cvs_batch_run(batch, &cfg, in.data(), nullptr, &t), "cvs_batch_run", cvs_batch_last_error(batch));
-            if (verbose) std::printf("batch of %d x %dx%d: upload %.2f ms, span %.2f ms\n", n, rows, cols, t.scatter_ms, t.compute_ms);
-            static const char* suffix[3] = {"_edges", "_lines_dark", "_lines_bright"};
-            // every rank's block of maps -> 8 bits on its GPU (one min/max launch, one quantise launch, one sync for the
-            // whole block) -> host; the ranks work side by side, each over its own link
+            cfg.gather = 1;
+            // 8-bit HOST output planes: every GPU turns its maps into bytes itself -- normalize(0, 255, MINMAX) per map
+            // (steer.cpp:98-104) or convertTo(gain) (steer.cpp:92-97) -- and only bytes come back, chunk by chunk, while
+            // the next chunk of frames is uploaded and filtered (cvs_batch_run on host planes; every rank over its own link)
             const size_t plane = (size_t)rows * cols;
             std::vector<uint8_t> u8((size_t)n * 3 * plane);
-            std::vector<int> first(gpus + 1, 0), rcs(gpus, CVS_OK);
-            std::vector<float*> blocks(gpus, nullptr);
-            std::vector<int> counts(gpus, 0);
-            for (int r = 0; r < gpus; ++r) {
-                int np = 0, br = 0, bc = 0;
-                check(cvs_batch_local_result(batch, r, &blocks[r], &counts[r], &np, &br, &bc), "cvs_batch_local_result", cvs_batch_last_error(batch));
-                if (counts[r] && np != 3) throw std::runtime_error("internal: expected 3 maps per frame");
-                first[r + 1] = first[r] + counts[r];
-            }
-            int frame = first[gpus];
-            auto convert = [&](int r) {
-                const int m = counts[r] * 3;
-                if (!m) return;
-                std::vector<cvs_plane> maps(m);
-                std::vector<uint8_t*> dst(m);
-                for (int i = 0; i < m; ++i) {
-                    maps[i] = cvs_plane{blocks[r] + (size_t)i * plane, rows, cols, (size_t)cols * sizeof(float), CVS_MEM_DEVICE};
-                    dst[i] = u8.data() + ((size_t)first[r] * 3 + i) * plane;
-                }
-                rcs[r] = gain > 0.f ? cvs_convert_u8_batch(conv[r], maps.data(), m, gain, 0.f, dst.data(), (size_t)cols, CVS_MEM_HOST)
-                                    : cvs_normalize_u8_batch(conv[r], maps.data(), m, dst.data(), (size_t)cols, CVS_MEM_HOST);
-            };
-            std::vector<std::thread> workers;
-            for (int r = 1; r < gpus; ++r) workers.emplace_back(convert, r);
-            convert(0);
-            for (std::thread& w : workers) w.join();
-            for (int r = 0; r < gpus; ++r) check(rcs[r], "cvs_*_u8_batch", cvs_last_error(conv[r]));
+            std::vector<cvs_plane> outp((size_t)n * 8);
+            std::memset(outp.data(), 0, outp.size() * sizeof(cvs_plane));
+            for (int f = 0; f < n; ++f)
+                for (int j = 0; j < 3; ++j)
+                    outp[(size_t)f * 8 + 5 + j] = cvs_plane{reinterpret_cast<float*>(u8.data() + ((size_t)f * 3 + j) * plane), rows, cols, (size_t)cols,
+                                                            CVS_MEM_HOST | CVS_DEPTH_U8};
+            check(cvs_batch_set_u8_gain(batch, gain > 0.f ? gain : 0.f), "cvs_batch_set_u8_gain", cvs_batch_last_error(batch));
+            cvs_batch_timing t;
+            check(cvs_batch_run(batch, &cfg, in.data(), outp.data(), &t), "cvs_batch_run", cvs_batch_last_error(batch));
+            if (verbose) std::printf("batch of %d x %dx%d: upload %.2f ms, download %.2f ms, span %.2f ms\n", n, rows, cols, t.scatter_ms, t.gather_ms, t.compute_ms);
+            static const char* suffix[3] = {"_edges", "_lines_dark", "_lines_bright"};
+            const int frame = n;
             std::vector<uint8_t> one(plane);
             for (int f = 0; f < frame; ++f)
                 for (int j = 0; j < 3; ++j) {
@@ -301,14 +280,11 @@ int main(int argc, char** argv)
                     write_u8(dst, one, rows, cols);
                     if (verbose) std::printf("%s\n", dst.c_str());
                 }
-            if (frame != n) throw std::runtime_error("internal: the ranks returned " + std::to_string(frame) + " frames of " + std::to_string(n));
         }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "cvsteer-run: %s\n", e.what());
         failures = failures ? failures : 1;
     }
-    for (cvs_handle h : conv)
-        if (h) cvs_destroy(h);
     if (batch) cvs_batch_destroy(batch);
     return failures ? 1 : 0;
 }
