@@ -389,12 +389,29 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
                             first = idx; run_dst = dst; count = 1;
                         }
                     flush();
-                } else
-                for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i)
-                    for (int j = 0; e == hipSuccess && j < K; ++j) {
-                        const cvs_plane& o = R.outputs[(size_t)(lo + i) * 8 + R.sel[j]];
-                        e = hipMemcpy2DAsync(o.data, o.step, s.out.p + ((size_t)i * K + j) * plane, rowb, rowb, rows, hipMemcpyDeviceToHost, s.down);
-                    }
+                } else {
+                    // f32 planes: the same -- dense planes that lie back to back leave as one linear copy per run
+                    size_t first = (size_t)c0[c] * K, count = 0;
+                    float* run_dst = nullptr;
+                    auto flush = [&]() {
+                        if (count && e == hipSuccess) e = hipMemcpyAsync(run_dst, s.out.p + first * plane, count * plane * sizeof(float), hipMemcpyDeviceToHost, s.down);
+                        count = 0;
+                    };
+                    for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i)
+                        for (int j = 0; e == hipSuccess && j < K; ++j) {
+                            const cvs_plane& o = R.outputs[(size_t)(lo + i) * 8 + R.sel[j]];
+                            const size_t idx = (size_t)i * K + j;
+                            if (o.step != rowb) {
+                                flush();
+                                if (e == hipSuccess) e = hipMemcpy2DAsync(o.data, o.step, s.out.p + idx * plane, rowb, rowb, rows, hipMemcpyDeviceToHost, s.down);
+                                continue;
+                            }
+                            if (count && o.data == run_dst + count * plane) { ++count; continue; }
+                            flush();
+                            first = idx; run_dst = o.data; count = 1;
+                        }
+                    flush();
+                }
                 if (e != hipSuccess) { drc = CVS_E_HIP; derr = std::string("download: ") + hipGetErrorString(e); return; }
             }
             hipError_t e = hipEventRecord(t[3], s.down);
@@ -415,10 +432,29 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
     int rc = CVS_OK;
     hipError_t e = hipEventRecord(t[0], s.up);
     for (int c = 0; c < nchunks && e == hipSuccess && rc == CVS_OK; ++c) {
-        for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i) {
-            const cvs_plane& im = R.inputs[lo + i];
-            if (R.u8) e = hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(s.in.p) + (size_t)i * plane, (size_t)cols, im.data, im.step, (size_t)cols, rows, hipMemcpyHostToDevice, s.up);
-            else e = hipMemcpy2DAsync(s.in.p + (size_t)i * plane, rowb, im.data, im.step, rowb, rows, hipMemcpyHostToDevice, s.up);
+        {
+            // dense frames that lie back to back on the host (one [n][rows][cols] block) go up as one linear copy per run
+            const size_t esz = R.u8 ? 1 : sizeof(float), frame_b = plane * esz;
+            uint8_t* dev = reinterpret_cast<uint8_t*>(s.in.p);
+            int first = c0[c], count = 0;
+            const uint8_t* run_src = nullptr;
+            auto flush = [&]() {
+                if (count && e == hipSuccess) e = hipMemcpyAsync(dev + (size_t)first * frame_b, run_src, (size_t)count * frame_b, hipMemcpyHostToDevice, s.up);
+                count = 0;
+            };
+            for (int i = c0[c]; e == hipSuccess && i < c0[c + 1]; ++i) {
+                const cvs_plane& im = R.inputs[lo + i];
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(im.data);
+                if (im.step != (size_t)cols * esz) {
+                    flush();
+                    if (e == hipSuccess) e = hipMemcpy2DAsync(dev + (size_t)i * frame_b, (size_t)cols * esz, im.data, im.step, (size_t)cols * esz, rows, hipMemcpyHostToDevice, s.up);
+                    continue;
+                }
+                if (count && src == run_src + (size_t)count * frame_b) { ++count; continue; }
+                flush();
+                first = i; run_src = src; count = 1;
+            }
+            flush();
         }
         if (e == hipSuccess) e = hipEventRecord(up_ev[c], s.up);
         if (e == hipSuccess && c == nchunks - 1) e = hipEventRecord(t[1], s.up);
