@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (M1/M4/M5/G4/C3/C4)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--strip-rows", type=int, default=0)
+    ap.add_argument("--extra-timeout", type=int, default=900, help="seconds the secondary legs may take before every rank gives up on them (0 = no watchdog)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -261,8 +262,40 @@ def main():
     }
 
     # ---- secondary legs (reported, not the headline) ----
+    # Insurance for runs with several ranks: the secondary legs contain collectives (barriers, the RCCL scatter / gather
+    # of `C4_e2e`) that have only ever run on one GPU here.  If a rank fails inside a leg, the others would wait in a
+    # collective for ever and the headline measured above would be lost with them.  A watchdog armed for the secondary
+    # legs makes every rank leave after `--extra-timeout` seconds: rank 0 prints the JSON line with the headline, the
+    # legs finished so far and an `extra_error` note, and all ranks exit with status 0.
+    import threading
+    extra = {}
+    done_flag = {"printed": False}
+    lock = threading.Lock()
+
+    def emit(final):
+        with lock:
+            if done_flag["printed"]:
+                return
+            done_flag["printed"] = True
+            if rank == 0:
+                if not args.no_extra:
+                    out["extra"] = dict(extra)
+                if not final:
+                    out["extra_error"] = "secondary legs did not finish within %d s (watchdog); headline unaffected" % args.extra_timeout
+                    out.setdefault("cpu_baseline", None)
+                sys.stdout.flush()
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    def watchdog():
+        emit(False)
+        os._exit(0)
+
+    timer = None
+    if not args.no_extra and args.extra_timeout > 0:
+        timer = threading.Timer(args.extra_timeout, watchdog)
+        timer.daemon = True
+        timer.start()
     if not args.no_extra:
-        extra = {}
         ksteps, kwarm = args.steps, max(10, args.warmup // 2)
         WARM_NEW = 6   # a new handle / new shape: first call + the one tuning call happen in here
 
@@ -588,16 +621,15 @@ def main():
                                                 "note": "whole = build + filter, level k+1 written by the filter launch of level k, two alternating images; "
                                                         "filter = five filter launches on a prebuilt pyramid; separate build + filter = filter_ms + pyramid_build_ms"}
             del bigs, lv, hp, fp3
-        out["extra"] = extra
+    if timer is not None:
+        timer.cancel()
 
     if rank == 0 and ws == 1 and not args.no_cpu:
         out["cpu_baseline"] = _cpu_baseline(THETA)
     elif rank == 0:
         out["cpu_baseline"] = None
 
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    emit(True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
