@@ -492,6 +492,26 @@ def test_setup_pyr_device_planes_and_chain(cv, ora):
         assert torch.equal(hs[0].basis(p_), ref.basis(p_))
 
 
+@pytest.mark.parametrize("n", [4096, 7000])
+def test_setup_pyr_streaming_and_per_plane_variants(cv, n):
+    """the fused level on images large enough for nontemporal stores (4096^2) and for one buffer resource per state
+    plane (7000^2: the 12-plane state block passes 2 GiB): next level == cvs_pyr_down, state == plain setup, bit for bit"""
+    import torch
+    x = torch.rand((n, n), generator=torch.Generator(device="cuda").manual_seed(n), device="cuda")
+    f = cv.SteerableFiltersG2(None)
+    want = f.pyrDown(x)
+    g = cv.SteerableFiltersG2(None)
+    got = g.setup_pyr(x, flags=cv.SETUP_FULL)
+    assert torch.equal(got, want)
+    ref = cv.SteerableFiltersG2(None)
+    ref.setup(x, flags=cv.SETUP_FULL)
+    for p_ in (0, 3, 6):
+        assert torch.equal(g.basis(p_), ref.basis(p_))
+    assert torch.equal(g.getDominantOrientationAngle(), ref.getDominantOrientationAngle())
+    got2 = g.setup_pyr(x, flags=cv.SETUP_BASIS)       # the same image again: the taller strips of a resident image
+    assert torch.equal(got2, want)
+
+
 def test_pyramid_5_levels_8192(cv, ora):
     """BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image"""
     import torch
