@@ -238,6 +238,38 @@ def test_host_planes_mixed_with_device_planes_rejected(cv):
     lib.cvs_batch_destroy(h)
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_byte_output_planes_padded_and_mixed_rejected(cv, world):
+    """cvs_batch_run with 8-bit HOST output planes through the C ABI: padded rows (step > cols) and planes that do not lie
+    back to back take the per-plane copies and give the same bytes; f32 and 8-bit output planes in one call are refused"""
+    import ctypes as C
+    import torch
+    from cvsteer_amd import _lib as L
+    from cvsteer_amd import batch
+    n, rows, cols = 5, 61, 130
+    u8 = np.random.default_rng(3).integers(0, 256, (n, rows, cols), dtype=np.uint8)
+    nb = batch.NativeBatch.local((0,) * world)
+    nb.set_persist(False)
+    want, _ = nb.run_to_u8(u8)                      # dense [n][3][rows][cols] block: linear copies
+    lib = L.lib()
+    pad = np.full((n, 3, rows, cols + 14), 7, np.uint8)
+    ins = (L.Plane * n)(*[L.Plane(u8[i].ctypes.data, rows, cols, cols, L.MEM_HOST | L.DEPTH_U8) for i in range(n)])
+    outs = (L.Plane * (8 * n))()
+    for i in range(n):
+        for j, k in enumerate((5, 6, 7)):
+            outs[i * 8 + k] = L.Plane(pad[i, j].ctypes.data, rows, cols, cols + 14, L.MEM_HOST | L.DEPTH_U8)
+    cfg = L.BatchCfg(rows, cols, n, (1 << 5) | (1 << 6) | (1 << 7), 0, 1, 0)
+    assert lib.cvs_batch_set_u8_gain(nb._b, C.c_float(0.0)) == 0
+    assert lib.cvs_batch_run(nb._b, C.byref(cfg), ins, outs, None) == 0, lib.cvs_batch_last_error(nb._b)
+    assert np.array_equal(pad[..., :cols], want) and (pad[..., cols:] == 7).all()
+    # one f32 plane among the 8-bit ones
+    f32 = np.zeros((rows, cols), np.float32)
+    outs[6] = L.Plane(f32.ctypes.data, rows, cols, cols * 4, L.MEM_HOST)
+    assert lib.cvs_batch_run(nb._b, C.byref(cfg), ins, outs, None) == L.E_SIZE
+    assert lib.cvs_batch_set_u8_gain(nb._b, C.c_float(-1.0)) == L.E_BADARG
+    nb.close()
+
+
 def test_batch_argument_errors(cv):
     import torch
     from cvsteer_amd import batch
