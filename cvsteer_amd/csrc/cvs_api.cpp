@@ -870,6 +870,7 @@ int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map
     PointOp op = h->kind == CVS_KIND_G2 ? (map ? OP_G2_STEER_MAP : OP_G2_STEER_SCALAR)
                                         : (map ? OP_G4_STEER_MAP : OP_G4_STEER_SCALAR);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
+    a.nt_loads = a.nt_stores;  // the state planes of an image that large are not cache-resident and are read once here
     HIP_TRY(h, launch_point(op, a, h->stream));
     return finish(c);
 }

@@ -124,6 +124,7 @@ struct PointArgs {
     int atan_mode;
     int find_on_e;        // pipeline: 1 = find*(e, phase), 0 = find*(magnitude, phase)
     int nt_stores;        // 1 = nontemporal (streaming) output stores
+    int nt_loads;         // 1 = nontemporal input loads (steer stages on the state planes of a large image)
 };
 
 hipError_t launch_point(PointOp op, const PointArgs& a, hipStream_t s);

@@ -99,7 +99,10 @@ __device__ __forceinline__ void point_eval(const float* in, float* out, const Po
 
 // VEC = 4: rows are walked in float4 units (host guarantees 16-B aligned pointers/pitches and
 // cols % 4 == 0); VEC = 1: plain dwords.  blockIdx.y strides rows, x threads stride columns.
-template <PointOp OP, int VEC, bool NT>
+// NTL: the inputs are state planes of a large image that a pass long ago wrote and nobody reads again soon: nontemporal
+// loads keep them from displacing what the caches hold (steer-by-map 67.5 -> 70.8 %, scalar steer 70.6 -> 71.8 % at 4096^2,
+// tools/ab_m3.py).  Not for stages whose inputs the kernel before has just written (magnitude / phase, find*: 86 -> 75 %).
+template <PointOp OP, int VEC, bool NT, bool NTL = false>
 __global__ __launch_bounds__(256) void k_point(const PointArgs a)
 {
     constexpr int NIN = OpShape<OP>::NIN, NOUT = OpShape<OP>::NOUT;
@@ -118,7 +121,10 @@ __global__ __launch_bounds__(256) void k_point(const PointArgs a)
                 if (a.in[i].p) {
                     const float* src = a.in[i].p + (size_t)row * a.in[i].pitch + (size_t)cv * VEC;
                     if constexpr (VEC == 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(src);
+                        typedef float f4l __attribute__((ext_vector_type(4)));
+                        f4l v;
+                        if constexpr (NTL) v = __builtin_nontemporal_load(reinterpret_cast<const f4l*>(src));
+                        else v = *reinterpret_cast<const f4l*>(src);
                         vin[i][0] = v.x; vin[i][1] = v.y; vin[i][2] = v.z; vin[i][3] = v.w;
                     } else {
                         vin[i][0] = *src;
@@ -186,6 +192,13 @@ static hipError_t launch_op(const PointArgs& a, hipStream_t s)
     const int cap = 256 * (kHeavy ? 64 : 16);
     if ((long)gx * gy > cap) gy = cap / gx > 0 ? cap / gx : 1;
     dim3 grid(gx, gy);
+    constexpr bool kStateIn = OP == OP_G2_STEER_SCALAR || OP == OP_G2_STEER_MAP || OP == OP_G4_STEER_SCALAR || OP == OP_G4_STEER_MAP;
+    if constexpr (kStateIn) {
+        if (v4 && a.nt_stores && a.nt_loads) {
+            hipLaunchKernelGGL((k_point<OP, 4, true, true>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
+    }
     if (v4 && a.nt_stores) hipLaunchKernelGGL((k_point<OP, 4, true>), grid, block, 0, s, a);
     else if (v4) hipLaunchKernelGGL((k_point<OP, 4, false>), grid, block, 0, s, a);
     else if (a.nt_stores) hipLaunchKernelGGL((k_point<OP, 1, true>), grid, block, 0, s, a);
