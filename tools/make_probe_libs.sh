@@ -11,6 +11,7 @@
 #   AUX<n>   streaming stores issued with cache-policy bits n instead of 2 (nt): 3 = nt sc0, 18 = nt sc1, 19 = nt sc0 sc1, 16 = sc1, 17 = sc0 sc1
 #   XVALU / XSALU   12 extra independent v_mov / s_mov per row and wave
 #   PW1     pipeline epilogue with ONE cos/sin evaluation for the three phase weights and none for 2*theta (prices those evaluations)
+#   LDAUX<n> input loads issued with cache-policy bits n (2 = nt, 1 = sc0, 3 = nt sc0, 16 = sc1, 18 = nt sc1)
 #   PAIRW<n> the G4 pair kernel compiled for n waves per SIMD (register budget 512/n)
 #   ILP     same source, machine scheduler strategy max-ilp (independent accumulation chains interleaved)
 set -eu
@@ -41,6 +42,7 @@ for v in "$@"; do
     XSALU)   build $v 's|^            // ---- column pass on the window; newest row is slot j, centre is W rows back ----$|            { int dmy; asm volatile("s_mov_b32 %0, 1\\ns_mov_b32 %0, 2\\ns_mov_b32 %0, 1\\ns_mov_b32 %0, 2\\ns_mov_b32 %0, 1\\ns_mov_b32 %0, 2\\ns_mov_b32 %0, 1\\ns_mov_b32 %0, 2\\ns_mov_b32 %0, 1\\ns_mov_b32 %0, 2\\ns_mov_b32 %0, 1\\ns_mov_b32 %0, 2" : "=s"(dmy)); }|' ;;
     ILP)     build $v 's/^$//' "-mllvm -amdgpu-sched-strategy=max-ilp" ;;
     PW1)     build $v 's/q\[6\] = __fmul_rn(en, phase_lambda<true>(q\[4\], 0.f, true));/q[6] = __fmul_rn(en, q[5]);/; s/q\[7\] = __fmul_rn(en, phase_lambda<true>(q\[4\], kPiF, true));/q[7] = __fmul_rn(q[5], q[6]);/; s/sincos_small(__fmul_rn(th, 2.0f), s2, cc2);/s2 = th * c2; cc2 = th * c3;/' ;;
+    LDAUX*)  build $v "s/__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0)/__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, ${v#LDAUX})/" ;;
     PAIRW*)  build $v "s/__global__ __launch_bounds__(256) void k_basis_pair/__global__ __launch_bounds__(256, ${v#PAIRW}) void k_basis_pair/" ;;
     *) echo "unknown probe $v"; exit 2 ;;
   esac
