@@ -68,6 +68,15 @@ struct cvs_context {
     std::string err;
 };
 
+// rows that are dense on both sides travel as ONE linear copy: over the host link a pitched 2-D copy of the same bytes
+// is served row by row and reaches a fraction of the rate (tools/d2h_probe.hip, tools/bytes_probe.py)
+static inline hipError_t copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
+                                   hipMemcpyKind kind, hipStream_t stream)
+{
+    if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * rows, kind, stream);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, stream);
+}
+
 namespace {
 
 int fail(cvs_handle h, int code, const char* what)
@@ -182,7 +191,7 @@ int in_ref(Call& c, const cvs_plane* p, PlaneRef& r)
                 r = {d, pitch};
                 return CVS_OK;
             }
-            HIP_TRY(h, hipMemcpy2DAsync(b, bpitch, p->data, p->step, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, copy_rows(b, bpitch, p->data, p->step, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, h->stream));
             c.touched_host = true;
             src = b;
             sstep = bpitch;
@@ -202,7 +211,7 @@ int in_ref(Call& c, const cvs_plane* p, PlaneRef& r)
         r = {d, pitch};
         return CVS_OK;
     }
-    HIP_TRY(h, hipMemcpy2DAsync(d, pitch * sizeof(float), p->data, p->step, (size_t)p->cols * sizeof(float), p->rows,
+    HIP_TRY(h, copy_rows(d, pitch * sizeof(float), p->data, p->step, (size_t)p->cols * sizeof(float), p->rows,
                                 hipMemcpyHostToDevice, h->stream));
     c.touched_host = true;
     r = {d, pitch};
@@ -232,7 +241,7 @@ int finish(Call& c)
 {
     cvs_handle h = c.h;
     for (const Pending& o : c.outs) {
-        HIP_TRY(h, hipMemcpy2DAsync(o.host->data, o.host->step, o.dev, o.pitch * sizeof(float),
+        HIP_TRY(h, copy_rows(o.host->data, o.host->step, o.dev, o.pitch * sizeof(float),
                                     (size_t)o.host->cols * sizeof(float), o.host->rows, hipMemcpyDeviceToHost, h->stream));
         c.touched_host = true;
     }
@@ -614,7 +623,7 @@ int host_pipeline(cvs_handle h, Call& c, BasisArgs& a, float* scr)
                                            (size_t)(hi - lo) * o.host->step, hipMemcpyDeviceToHost, s_down);
                         continue;
                     }
-                    e = hipMemcpy2DAsync(reinterpret_cast<char*>(o.host->data) + (size_t)lo * o.host->step, o.host->step, o.dev + (size_t)lo * o.pitch,
+                    e = copy_rows(reinterpret_cast<char*>(o.host->data) + (size_t)lo * o.host->step, o.host->step, o.dev + (size_t)lo * o.pitch,
                                          o.pitch * sizeof(float), (size_t)o.host->cols * sizeof(float), hi - lo, hipMemcpyDeviceToHost, s_down);
                 }
             }
@@ -640,14 +649,14 @@ int host_pipeline(cvs_handle h, Call& c, BasisArgs& a, float* scr)
             if (need > up_to) {
                 hipError_t e;
                 if (c.deferred_u8) {
-                    e = hipMemcpy2DAsync(c.deferred_u8 + (size_t)up_to * c.deferred_u8_pitch, c.deferred_u8_pitch,
+                    e = copy_rows(c.deferred_u8 + (size_t)up_to * c.deferred_u8_pitch, c.deferred_u8_pitch,
                                          reinterpret_cast<const char*>(img->data) + (size_t)up_to * img->step, img->step, (size_t)img->cols, need - up_to,
                                          hipMemcpyHostToDevice, h->s_up);
                     if (e == hipSuccess)
                         e = launch_u8_to_f32(c.deferred_u8 + (size_t)up_to * c.deferred_u8_pitch, c.deferred_u8_pitch, need - up_to, img->cols,
                                              const_cast<float*>(a.in) + (size_t)up_to * a.in_pitch, a.in_pitch, h->s_up);
                 } else {
-                    e = hipMemcpy2DAsync(const_cast<float*>(a.in) + (size_t)up_to * a.in_pitch, a.in_pitch * sizeof(float),
+                    e = copy_rows(const_cast<float*>(a.in) + (size_t)up_to * a.in_pitch, a.in_pitch * sizeof(float),
                                          reinterpret_cast<const char*>(img->data) + (size_t)up_to * img->step, img->step, (size_t)img->cols * sizeof(float),
                                          need - up_to, hipMemcpyHostToDevice, h->s_up);
                 }
@@ -1160,7 +1169,7 @@ int cvs_read_state(cvs_handle h, int which, const cvs_plane* dst)
     if (rc) return rc;
     if ((rc = check_plane(h, dst, "dst")) || (rc = check_same(h, dst, h->rows, h->cols))) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpy2DAsync(dst->data, dst->step, src.data, src.step, (size_t)h->cols * sizeof(float), h->rows,
+    HIP_TRY(h, copy_rows(dst->data, dst->step, src.data, src.step, (size_t)h->cols * sizeof(float), h->rows,
                                 dst->mem == CVS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
     if (dst->mem == CVS_MEM_HOST) HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CVS_OK;
@@ -1540,7 +1549,7 @@ static int to_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_st
         HIP_TRY(h, launch_convert_u8(in.p, in.pitch, src->rows, src->cols, alpha, beta, d, dstep, h->stream));
     }
     if (dst_mem == CVS_MEM_DEVICE) return finish(c);
-    HIP_TRY(h, hipMemcpy2DAsync(dst, dst_step, d, dstep, (size_t)src->cols, src->rows, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, copy_rows(dst, dst_step, d, dstep, (size_t)src->cols, src->rows, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CVS_OK;
 }
@@ -1590,7 +1599,7 @@ static int to_u8_batch(cvs_handle h, const cvs_plane* src, int n, uint8_t* const
             HIP_TRY(h, hipMemcpyAsync(dst[0], stage, plane_b * n, hipMemcpyDeviceToHost, h->stream));
         } else {
             for (int i = 0; i < n; ++i)
-                HIP_TRY(h, hipMemcpy2DAsync(dst[i], dst_step, stage + (size_t)i * plane_b, dpitch, (size_t)cols, rows, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(h, copy_rows(dst[i], dst_step, stage + (size_t)i * plane_b, dpitch, (size_t)cols, rows, hipMemcpyDeviceToHost, h->stream));
         }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return CVS_OK;
