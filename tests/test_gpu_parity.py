@@ -396,6 +396,45 @@ def test_full_size_4096_properties(cv, ora):
     assert float((h - (w[3] * bx[3] + w[4] * bx[4] + w[5] * bx[5] + w[6] * bx[6])).abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("kind,shape", [(2, (4096, 4096)), (4, (4096, 4096)), (2, (1531, 2049)), (4, (1080, 1920))])
+def test_mirror_and_transpose_properties_full_size(cv, kind, shape):
+    """oracle-independent, size-independent properties of the separable banks at BASELINE sizes (configs 2, 4, 5):
+    (1) mirroring the image mirrors every basis plane, with a sign flip where the 1-D kernel along that axis is odd --
+        BIT-exact: the folded sums s[+i] + s[-i] commute, the differences change sign, REFLECT_101 is symmetric;
+    (2) transposing the image swaps the roles of the row and column kernels: plane (kx, ky) of the transposed image is the
+        transpose of plane (ky, kx) -- g2a <-> g2c, h2a <-> h2d, h2b <-> h2c; g4a <-> g4e, g4b <-> g4d, h4a <-> h4f, h4b <-> h4e,
+        h4c <-> h4d -- to rounding (the two passes run in the other order), which pins the pairing of kernels and planes of
+        G4 / H4, to which the reference's golden images are blind."""
+    import torch
+    rows, cols = shape
+    nb = 7 if kind == 2 else 11
+    w, sp = (4, 0.67) if kind == 2 else (6, 0.5)
+    cls = cv.SteerableFiltersG2 if kind == 2 else cv.SteerableFiltersG4
+    x = torch.rand(shape, generator=torch.Generator(device="cuda").manual_seed(77 + kind), device="cuda")
+    flags = cv.SETUP_BASIS
+    f = cls(x, w, sp, setup_flags=flags)
+    base = [f.basis(p).clone() for p in range(nb)]
+    taps = [cv.make_taps(kind, i, w, sp) for i in range(7 if kind == 2 else 11)]
+    odd = lambda t: bool(t[0] == -t[-1] and t[len(t) // 2] == 0.0)
+    pair = [cv.basis_taps(kind, p) for p in range(nb)]
+    # (1) mirrors
+    fl = cls(torch.flip(x, dims=(1,)).contiguous(), w, sp, setup_flags=flags)
+    fu = cls(torch.flip(x, dims=(0,)).contiguous(), w, sp, setup_flags=flags)
+    for p in range(nb):
+        ix, iy = pair[p]
+        sx = -1.0 if odd(taps[ix]) else 1.0
+        sy = -1.0 if odd(taps[iy]) else 1.0
+        assert torch.equal(fl.basis(p), sx * torch.flip(base[p], dims=(1,))), (kind, p, "left-right")
+        assert torch.equal(fu.basis(p), sy * torch.flip(base[p], dims=(0,))), (kind, p, "up-down")
+    # (2) transpose
+    ft = cls(x.t().contiguous(), w, sp, setup_flags=flags)
+    for p in range(nb):
+        ix, iy = pair[p]
+        q = [k for k in range(nb) if np.array_equal(taps[pair[k][0]], taps[iy]) and np.array_equal(taps[pair[k][1]], taps[ix])]
+        assert len(q) == 1, (kind, p, q)      # every plane has exactly one partner (itself for g2b / g4c)
+        assert float((ft.basis(p) - base[q[0]].t()).abs().max()) <= TOL, (kind, p, q[0])
+
+
 def test_full_size_g4_4096_band(cv, ora):
     """config 5 (G4+H4 at 4096x4096): oracle on bands + constant-image property"""
     import torch
