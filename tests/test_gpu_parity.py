@@ -435,6 +435,32 @@ def test_mirror_and_transpose_properties_full_size(cv, kind, shape):
         assert float((ft.basis(p) - base[q[0]].t()).abs().max()) <= TOL, (kind, p, q[0])
 
 
+@pytest.mark.parametrize("kind", [2, 4])
+@pytest.mark.parametrize("theta", [0.3, -1.1, 2.0])
+def test_steering_under_transpose_and_mirror(cv, kind, theta):
+    """the steering property itself, oracle-independent (1080 x 1920, config 4's frame): for the transposed image
+    g'(theta) = [g(pi/2 - theta)]^T and h'(theta) = -[h(pi/2 - theta)]^T; for the left-right mirrored image g'(theta) =
+    mirror(g(-theta)) and h'(theta) = -mirror(h(-theta)).  Both follow from the steering polynomials of G2.cpp:137-145 /
+    G4.cpp:114-122 and the parities of the kernels, and both pin the SIGN convention of the odd (H) bank, to which the
+    reference's golden images are blind."""
+    import torch
+    w, sp = (4, 0.67) if kind == 2 else (6, 0.5)
+    cls = cv.SteerableFiltersG2 if kind == 2 else cv.SteerableFiltersG4
+    x = torch.rand((1080, 1920), generator=torch.Generator(device="cuda").manual_seed(5 + kind), device="cuda")
+    f = cls(x, w, sp, setup_flags=cv.SETUP_BASIS)
+    ft = cls(x.t().contiguous(), w, sp, setup_flags=cv.SETUP_BASIS)
+    fm = cls(torch.flip(x, dims=(1,)).contiguous(), w, sp, setup_flags=cv.SETUP_BASIS)
+    gt, ht = ft.steer(theta)
+    g1, h1 = f.steer(float(np.float32(np.pi / 2) - np.float32(theta)))
+    scale = max(float(g1.abs().max()), float(h1.abs().max()), 1.0)
+    assert float((gt - g1.t()).abs().max()) <= 2 * TOL * scale
+    assert float((ht + h1.t()).abs().max()) <= 2 * TOL * scale
+    gm, hm = fm.steer(theta)
+    g2_, h2_ = f.steer(-theta)
+    assert float((gm - torch.flip(g2_, dims=(1,))).abs().max()) <= 1e-6 * scale
+    assert float((hm + torch.flip(h2_, dims=(1,))).abs().max()) <= 1e-6 * scale
+
+
 def test_full_size_g4_4096_band(cv, ora):
     """config 5 (G4+H4 at 4096x4096): oracle on bands + constant-image property"""
     import torch
