@@ -441,8 +441,8 @@ def test_steering_under_transpose_and_mirror(cv, kind, theta):
     """the steering property itself, oracle-independent (1080 x 1920, config 4's frame): for the transposed image
     g'(theta) = [g(pi/2 - theta)]^T and h'(theta) = -[h(pi/2 - theta)]^T; for the left-right mirrored image g'(theta) =
     mirror(g(-theta)) and h'(theta) = -mirror(h(-theta)).  Both follow from the steering polynomials of G2.cpp:137-145 /
-    G4.cpp:114-122 and the parities of the kernels, and both pin the SIGN convention of the odd (H) bank, to which the
-    reference's golden images are blind."""
+    G4.cpp:114-122 and the parities of the kernels, and both pin the pairing and the RELATIVE signs of the planes of the odd
+    (H) bank, to which the reference's golden images are blind (a global sign of the whole H bank would still pass)."""
     import torch
     w, sp = (4, 0.67) if kind == 2 else (6, 0.5)
     cls = cv.SteerableFiltersG2 if kind == 2 else cv.SteerableFiltersG4

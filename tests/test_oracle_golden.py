@@ -230,3 +230,35 @@ def test_row_bands_reassemble_the_whole_plane(ora):
                 ora.sepfilter2d_f32_rows(img, kx, ky, lo, hi, dst)
             assert np.array_equal(dst, whole), cuts
     assert ora.time_g2_filter_steer_mt(rand_image(64, 48, seed=2), 0.3, 1, 3) > 0.0
+
+
+@pytest.mark.parametrize("kind", [2, 4])
+def test_oracle_mirror_transpose_and_steering_identities(ora, kind):
+    """the oracle itself obeys the oracle-independent properties the GPU suite checks at BASELINE sizes: mirroring the
+    image mirrors every plane (sign flip where the kernel along that axis is odd), transposing it swaps the row and the
+    column kernel (g2a <-> g2c, h2a <-> h2d, ...; g4a <-> g4e, h4a <-> h4f, ...), and the steered pair follows
+    g'(theta) = [g(pi/2 - theta)]^T, h'(theta) = -[h(pi/2 - theta)]^T -- the pairing and the relative signs inside the odd
+    bank, which the reference's golden images do not see"""
+    rng = np.random.default_rng(40 + kind)
+    x = rng.random((57, 83), dtype=np.float32)
+    w, sp = (4, 0.67) if kind == 2 else (6, 0.5)
+    nb = 7 if kind == 2 else 11
+    base = ora.basis(kind, x, w, sp, f64=True)
+    taps = [ora.make_taps(kind, i, w, sp) for i in range(nb)]
+    pair = [ora.basis_pair(kind, p) for p in range(nb)]
+    odd = lambda t: bool(t[0] == -t[-1] and t[len(t) // 2] == 0.0)
+    lr = ora.basis(kind, np.ascontiguousarray(x[:, ::-1]), w, sp, f64=True)
+    ud = ora.basis(kind, np.ascontiguousarray(x[::-1]), w, sp, f64=True)
+    tr = ora.basis(kind, np.ascontiguousarray(x.T), w, sp, f64=True)
+    for p in range(nb):
+        ix, iy = pair[p]
+        assert np.abs(lr[p] - (-1.0 if odd(taps[ix]) else 1.0) * base[p][:, ::-1]).max() <= 1e-6
+        assert np.abs(ud[p] - (-1.0 if odd(taps[iy]) else 1.0) * base[p][::-1]).max() <= 1e-6
+        q = [k for k in range(nb) if np.array_equal(taps[pair[k][0]], taps[iy]) and np.array_equal(taps[pair[k][1]], taps[ix])]
+        assert len(q) == 1
+        assert np.abs(tr[p] - base[q[0]].T).max() <= 1e-6
+    steer = ora.g2_steer_scalar if kind == 2 else ora.g4_steer_scalar
+    for theta in (0.3, -1.1):
+        gt, ht = steer(tr.astype(np.float32), theta)[:2]
+        g1, h1 = steer(base.astype(np.float32), float(np.float32(np.pi / 2) - np.float32(theta)))[:2]
+        assert np.abs(gt - g1.T).max() <= 1e-5 and np.abs(ht + h1.T).max() <= 1e-5
