@@ -18,6 +18,7 @@
 #include <limits>
 #include <map>
 #include <mutex>
+#include <set>
 #include <tuple>
 #include <new>
 #include <string>
@@ -277,6 +278,7 @@ float* state_plane(cvs_handle h, int idx)
 // cvs_release_cached_memory() empties it.
 std::mutex g_pool_mutex;
 std::vector<StateBlock> g_pool;
+std::set<std::tuple<int, int, int, size_t>> g_no_window;  // (device, planes, rows, pitch) whose placement probe found nothing
 
 size_t pool_limit_bytes()
 {
@@ -336,8 +338,15 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
     const int nplanes = h->nb + 5;
     // Large single-image states get one physical allocation per plane, placed by a bounded search (cvs_state.cpp);
     // small ones (they live in the Infinity Cache anyway) and frame batches take a plain block.
-    const bool want_planes = h->placement != 0 && nframes == 1 && stride * sizeof(float) >= ((size_t)8 << 20) &&
-                             stride * sizeof(float) * nplanes >= ((size_t)256 << 20);
+    bool want_planes = h->placement != 0 && nframes == 1 && stride * sizeof(float) >= ((size_t)8 << 20) &&
+                       stride * sizeof(float) * nplanes >= ((size_t)256 << 20);
+    // a geometry whose probe found no window on this device takes plain blocks from now on (cvs_release_cached_memory()
+    // forgets that): the reference's callers build one object per image, and every new handle would search again
+    const auto geo = std::make_tuple(h->device, nplanes, rows, pitch);
+    if (want_planes) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (g_no_window.count(geo)) want_planes = false;
+    }
     bool reuse = h->state != nullptr;
     if (reuse) {
         if (want_planes && h->sb.vmm) reuse = (int)h->sb.pieces.size() == nplanes && h->sb.piece_bytes >= stride * sizeof(float) &&
@@ -358,6 +367,10 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
             (void)hipStreamIsCapturing(h->stream, &cap);
             if (want_planes && cap == hipStreamCaptureStatusNone) HIP_TRY(h, state_block_alloc_planes(h->device, nplanes, rows, pitch, h->stream, h->placement, h->sb));
             else HIP_TRY(h, state_block_alloc_plain(h->device, elems, h->sb));
+        }
+        if (want_planes && h->sb.searched) {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            g_no_window.insert(geo);
         }
         h->state = h->sb.base;
         h->state_elems = h->sb.elems;
@@ -454,6 +467,12 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
         // ... and when every call brings a new image (inputs come from HBM, not the Infinity Cache) the plain order wins
         // too (8 rotating 4096^2 inputs, one handle: M2 70-72 % plain, 64-68 % weighted)
         a.block_order = (fast && big && !huge && !a.no_state && !fresh_input && h->kind == CVS_KIND_G2) ? 1 : 0;
+        // fresh images in the plain order fetch 1.24 x the image into the L2s: the 128-B line at a tile's left / right edge
+        // is wanted by two XCDs.  With every XCD owning a contiguous range of column blocks it is 1.11 x, at the same launch
+        // time (8 rotating 4096^2 inputs 66.0 vs 65.9 %, two 8192^2 inputs 66.4 vs 66.4 %) -- less HBM traffic for nothing.
+        // Needs the column blocks to divide evenly among the 8 XCDs.
+        const int grid_x = ((a.cols + 63) / 64 + 3) / 4;
+        if (fresh_input && fast && big && h->kind == CVS_KIND_G2 && a.batch == 0 && grid_x % 8 == 0) a.block_order = kOrderXcdColumns;
     }
     // small images and the generic path keep the plain configuration
     if (!fast || !big) return CVS_OK;
@@ -971,6 +990,7 @@ int cvs_release_cached_memory(void)
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         blocks.swap(g_pool);
+        g_no_window.clear();  // the next handle of a large geometry probes again
     }
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;

@@ -12,6 +12,7 @@ namespace cvs {
 constexpr int kMaxWidth = 32;           // generic path: up to 65 taps
 constexpr int kMaxTaps = 2 * kMaxWidth + 1;
 constexpr int kMaxBasis = 11;
+constexpr int kOrderXcdColumns = 1000000;  // BasisArgs::block_order: every XCD owns a contiguous range of column blocks
 
 struct PlaneRef {
     float* p;       // nullptr = not requested
@@ -152,6 +153,7 @@ struct StateBlock {
     size_t elems = 0;          // usable floats from base
     int device = 0;
     bool vmm = false;          // built with the virtual-memory API: piece_bytes per plane, pieces.size() planes
+    bool searched = false;     // a plain block handed out by state_block_alloc_planes after a COMPLETE probe found no window
     size_t piece_bytes = 0;
     std::vector<hipMemGenericAllocationHandle_t> pieces;
     void* va_base = nullptr;   // the reserved virtual range the planes are a window of (freed with the block)

@@ -227,7 +227,14 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
         if (!ok) window = -1;
         (void)hipStreamSynchronize(stream);
     }
-    if (window < 0) return plain();
+    if (mode != 2 && std::getenv("CVS_TEST_NO_WINDOW")) window = -1;  // tests: a box on which the probe finds nothing
+    if (window < 0) {
+        // the probe ran to the end and no window beats a plain block: say so, so that the next handle of this geometry
+        // does not search again (one short-lived object per image would pay ~8 ms of probing each)
+        const hipError_t e = plain();
+        if (e == hipSuccess && mode != 2) b.searched = true;
+        return e;
+    }
     // the window stays, everything else goes back to the allocator (pieces are unmapped for good, never remapped)
     for (int i = 0; i < pool_n; ++i) {
         if (i >= window && i < window + nplanes) continue;

@@ -892,7 +892,7 @@ def test_block_order_never_changes_results(cv):
     from cvsteer_amd import _lib as L
     img = torch.rand((1100, 1500), device="cuda")     # >= 1 Mpix: eligible for autotune
     ref = None
-    for order in (0, 1, 2, 7, 32, 100000, -1):
+    for order in (0, 1, 2, 7, 32, 100000, 1000000, -1):   # 1000000 = XCD-owned column ranges (the default for fresh images)
         f = cv.SteerableFiltersG2(None)
         f.set_option(L.OPT_BLOCK_ORDER, order)
         outs = []
@@ -1157,6 +1157,36 @@ def test_plane_placement_keeps_results(cv):
     assert torch.equal(a4, c4) and torch.equal(b4, d4)
     for p in (0, 4, 10):
         assert torch.equal(f4.basis(p), r4.basis(p))
+
+
+def test_one_object_per_image_probes_once_when_no_window_is_found(cv, monkeypatch):
+    """the reference's usage is one short-lived object per image (example/steer.cpp:86).  On a box where the allocation-time
+    placement probe finds no window, the verdict is remembered per geometry: the second object must not probe again
+    (~8 ms of launches at 2048 x 4096) but take the parked plain block.  cvs_release_cached_memory() forgets the verdict."""
+    import time
+    import torch
+    monkeypatch.setenv("CVS_TEST_NO_WINDOW", "1")
+    x = torch.rand((2048, 4096), device="cuda")          # 12 planes x 32 MiB = 384 MiB of state: large enough to be probed
+    g, h = torch.empty_like(x), torch.empty_like(x)
+    cv.lib().cvs_release_cached_memory()
+
+    def one_object():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f = cv.SteerableFiltersG2(None)
+        f.setup_steer(x, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        torch.cuda.synchronize()
+        del f
+        return (time.perf_counter() - t0) * 1e3
+
+    first = one_object()
+    later = [one_object() for _ in range(4)]
+    assert first > 2.0 * max(later), (first, later)      # the probe ran once ...
+    assert max(later) < 2.0, later                        # ... and never again (a call is ~0.1 ms)
+    cv.lib().cvs_release_cached_memory()
+    again = one_object()
+    assert again > 2.0 * max(later), (again, later)
+    cv.lib().cvs_release_cached_memory()
 
 
 def test_hip_graph_capture_and_replay(cv):
