@@ -59,6 +59,7 @@ struct cvs_context {
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
     int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 1, autotune = 1;
+    int pyr_strip = 1;   // cvs_pyr_down as a strip march (CVS_PYR_STRIP=0: the stand-alone kernel; A/B only, same values)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
     hipEvent_t ev_order = nullptr;            // cvs_set_stream: orders the new stream behind the old one
     // overlapped host path (host_pipeline): copy streams and per-band events, created on first use
@@ -958,6 +959,7 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
         return CVS_E_NOMEM;
     }
     if (const char* e = std::getenv("CVS_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CVS_PYR_STRIP")) h->pyr_strip = std::atoi(e) != 0;
     if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::max(0, std::min(2, std::atoi(e)));  // default for new handles
     *out = h;
     return CVS_OK;
@@ -1539,7 +1541,9 @@ int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst)
     if ((rc = begin(h, c, {src, dst}))) return rc;
     PlaneRef in, out;
     if ((rc = in_ref(c, src, in)) || (rc = out_ref(c, dst, out))) return rc;
-    HIP_TRY(h, launch_pyr_down(in.p, in.pitch, src->rows, src->cols, out.p, out.pitch, h->stream));
+    hipError_t pe = hipSuccess;
+    if (h->pyr_strip && launch_pyr_strip(in.p, in.pitch, src->rows, src->cols, out.p, out.pitch, h->stream, &pe)) HIP_TRY(h, pe);
+    else HIP_TRY(h, launch_pyr_down(in.p, in.pitch, src->rows, src->cols, out.p, out.pitch, h->stream));
     return finish(c);
 }
 

@@ -146,6 +146,8 @@ hipError_t launch_convert_u8(const float* src, size_t pitch, int rows, int cols,
                              size_t dst_step, hipStream_t s);
 hipError_t launch_u8_to_f32(const uint8_t* src, size_t sstep, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
+// the same as a strip march of the basis kernel's machinery (cvs_kernels_basis.hip); false = geometry not covered, use launch_pyr_down
+bool launch_pyr_strip(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s, hipError_t* err);
 
 // ---- state blocks (cvs_state.cpp): a plain hipMalloc block, or one physical allocation per plane mapped back to back ----
 struct StateBlock {

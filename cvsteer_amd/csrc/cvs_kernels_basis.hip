@@ -27,6 +27,9 @@
 //    single state resource; G4 runs as two half banks side by side in one launch (k_basis_pair).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "cvs_device_math.h"
 #include "cvs_internal.h"
 
@@ -94,8 +97,9 @@ struct Folded {
     float od[B::NO][B::W];
 };
 
-enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8, F_PYR = 16 };  // F_PIPE implies F_ORIENT; F_NOSTATE: outputs only;
-                                                                            // F_PYR: also emit cv::pyrDown(image) (next pyramid level)
+enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8, F_PYR = 16, F_PYRONLY = 32 };  // F_PIPE implies F_ORIENT; F_NOSTATE: outputs only;
+                                                                            // F_PYR: also emit cv::pyrDown(image) (next pyramid level);
+                                                                            // F_PYRONLY (with F_PYR): nothing but that -- cvs_pyr_down as a strip march
 
 // LDS hand-off inside ONE wave: DS ops of a wave execute in issue order, so only the compiler
 // must be kept from moving them across this point.
@@ -347,6 +351,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     bst<false>(r_pyr, xpb, (unsigned)((y0 + ci) >> 1) * pyr_pitch_b, __fmul_rn(v, 1.0f / 256.0f));
                 }
             }
+            if constexpr ((FLAGS & F_PYRONLY) == 0) {
             float sum[W + 1], dif[W + 1];
 #pragma unroll
             for (int i = 1; i <= W; ++i) {
@@ -477,6 +482,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     }
                 }
             }
+            }  // !F_PYRONLY
         }
     }
 #ifdef CVS_DIAG_STAMPS
@@ -800,6 +806,39 @@ bool basis_fuses_pyr(int kind, int width, const float (*taps)[kMaxTaps], const B
     if (!fast_geometry_ok(a, width) || band_rows(a, width) < a.rows) return false;
     if (a.out_row_hi > a.out_row_lo || a.frames || a.batch_regular || a.pipe || (a.steer_g && a.steer_h)) return false;
     return (size_t)((a.rows + 1) / 2) * a.pyr_pitch * sizeof(float) <= kMaxPlaneBytes;
+}
+
+// cv::pyrDown of one plane as a strip march (cvs_pyr_down): the F_PYR emission of the basis kernel with the filters
+// compiled out -- every wave stages its rows in LDS once, keeps five blurred rows in registers and writes every second one:
+// each input line is requested once per strip (the stand-alone k_pyr_down asks for it 10.5 times per output pixel through
+// the caches).  Same arithmetic, bit-identical.  false = the geometry is not covered (tiny images, planes of 2 GiB and more).
+bool launch_pyr_strip(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s, hipError_t* err)
+{
+    constexpr int W = BankG2::W;
+    if (rows < 3 * W + 1 || cols < W + 1) return false;
+    if ((size_t)rows * spitch * sizeof(float) > kMaxPlaneBytes || (size_t)((rows + 1) / 2) * dpitch * sizeof(float) > kMaxPlaneBytes) return false;
+    BasisArgs a{};
+    a.in = src;
+    a.in_pitch = spitch;
+    a.rows = rows;
+    a.cols = cols;
+    a.pitch = spitch;          // no state plane is touched; the resources built from these are never used
+    a.plane_stride = 0;
+    a.pyr_out = dst;
+    a.pyr_pitch = dpitch;
+    a.strip_rows = 6 * (2 * W + 1) - 2 * W;   // 46 rows: 17 % more rows staged than written, ~11 k waves at 8192^2
+    if (const char* e = std::getenv("CVS_PYR_STRIP_ROWS")) a.strip_rows = std::max(1, std::atoi(e));  // tuning aid
+    a.row_lo = 0;
+    a.row_hi = rows;
+    a.row_base = 0;
+    const int strips_x = (cols + 63) / 64;
+    dim3 grid((strips_x + 3) / 4, (rows + a.strip_rows - 1) / a.strip_rows), block(256);
+    a.grid_x = grid.x;
+    a.grid_y = grid.y;
+    Folded<BankG2> f{};
+    hipLaunchKernelGGL((k_basis<BankG2, F_PYR | F_PYRONLY, false, 0, false, 4>), grid, block, 0, s, a, f);
+    *err = hipGetLastError();
+    return true;
 }
 
 // launch `fn(args)` once per row band, with the plane pointers shifted to the band's first halo row
