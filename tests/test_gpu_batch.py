@@ -397,3 +397,27 @@ def test_two_processes_hip_frame_function(n_frames):
         p.join(300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+def test_bench_starts_its_own_ranks_and_watchdog_emits_the_headline(tmp_path):
+    """bench.py --gpus 2 without a launcher: the parent starts two rank processes before it touches the GPU (rehearsal on one
+    device: CVS_BENCH_TEST_BACKEND=gloo puts both ranks on device 0), rank 0 prints ONE JSON line with n_gpus = 2; and with
+    a watchdog too short for the secondary legs every rank still exits 0 and the line carries the headline + extra_error."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVS_BENCH_TEST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extra"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["config"]["ranks_started_by"] == "bench.py"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--extra-timeout", "1"],
+                       env=os.environ, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "extra_error" in d
