@@ -32,6 +32,13 @@ class CvsError(RuntimeError):
         super().__init__(msg)
 
 
+class LaunchInfo(C.Structure):
+    """struct cvs_launch_info"""
+    _fields_ = [("placement_mode", C.c_int32), ("state_per_plane", C.c_int32), ("window_found", C.c_int32), ("probes_run", C.c_int32),
+                ("probe_ms", C.c_double), ("block_order", C.c_int32), ("xcd_weights", C.c_int32), ("strip_rows", C.c_int32),
+                ("nt_stores", C.c_int32), ("g4_split", C.c_int32)]
+
+
 _PP = C.POINTER(Plane)
 _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int)
@@ -51,6 +58,7 @@ SIGNATURES = {
     "cvs_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvs_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "cvs_get_option": (C.c_int, [C.c_void_p, C.c_int, _IP]),
+    "cvs_get_launch_info": (C.c_int, [C.c_void_p, C.POINTER(LaunchInfo)]),
     "cvs_taps": (C.c_int, [C.c_void_p, C.c_int, _FP]),
     "cvs_kind": (C.c_int, [C.c_void_p, _IP, _IP, _FP]),
     "cvs_shape": (C.c_int, [C.c_void_p, _IP, _IP]),

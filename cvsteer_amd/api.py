@@ -153,6 +153,12 @@ class SteerableFilters:
     def set_option(self, option, value):
         self._check(lib().cvs_set_option(self._h, option, int(value)), "cvs_set_option")
 
+    def launch_info(self):
+        """cvs_get_launch_info as a dict: placement of the state block + configuration of the last basis launch"""
+        li = L.LaunchInfo()
+        self._check(lib().cvs_get_launch_info(self._h, C.byref(li)), "cvs_get_launch_info")
+        return {k: getattr(li, k) for k, _ in L.LaunchInfo._fields_}
+
     def set_atan_mode(self, exact):
         self.set_option(L.OPT_ATAN_MODE, 1 if exact else 0)
 

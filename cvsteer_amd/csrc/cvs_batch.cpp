@@ -48,6 +48,7 @@ struct Rccl {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -83,6 +84,7 @@ Rccl* rccl(std::string* why = nullptr)
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
         if (!ok) {
             dlclose(r.so);
@@ -121,6 +123,7 @@ struct Slot {
     bool last_staged = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t up = nullptr, down = nullptr;  // host planes: upload / download streams beside `stream`
+    int* agree = nullptr;                   // 4 ints of device memory for the status agreement of a multi-process world
 };
 
 }  // namespace
@@ -204,24 +207,67 @@ struct Move {
     size_t count;
 };
 
+// An RCCL group that was started MUST be ended, whatever happens inside it: a return between ncclGroupStart and
+// ncclGroupEnd leaves the group open, and every later RCCL call of the process is silently queued into it.  So errors
+// inside a group are collected, the group is closed, and only then does the call fail.
+struct GroupGuard {
+    Rccl* R;
+    bool open = false;
+    int rc = CVS_OK;
+    std::string err;
+    explicit GroupGuard(Rccl* r) : R(r) {}
+    void start()
+    {
+        const ncclResult_t r = R->GroupStart();
+        if (r == ncclSuccess) open = true;
+        else note(CVS_E_HIP, std::string("ncclGroupStart: ") + R->GetErrorString(r));
+    }
+    void note(int code, const std::string& what)
+    {
+        if (rc == CVS_OK) { rc = code; err = what; }
+    }
+    void hip(hipError_t e, const char* what)
+    {
+        if (e != hipSuccess) note(e == hipErrorOutOfMemory ? CVS_E_NOMEM : CVS_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+    void nccl(ncclResult_t r, const char* what)
+    {
+        if (r != ncclSuccess) note(CVS_E_HIP, std::string(what) + ": " + R->GetErrorString(r));
+    }
+    bool ok() const { return rc == CVS_OK; }
+    int end(cvs_batch b)
+    {
+        if (open) {
+            open = false;
+            nccl(R->GroupEnd(), "ncclGroupEnd");
+        }
+        return rc == CVS_OK ? CVS_OK : fail(b, rc, err);
+    }
+    ~GroupGuard()
+    {
+        if (open) (void)R->GroupEnd();
+    }
+};
+
 int run_moves(cvs_batch b, const std::vector<Move>& moves)
 {
     if (moves.empty()) return CVS_OK;
     if (b->transport == TRANSPORT_RCCL) {
-        Rccl* R = rccl();
-        B_NCCL(b, R->GroupStart());
+        GroupGuard g(rccl());
+        g.start();
         for (const Move& m : moves) {
+            if (!g.ok()) break;
             if (Slot* s = local(b, m.src_rank)) {
-                B_HIP(b, hipSetDevice(s->device));
-                B_NCCL(b, R->Send(m.src, m.count, ncclFloat, m.dst_rank, s->comm, s->stream));
+                g.hip(hipSetDevice(s->device), "hipSetDevice");
+                if (g.ok()) g.nccl(g.R->Send(m.src, m.count, ncclFloat, m.dst_rank, s->comm, s->stream), "ncclSend");
             }
+            if (!g.ok()) break;
             if (Slot* d = local(b, m.dst_rank)) {
-                B_HIP(b, hipSetDevice(d->device));
-                B_NCCL(b, R->Recv(m.dst, m.count, ncclFloat, m.src_rank, d->comm, d->stream));
+                g.hip(hipSetDevice(d->device), "hipSetDevice");
+                if (g.ok()) g.nccl(g.R->Recv(m.dst, m.count, ncclFloat, m.src_rank, d->comm, d->stream), "ncclRecv");
             }
         }
-        B_NCCL(b, R->GroupEnd());
-        return CVS_OK;
+        return g.end(b);
     }
     // rehearsal transport (ranks sharing a device, one process): the copy runs on the destination's stream after an
     // event on the source's stream -- the same ordering a send / recv pair gives
@@ -246,6 +292,65 @@ int run_moves(cvs_batch b, const std::vector<Move>& moves)
         B_HIP(b, hipEventDestroy(done));
     }
     return CVS_OK;
+}
+
+// Ranks of a world spread over SEVERAL processes agree on "may data be queued?" before any of them queues a message:
+// a failure that only one process can see (the root's planes are not what cvs_batch_run needs, a staging allocation
+// fails on one rank, the ranks were handed different geometries) would otherwise leave the others inside ncclRecv for
+// ever.  One 4-int all-reduce (min) per call: {status, geometry hash, -geometry hash, 0}; the hashes agree iff
+// min(h) == -min(-h).  A world that lives in one process has nothing to agree on (the same code path sees every rank's
+// status before anything is queued) and skips this.  Returns local_rc if that is already an error.
+int agree(cvs_batch b, int local_rc, uint32_t geometry_hash)
+{
+    if (b->transport != TRANSPORT_RCCL || (int)b->slots.size() == b->world) return local_rc;
+    Rccl* R = rccl();
+    const int h31 = (int)(geometry_hash & 0x3fffffffu);
+    int mine[4] = {local_rc, h31, -h31, 0};
+    int rc = CVS_OK;
+    std::string err;
+    for (Slot& s : b->slots) {
+        if (hipSetDevice(s.device) != hipSuccess || (!s.agree && hipMalloc(&s.agree, 4 * sizeof(int)) != hipSuccess) ||
+            hipMemcpyAsync(s.agree, mine, sizeof(mine), hipMemcpyHostToDevice, s.stream) != hipSuccess) {
+            // even the agreement cannot be prepared here: take part with an error status if at all possible, so that the
+            // peers do not wait -- without device memory for it there is no way to tell them
+            (void)hipGetLastError();
+            rc = CVS_E_HIP;
+            err = "status agreement: no device memory";
+        }
+    }
+    {
+        GroupGuard g(R);
+        g.start();
+        for (Slot& s : b->slots) {
+            if (!g.ok() || !s.agree) break;
+            g.hip(hipSetDevice(s.device), "hipSetDevice");
+            if (g.ok()) g.nccl(R->AllReduce(s.agree, s.agree, 4, ncclInt32, ncclMin, s.comm, s.stream), "ncclAllReduce");
+        }
+        const int grc = g.end(b);
+        if (grc != CVS_OK) return grc;
+    }
+    if (rc != CVS_OK) return fail(b, rc, err);
+    int agreed[4] = {0, 0, 0, 0};
+    for (Slot& s : b->slots) {
+        B_HIP(b, hipSetDevice(s.device));
+        B_HIP(b, hipMemcpyAsync(agreed, s.agree, sizeof(agreed), hipMemcpyDeviceToHost, s.stream));
+        B_HIP(b, hipStreamSynchronize(s.stream));
+        if (agreed[0] != CVS_OK && local_rc == CVS_OK)
+            return fail(b, agreed[0], "a peer rank cannot run this call (status " + std::to_string(agreed[0]) + "); nothing was queued");
+        if (agreed[1] != -agreed[2] && local_rc == CVS_OK)
+            return fail(b, CVS_E_BADARG, "the ranks were called with different geometries / options; nothing was queued");
+    }
+    return local_rc;
+}
+
+uint32_t hash_ints(std::initializer_list<long long> v)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (long long x : v) {
+        h ^= (uint64_t)x;
+        h *= 1099511628211ull;
+    }
+    return (uint32_t)(h ^ (h >> 32));
 }
 
 int record_all(cvs_batch b, int which)
@@ -689,6 +794,7 @@ int cvs_batch_destroy(cvs_batch b)
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.up) (void)hipStreamDestroy(s.up);
         if (s.down) (void)hipStreamDestroy(s.down);
+        if (s.agree) (void)hipFree(s.agree);
     }
     delete b;
     return CVS_OK;
@@ -734,30 +840,47 @@ int cvs_batch_run(cvs_batch b, const cvs_batch_cfg* cfg, const cvs_plane* inputs
     const size_t plane = (size_t)rows * cols;
     Slot* rs = local(b, root);
     const bool via = cfg->self_via_transport != 0 && b->transport != TRANSPORT_NONE;
+    if (b->world > 1 && b->transport == TRANSPORT_NONE) return fail(b, CVS_E_HIP, "no transport");
+    // What only THIS process can know -- are the root's planes usable, do the staging buffers fit -- is collected into
+    // local_rc without returning, and the ranks agree on it before anybody queues a message (see agree()): a rank that
+    // returned early here would leave its peers inside ncclRecv for ever.
+    int local_rc = CVS_OK;
+    auto lfail = [&](int code, const char* what) {
+        if (local_rc == CVS_OK) local_rc = fail(b, code, what);
+    };
+    bool host = false;
     if (rs) {
-        if (!inputs) return fail(b, CVS_E_BADARG, "the root rank needs the input frames");
-        if (cfg->gather && !outputs) return fail(b, CVS_E_BADARG, "the root rank needs output planes to gather into");
-        if ((inputs[0].mem & 0xff) == CVS_MEM_HOST) return run_host(b, cfg, inputs, outputs, sel, K, timing);
-        for (int f = 0; f < F; ++f) {
-            if (!dense_device(&inputs[f], rows, cols)) return fail(b, CVS_E_SIZE, "input frames must be dense f32 device planes of rows x cols");
-            for (int j = 0; cfg->gather && j < K; ++j)
-                if (!dense_device(&outputs[(size_t)f * 8 + sel[j]], rows, cols))
-                    return fail(b, CVS_E_SIZE, "requested output planes must be dense f32 device planes of rows x cols");
+        if (!inputs) lfail(CVS_E_BADARG, "the root rank needs the input frames");
+        else if (cfg->gather && !outputs) lfail(CVS_E_BADARG, "the root rank needs output planes to gather into");
+        else if ((inputs[0].mem & 0xff) == CVS_MEM_HOST) {
+            host = true;
+            if ((int)b->slots.size() != b->world)
+                lfail(CVS_E_UNSUPPORTED, "host planes need every rank in the calling process (each GPU pulls its frames over its own link)");
+        } else {
+            for (int f = 0; f < F && local_rc == CVS_OK; ++f) {
+                if (!dense_device(&inputs[f], rows, cols)) lfail(CVS_E_SIZE, "input frames must be dense f32 device planes of rows x cols");
+                for (int j = 0; cfg->gather && j < K && local_rc == CVS_OK; ++j)
+                    if (!dense_device(&outputs[(size_t)f * 8 + sel[j]], rows, cols))
+                        lfail(CVS_E_SIZE, "requested output planes must be dense f32 device planes of rows x cols");
+            }
         }
     }
-    if (b->world > 1 && b->transport == TRANSPORT_NONE) return fail(b, CVS_E_HIP, "no transport");
     int rc;
     // staging on every local rank that does not work in place
     for (Slot& s : b->slots) {
+        if (local_rc != CVS_OK || host) break;
         int lo, hi;
         shard_range(F, b->world, s.rank, &lo, &hi);
         const size_t n = (size_t)(hi - lo);
         const bool in_place = s.rank == root && !via;
-        if (!in_place && n && (rc = reserve(b, s, s.in, n * plane))) return rc;
+        if (!in_place && n && (rc = reserve(b, s, s.in, n * plane))) { local_rc = rc; break; }
         // the root writes its own shard straight into the caller's planes when it gathers; everybody else stages
         const bool out_in_place = s.rank == root && cfg->gather && !via;
-        if (!out_in_place && n && (rc = reserve(b, s, s.out, n * K * plane))) return rc;
+        if (!out_in_place && n && (rc = reserve(b, s, s.out, n * K * plane))) { local_rc = rc; break; }
     }
+    if ((rc = agree(b, local_rc, hash_ints({rows, cols, F, (long long)cfg->outputs, root, cfg->gather, cfg->self_via_transport, 4}))))
+        return rc;
+    if (host) return run_host(b, cfg, inputs, outputs, sel, K, timing);   // every rank is in this process (checked above)
     if ((rc = record_all(b, 0))) return rc;
     // ---- scatter: root -> ranks, frame by frame (a frame is one contiguous message) ----
     {
@@ -845,7 +968,10 @@ int cvs_batch_pyramid_setup(cvs_batch b, const cvs_plane* image, int rows, int c
     if (b->world > 1 && b->transport == TRANSPORT_NONE) return fail(b, CVS_E_HIP, "no transport");
     if (!(flags & CVS_SETUP_BASIS)) flags |= CVS_SETUP_BASIS;
     Slot* rs = local(b, root);
-    if (rs && !dense_device(image, rows, cols)) return fail(b, CVS_E_SIZE, "the image must be a dense f32 device plane of rows x cols on the root");
+    // root-only and per-rank failures are agreed on before anything is queued (see agree() / cvs_batch_run)
+    int local_rc = CVS_OK;
+    if (rs && !dense_device(image, rows, cols))
+        local_rc = fail(b, CVS_E_SIZE, "the image must be a dense f32 device plane of rows x cols on the root");
     const int nb = cvs_num_basis(b->kind);
     const int nplanes = nb + ((flags & CVS_SETUP_ORIENT) ? 5 : 0);
     std::vector<int> lr(levels), lc(levels);
@@ -857,19 +983,24 @@ int cvs_batch_pyramid_setup(cvs_batch b, const cvs_plane* image, int rows, int c
     }
     int rc;
     const size_t plane0 = (size_t)rows * cols;
-    for (Slot& s : b->slots) {
-        if (s.rank != root && (rc = reserve(b, s, s.image, plane0))) return rc;
-        while ((int)s.level.size() < levels) {
-            cvs_handle h = nullptr;
-            rc = cvs_create(b->kind, b->width, b->spacing, s.device, &h);
-            if (rc != CVS_OK) return fail(b, rc, "cvs_create (level handle)");
-            B_CVS(b, h, cvs_set_stream(h, s.stream));
-            s.level.push_back(h);
-            s.level_img.push_back(DevBuf());
+    auto prepare = [&]() -> int {
+        for (Slot& s : b->slots) {
+            if (s.rank != root && (rc = reserve(b, s, s.image, plane0))) return rc;
+            while ((int)s.level.size() < levels) {
+                cvs_handle h = nullptr;
+                rc = cvs_create(b->kind, b->width, b->spacing, s.device, &h);
+                if (rc != CVS_OK) return fail(b, rc, "cvs_create (level handle)");
+                B_CVS(b, h, cvs_set_stream(h, s.stream));
+                s.level.push_back(h);
+                s.level_img.push_back(DevBuf());
+            }
+            for (int l = 1; l < levels; ++l)
+                if ((rc = reserve(b, s, s.level_img[l], (size_t)lr[l] * lc[l]))) return rc;
         }
-        for (int l = 1; l < levels; ++l)
-            if ((rc = reserve(b, s, s.level_img[l], (size_t)lr[l] * lc[l]))) return rc;
-    }
+        return CVS_OK;
+    };
+    if (local_rc == CVS_OK) local_rc = prepare();
+    if ((rc = agree(b, local_rc, hash_ints({rows, cols, levels, (long long)flags, root, 3})))) return rc;
     b->pyr_levels = levels;
     b->pyr_root = root;
     if ((rc = record_all(b, 0))) return rc;
@@ -878,15 +1009,16 @@ int cvs_batch_pyramid_setup(cvs_batch b, const cvs_plane* image, int rows, int c
     const bool self_bcast = b->world == 1 && b->transport == TRANSPORT_RCCL && std::getenv("CVS_BATCH_SELF_TRANSPORT");
     if (b->world > 1 || self_bcast) {
         if (b->transport == TRANSPORT_RCCL) {
-            Rccl* R = rccl();
-            B_NCCL(b, R->GroupStart());
+            GroupGuard g(rccl());
+            g.start();
             for (Slot& s : b->slots) {
-                B_HIP(b, hipSetDevice(s.device));
+                if (!g.ok()) break;
+                g.hip(hipSetDevice(s.device), "hipSetDevice");
                 const float* src = s.rank == root ? image->data : s.image.p;
                 float* dst = s.rank == root ? image->data : s.image.p;
-                B_NCCL(b, R->Broadcast(src, dst, plane0, ncclFloat, root, s.comm, s.stream));
+                if (g.ok()) g.nccl(g.R->Broadcast(src, dst, plane0, ncclFloat, root, s.comm, s.stream), "ncclBroadcast");
             }
-            B_NCCL(b, R->GroupEnd());
+            if ((rc = g.end(b))) return rc;
         } else {
             std::vector<Move> mv;
             for (Slot& s : b->slots)

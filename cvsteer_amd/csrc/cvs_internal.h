@@ -156,6 +156,8 @@ struct StateBlock {
     int device = 0;
     bool vmm = false;          // built with the virtual-memory API: piece_bytes per plane, pieces.size() planes
     bool searched = false;     // a plain block handed out by state_block_alloc_planes after a COMPLETE probe found no window
+    bool probed = false;       // this allocation ran the placement probe (to the end or not)
+    float probe_ms = 0.f;      // host wall time the probe took (pool creation, launches, release of the spare pieces)
     size_t piece_bytes = 0;
     std::vector<hipMemGenericAllocationHandle_t> pieces;
     void* va_base = nullptr;   // the reserved virtual range the planes are a window of (freed with the block)
@@ -164,6 +166,8 @@ struct StateBlock {
 hipError_t state_block_alloc_plain(int device, size_t elems, StateBlock& b);
 hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b);
 void state_block_free(StateBlock& b);
+// placement probes this process has run so far (tests and bench.py read it through cvs_get_launch_info)
+int state_probes_run();
 // streaming-store probe used by the placement search: writes `n` planes (<= 12) of rows x pitch floats in the basis
 // kernel's access shape (wave = 64-column strip of 19 rows, nontemporal dword stores)
 hipError_t launch_place_probe(float* const* planes, int n, int rows, size_t pitch, hipStream_t s);

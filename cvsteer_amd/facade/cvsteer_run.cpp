@@ -174,6 +174,14 @@ std::vector<std::string> input_list(const std::string& arg)
     return out;
 }
 
+// the status first, THEN the error text: written as `check(call(&batch), ..., cvs_batch_last_error(batch))` the two
+// arguments are evaluated in unspecified order and the text may be read before the call has run (or created `batch`)
+#define CHECK_BATCH(batch, call, what)                         \
+    do {                                                       \
+        const int rc__ = (call);                               \
+        check(rc__, what, cvs_batch_last_error(batch));        \
+    } while (0)
+
 void check(int rc, const char* what, const char* detail)
 {
     if (rc != CVS_OK) throw std::runtime_error(std::string(what) + ": " + cvs_status_string(rc) + (detail && *detail ? std::string(" -- ") + detail : ""));
@@ -220,8 +228,8 @@ int main(int argc, char** argv)
         const std::vector<std::string> files = input_list(input);
         std::vector<int> devices(gpus);
         for (int d = 0; d < gpus; ++d) devices[d] = device_list.empty() ? d : device_list[d];
-        check(cvs_batch_create_local(CVS_KIND_G2, 4, 0.67f, gpus, devices.data(), &batch), "cvs_batch_create_local", cvs_batch_last_error(batch));
-        check(cvs_batch_set_option(batch, CVS_OPT_PERSIST_STATE, 0), "cvs_batch_set_option", cvs_batch_last_error(batch));  // only the three maps are kept
+        CHECK_BATCH(batch, cvs_batch_create_local(CVS_KIND_G2, 4, 0.67f, gpus, devices.data(), &batch), "cvs_batch_create_local");
+        CHECK_BATCH(batch, cvs_batch_set_option(batch, CVS_OPT_PERSIST_STATE, 0), "cvs_batch_set_option");  // only the three maps are kept
 
         size_t next = 0;
         while (next < files.size()) {
@@ -266,9 +274,9 @@ int main(int argc, char** argv)
                 for (int j = 0; j < 3; ++j)
                     outp[(size_t)f * 8 + 5 + j] = cvs_plane{reinterpret_cast<float*>(u8.data() + ((size_t)f * 3 + j) * plane), rows, cols, (size_t)cols,
                                                             CVS_MEM_HOST | CVS_DEPTH_U8};
-            check(cvs_batch_set_u8_gain(batch, gain > 0.f ? gain : 0.f), "cvs_batch_set_u8_gain", cvs_batch_last_error(batch));
+            CHECK_BATCH(batch, cvs_batch_set_u8_gain(batch, gain > 0.f ? gain : 0.f), "cvs_batch_set_u8_gain");
             cvs_batch_timing t;
-            check(cvs_batch_run(batch, &cfg, in.data(), outp.data(), &t), "cvs_batch_run", cvs_batch_last_error(batch));
+            CHECK_BATCH(batch, cvs_batch_run(batch, &cfg, in.data(), outp.data(), &t), "cvs_batch_run");
             if (verbose) std::printf("batch of %d x %dx%d: upload %.2f ms, download %.2f ms, span %.2f ms\n", n, rows, cols, t.scatter_ms, t.gather_ms, t.compute_ms);
             static const char* suffix[3] = {"_edges", "_lines_dark", "_lines_bright"};
             const int frame = n;

@@ -80,7 +80,9 @@ enum {
                                  0 (default) = 4:3, or what the autotuner found (tuning) */
     CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the second launch of a shape times a few launch configurations and caches the
                                 winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
-    CVS_OPT_PLACEMENT_SEARCH = 11, /* where the state planes of a large image (state >= 256 MiB) live.  1 (default): one physical
+    CVS_OPT_PLACEMENT_SEARCH = 11, /* where the state planes of a large image (state >= 256 MiB) live.  0 (DEFAULT since round 3):
+                                      a plain hipMalloc block, no probe, no side effects.  1 (opt-in tuning knob; also
+                                      CVS_PLACEMENT_SEARCH=1 in the environment): one physical
                                       allocation per plane, mapped back to back (planes then start on 2 MiB boundaries); when the
                                       block is allocated, once, five blocks' worth of pieces are created and mapped, a streaming-
                                       store probe is slid over them (10-12 ms at 4096^2 on the handle's stream) and, if some window
@@ -89,9 +91,10 @@ enum {
                                       released again, else everything is and the block is a plain hipMalloc.  Bounded: at most four
                                       extra blocks of transient memory and never more than 8 GiB; one search at a time per
                                       process; none under stream capture; each search keeps its virtual range reserved for the
-                                      life of the process (address space only, capped at 4 TiB).  0 = a plain hipMalloc block,
-                                      no probe.  2 = always take the window in the middle of the pool (tests).  Results never
-                                      depend on it. */
+                                      life of the process (address space only, capped at 4 TiB); a chosen window is verified by
+                                      a fill + sampled readback before use and is made accessible to the peer devices of the
+                                      process.  2 = always take the window in the middle of the pool (tests).  Results never
+                                      depend on it; cvs_get_launch_info reports what the last allocation did. */
     CVS_OPT_HOST_OVERLAP = 13, /* cvs_setup / cvs_setup_steer / cvs_pipeline with HOST planes on images of 1 Mpix and more:
                                   1 (default) = the image goes up, is filtered and comes down in row bands, all three at once
                                   (full-duplex host link, a second host thread for the downloads); 0 = one after the other */
@@ -152,6 +155,23 @@ const char* cvs_last_error(cvs_handle h);
 int cvs_set_stream(cvs_handle h, void* hip_stream);
 int cvs_set_option(cvs_handle h, int option, int value);
 int cvs_get_option(cvs_handle h, int option, int* value);
+/* What the engine decided by itself for this handle: where its state block lives (the opt-in placement search) and how
+ * the last basis launch was configured (launch order, XCD weights, strip height, store policy: defaults or what the
+ * launch-order tuner kept).  For benchmarks and tests -- a record must say whether a window was found, and a test asks
+ * "did a probe run" instead of reading the wall clock.  Nothing of this changes results. */
+typedef struct cvs_launch_info {
+    int32_t placement_mode;   /* CVS_OPT_PLACEMENT_SEARCH of the handle */
+    int32_t state_per_plane;  /* 1 = the current state block is a window of per-plane physical allocations */
+    int32_t window_found;     /* the allocation of the current state block found (or was handed) such a window */
+    int32_t probes_run;       /* placement probes this PROCESS has run so far */
+    double probe_ms;          /* host wall time of the probe this handle's current block paid for (0 = none) */
+    int32_t block_order;      /* last basis launch: CVS_OPT_BLOCK_ORDER value in effect */
+    int32_t xcd_weights;      /* ... 100 * even + odd */
+    int32_t strip_rows;       /* ... output rows per wave strip */
+    int32_t nt_stores;        /* ... 1 = streaming (nontemporal) stores */
+    int32_t g4_split;         /* ... CVS_OPT_G4_SPLIT value in effect */
+} cvs_launch_info;
+int cvs_get_launch_info(cvs_handle h, cvs_launch_info* out);
 /* the handle's idx-th tap vector (m_g1.. members), 2*width+1 floats */
 int cvs_taps(cvs_handle h, int idx, float* out);
 int cvs_kind(cvs_handle h, int* kind, int* width, float* spacing);
@@ -254,7 +274,12 @@ int cvs_convert_u8_batch(cvs_handle h, const cvs_plane* src, int n, float alpha,
  * device listed twice = rehearsal on a smaller box, transport = device copies instead of RCCL) or by one process per
  * GPU (cvs_batch_unique_id on one rank, the 128 bytes distributed by the caller, cvs_batch_create_rank everywhere).
  * Every rank of the world calls cvs_batch_run / cvs_batch_pyramid_setup with the same arguments; ranks that do not
- * hold the root pass NULL planes.  Calls return when the root holds the results. */
+ * hold the root pass NULL planes.  Calls return when the root holds the results.
+ * In a world of several processes the ranks first AGREE (one 4-int ncclAllReduce, before any data is queued) that
+ * every one of them can run the call -- the root's planes are what the call needs, every rank's staging fits, all ranks
+ * were given the same geometry -- and otherwise all of them return an error with nothing queued; no rank is left
+ * waiting in a receive.  (A failure after that point -- a kernel launch error on one rank -- is not recoverable across
+ * processes: destroy the batch.)  An RCCL group that was started is always ended, also on errors. */
 typedef struct cvs_batch_context* cvs_batch;
 enum { CVS_BATCH_ID_BYTES = 128 };
 enum { CVS_BATCH_TRANSPORT_NONE = 0, CVS_BATCH_TRANSPORT_RCCL = 1, CVS_BATCH_TRANSPORT_COPY = 2 };
