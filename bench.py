@@ -34,10 +34,14 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ROWS = COLS = 4096
 THETA = 0.3
 BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56}
-# calls on a new handle before a timed region: the engine times a few launch orders on the SECOND call with a
-# shape (bounded: ~20 launches, cached process-wide).  Nothing else is deferred -- the
-# placement search of round 1 is opt-in now and off here.  `M2_untuned` / `M2_first_call` report the legs without it.
+# calls on a new handle before a timed region: the engine times a few launch orders on the SECOND repeat of a shape
+# (bounded: ~50 launches, cached process-wide).  Nothing else is deferred: the allocation-time
+# placement search is OPT-IN since round 3 and OFF for the headline (`config.placement` records mode / window_found /
+# probe_ms as the library reports them; `extra.M2_placement_search` is the same loop with the search switched on, so
+# that one line shows what a window is worth on the box it ran on).  `M2_untuned` / `M2_first_call` = no tuner either.
 INIT_CALLS = 4
+EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
+EXIT_TERMINATED = 4   # SIGTERM (another rank failed / the launcher gave up): whatever was measured is printed first
 
 
 def _dist_env():
@@ -78,7 +82,7 @@ def _spawn_ranks(n):
                 if code != 0 and rc == 0:
                     rc = code if code > 0 else 1
                     print("bench.py: rank process %d exited with status %d; stopping the others" % (p.pid, code), file=sys.stderr)
-                    for q in live:
+                    for q in live:   # every rank prints what it has (rank 0: the JSON line) from its SIGTERM watcher thread
                         q.send_signal(signal.SIGTERM)
     except KeyboardInterrupt:
         for q in procs:
@@ -93,24 +97,33 @@ def _spawn_ranks(n):
     return rc
 
 
-def _time_steps(torch, fn, steps, warmup, barrier):
-    """W untimed warm-ups, then exactly K steps between barrier + synchronize; returns
-    (wall seconds, HIP-event milliseconds on the launch stream)."""
+def _time_steps(torch, fn, steps, warmup, barrier, repeats=1):
+    """W untimed warm-ups, then R regions of exactly K steps, each between barrier + synchronize on both sides;
+    returns ([wall seconds per region], [HIP-event milliseconds per region, on the launch stream])."""
     for _ in range(warmup):
         fn()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(steps):
-        fn()
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    return t1 - t0, ev0.elapsed_time(ev1)
+    walls, evs = [], []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        walls.append(t1 - t0)
+        evs.append(ev0.elapsed_time(ev1))
+    return walls, evs
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
 def _cpu_baseline(theta):
@@ -158,11 +171,21 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--extra-timeout", type=int, default=900, help="seconds the secondary legs may take before every rank gives up on them (0 = no watchdog)")
+    ap.add_argument("--repeats", type=int, default=11, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
+    ap.add_argument("--leg-repeats", type=int, default=5, help="repeats of every secondary leg's timed region (median reported)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_spawn_ranks(args.gpus))   # before torch is imported: the parent never touches the GPU
+
+    # SIGTERM (a sibling rank failed and the launcher -- ours or torchrun -- stops everybody): blocked in every thread
+    # of this process (set before any library starts threads; threads inherit the mask) and received by ONE watcher
+    # thread through sigwait, which prints what has been measured so far and leaves with a distinct status.  A Python
+    # signal handler would never run here: the main thread sits inside a collective or a device synchronisation (C code).
+    import signal
+    import threading
+    signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
 
     # stdout carries exactly one thing, the JSON line: libraries that print banners there (RCCL does, at communicator
     # creation) are sent to stderr at the file-descriptor level, and the line goes out through the saved descriptor
@@ -228,14 +251,49 @@ def main():
     def step():
         f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
 
+    # the one-line result and its emitter exist before anything is timed: the SIGTERM watcher and the watchdog print
+    # whatever has been measured when they fire
+    out = {"metric": "Mpix/s for G2+H2 7-basis filter+steer at 4096x4096 f32; % HBM roofline", "value": None, "unit": "Mpix/s",
+           "n_gpus": ws, "steps": args.steps, "warmup": args.warmup}
+    extra = {}
+    done_flag = {"printed": False}
+    lock = threading.Lock()
+
+    def emit(final, why=None):
+        with lock:
+            if done_flag["printed"]:
+                return
+            done_flag["printed"] = True
+            if rank == 0:
+                if not args.no_extra:
+                    out["extra"] = dict(extra)
+                if not final:
+                    out["extra_error"] = why or "incomplete"
+                    out.setdefault("cpu_baseline", None)
+                sys.stdout.flush()
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    def sigterm_watcher():
+        signal.sigwait({signal.SIGTERM})
+        emit(False, "terminated by SIGTERM before the run finished (a sibling rank failed, or the launcher gave up); "
+                    "the line holds what had been measured")
+        os._exit(EXIT_TERMINATED)
+
+    threading.Thread(target=sigterm_watcher, daemon=True).start()
+
     for _ in range(INIT_CALLS):
         step()
     torch.cuda.synchronize()
-    wall, ev_ms = _time_steps(torch, step, args.steps, args.warmup, barrier)
-    wall, ev_ms = max_over_ranks(wall, ev_ms)
+    R = max(1, args.repeats)
+    walls, evs = _time_steps(torch, step, args.steps, args.warmup, barrier, repeats=R)
+    # per repeat: the slowest rank; then the median over the repeats
+    both = max_over_ranks(*(walls + evs))
+    walls, evs = list(both[:R]), list(both[R:])
+    wall, ev_ms = _median(walls), _median(evs)
     value = ws * args.steps * npix / wall / 1e6
-    k_ms = ev_ms / args.steps  # average launch-to-launch duration of the single kernel, HIP events
+    k_ms = ev_ms / args.steps  # average launch-to-launch duration of the single kernel, HIP events on the launch stream
     achieved = BYTES_PER_PIX["M2"] * npix / (k_ms * 1e-3) / 1e9
+    achieved_wall = BYTES_PER_PIX["M2"] * npix / (wall / args.steps) / 1e9
 
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -246,49 +304,43 @@ def main():
         except Exception:
             traffic = None
 
-    out = {
-        "metric": "Mpix/s for G2+H2 7-basis filter+steer at 4096x4096 f32; % HBM roofline",
-        "value": round(value, 1), "unit": "Mpix/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+    info = f.launch_info()
+    out.update({
+        "value": round(value, 1), "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeats": {"repeats": R, "of": "the %d-step timed region (barrier + synchronize on both sides, slowest rank per repeat)" % args.steps,
+                    "ms_per_step": {"min": round(min(walls) / args.steps * 1e3, 5), "median": round(wall / args.steps * 1e3, 5),
+                                    "max": round(max(walls) / args.steps * 1e3, 5)},
+                    "Mpix/s": {"min": round(ws * args.steps * npix / max(walls) / 1e6, 1), "median": round(value, 1),
+                               "max": round(ws * args.steps * npix / min(walls) / 1e6, 1)},
+                    "event_ms_per_launch": {"min": round(min(evs) / args.steps, 5), "median": round(k_ms, 5), "max": round(max(evs) / args.steps, 5)}},
         "config": {"workload": "G2+H2 7-basis separable pass + scalar steer (theta=0.3), one 4096x4096 f32 image "
                                "per GPU per step, image resident in HBM, bases persisted (BASELINE configs[1])",
                    "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective",
-                   "init_calls": INIT_CALLS, "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process")},
+                   "init_calls": INIT_CALLS, "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process"),
+                   "placement": {"mode": info["placement_mode"], "window_found": bool(info["window_found"]), "probe_ms": round(info["probe_ms"], 3),
+                                 "note": "CVS_OPT_PLACEMENT_SEARCH of the headline handle (0 = plain hipMalloc block, the library default)"},
+                   "launch": {"block_order": info["block_order"], "xcd_weights": info["xcd_weights"], "strip_rows": info["strip_rows"],
+                              "nt_stores": info["nt_stores"], "note": "configuration of the timed launches: engine defaults or what the launch-order tuner kept"}},
+        "clocks": {"value": "host wall clock around the timed region, median of the repeats",
+                   "roofline": "HIP events on the launch stream around the same region, median of the repeats; roofline.frac_wall = the same from the wall clock"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_wall": round(achieved_wall / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "cvs::k_basis<BankG2, F_STEER>", "algorithmic_bytes_per_launch": BYTES_PER_PIX["M2"] * npix,
                      "avg_launch_ms": round(k_ms, 5)},
-    }
+    })
 
     # ---- secondary legs (reported, not the headline) ----
     # Insurance for runs with several ranks: the secondary legs contain collectives (barriers, the RCCL scatter / gather
     # of `C4_e2e`) that have only ever run on one GPU here.  If a rank fails inside a leg, the others would wait in a
     # collective for ever and the headline measured above would be lost with them.  A watchdog armed for the secondary
     # legs makes every rank leave after `--extra-timeout` seconds: rank 0 prints the JSON line with the headline, the
-    # legs finished so far and an `extra_error` note, and all ranks exit with status 0.
-    import threading
-    extra = {}
-    done_flag = {"printed": False}
-    lock = threading.Lock()
-
-    def emit(final):
-        with lock:
-            if done_flag["printed"]:
-                return
-            done_flag["printed"] = True
-            if rank == 0:
-                if not args.no_extra:
-                    out["extra"] = dict(extra)
-                if not final:
-                    out["extra_error"] = "secondary legs did not finish within %d s (watchdog); headline unaffected" % args.extra_timeout
-                    out.setdefault("cpu_baseline", None)
-                sys.stdout.flush()
-                os.write(json_fd, (json.dumps(out) + "\n").encode())
-
+    # legs finished so far and an `extra_error` note, and all ranks exit with status EXIT_WATCHDOG (non-zero).  A rank
+    # that CRASHES is covered by the SIGTERM watcher above (the launcher stops the siblings; rank 0 prints first).
     def watchdog():
-        emit(False)
-        os._exit(0)
+        emit(False, "secondary legs did not finish within %d s (watchdog); headline unaffected" % args.extra_timeout)
+        os._exit(EXIT_WATCHDOG)   # non-zero: a hung or failed set of secondary legs must not look like a clean run
 
     timer = None
     if not args.no_extra and args.extra_timeout > 0:
@@ -303,9 +355,17 @@ def main():
             return {"Mpix/s": round(pix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5), "GB/s": round(bpp * pix / (ms * 1e-3) / 1e9, 1),
                     "frac_hbm": round(bpp * pix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": bpp}
 
+        LR = max(1, args.leg_repeats)
+
+        def timed(fn, steps, warm):
+            """median / min / max over LR repeats of the HIP-event time per step (slowest rank per repeat)"""
+            _w, e_ = _time_steps(torch, fn, steps, warm, barrier, repeats=LR)
+            per = sorted(v / steps for v in max_over_ranks(*e_))
+            return _median(per), per[0], per[-1]
+
         def leg(name, fn, bpp, pix=npix, steps=None, warm=None):
-            w_, e_ = _time_steps(torch, fn, steps or ksteps, kwarm if warm is None else warm, barrier)
-            extra[name] = rate(e_ / (steps or ksteps), bpp, pix)
+            ms, lo, hi = timed(fn, steps or ksteps, kwarm if warm is None else warm)
+            extra[name] = dict(rate(ms, bpp, pix), ms_min=round(lo, 5), ms_max=round(hi, 5), repeats=LR)
 
         # the headline loop re-filters ONE 64 MiB image, which can stay resident in the 256 MiB Infinity Cache
         # between steps; this leg rotates 8 distinct images (512 MiB) so every input read comes from HBM
@@ -360,6 +420,26 @@ def main():
                                       note="one new handle per image, a different image each time; median of 10; "
                                            "ms = events around the single call, ms_object = create+call+sync+destroy wall")
         del imgs8
+
+        # the headline loop once more with the OPT-IN placement search switched on (cvs_state.cpp): what a window of state
+        # planes that straddles a run boundary of the VRAM allocator is worth on THIS box -- or that none was found
+        try:
+            torch.cuda.synchronize()
+            cv.lib().cvs_release_cached_memory()
+            fp_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            fp_.set_option(L.OPT_PLACEMENT_SEARCH, 1)
+            for _ in range(INIT_CALLS):
+                fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
+            leg("M2_placement_search", lambda: fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], warm=max(2, args.warmup))
+            pi_ = fp_.launch_info()
+            extra["M2_placement_search"].update({"window_found": bool(pi_["window_found"]), "probe_ms": round(pi_["probe_ms"], 3),
+                                                 "block_order": pi_["block_order"], "xcd_weights": pi_["xcd_weights"], "strip_rows": pi_["strip_rows"],
+                                                 "note": "CVS_OPT_PLACEMENT_SEARCH = 1 (opt-in), otherwise the headline loop; the headline itself runs with 0"})
+            del fp_
+            torch.cuda.synchronize()
+            cv.lib().cvs_release_cached_memory()
+        except Exception as ex:
+            extra["M2_placement_search"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
         if ws == 1:
             # (for a second or two after gigabytes of device memory have been released -- the spare pieces of a placement
@@ -483,11 +563,10 @@ def main():
             alt["i"] ^= 1
             ff.pipeline_batch(fsets[alt["i"]], out=fout)
 
-        w_, e_ = _time_steps(torch, step_c4, csteps, WARM_NEW, barrier)
-        (ms,) = max_over_ranks(e_ / csteps)
+        ms, ms_lo, ms_hi = timed(step_c4, csteps, WARM_NEW)
         fp = nfr * 1080 * 1920
         extra["C4_32x1080p_pipeline_batch"] = dict(rate(ms, 84, ws * fp), ms_per_frame=round(ms / nfr, 5), launches_per_batch=1,
-                                                   frames_per_gpu=nfr, timed_steps=csteps, frame_sets=2)
+                                                   frames_per_gpu=nfr, timed_steps=csteps, frame_sets=2, ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR)
         ff.set_persist(False)
         fo3 = torch.empty((nfr, 3, 1080, 1920), device=dev)
 
@@ -495,9 +574,9 @@ def main():
             alt["i"] ^= 1
             ff.pipeline_batch(fsets[alt["i"]], out=fo3, outputs=(5, 6, 7))
 
-        w_, e_ = _time_steps(torch, step_c4f, csteps, WARM_NEW, barrier)
-        (ms,) = max_over_ranks(e_ / csteps)
+        ms, ms_lo, ms_hi = timed(step_c4f, csteps, WARM_NEW)
         extra["C4_32x1080p_feature_maps_only"] = dict(rate(ms, 16, ws * fp), ms_per_frame=round(ms / nfr, 5), timed_steps=csteps,
+                                                      ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR,
                                                       note="edges + dark + bright only, no state persisted (what example/steer.cpp keeps)")
         del fout, fo3
 
@@ -606,9 +685,10 @@ def main():
                         hnd.setup(cur, flags=cv.SETUP_BASIS)
 
             c3 = max(10, args.steps // 10)
-            w_, e_ = _time_steps(torch, pyr_filter, c3, WARM_NEW, barrier)
-            w2_, e2_ = _time_steps(torch, lambda: fp3.pyramid(bigs[0], 5), c3, 2, barrier)
-            w3_, e3_ = _time_steps(torch, pyr_whole, c3, WARM_NEW, barrier)
+            e_, _lo, _hi = timed(pyr_filter, c3, WARM_NEW)
+            e2_, _lo, _hi = timed(lambda: fp3.pyramid(bigs[0], 5), c3, 2)
+            e3_, e3_lo, e3_hi = timed(pyr_whole, c3, WARM_NEW)
+            e_, e2_, e3_ = e_ * c3, e2_ * c3, e3_ * c3
             # algorithmic bytes of the whole configuration: 4 B read + 28 B written per pixel of every level, plus the
             # 4 B written per pixel of every level that is made here (levels 1..4)
             whole_bytes = 32 * ppix + 4 * (ppix - lv[0].shape[0] * lv[0].shape[1])
@@ -618,13 +698,44 @@ def main():
                                                 "filter_Mpix/s": round(ppix / (e_ / c3 * 1e-3) / 1e6, 1), "filter_ms": round(e_ / c3, 4),
                                                 "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                 "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix, "timed_steps": c3,
+                                                "whole_ms_min": round(e3_lo, 4), "whole_ms_max": round(e3_hi, 4), "repeats": LR,
                                                 "note": "whole = build + filter, level k+1 written by the filter launch of level k, two alternating images; "
                                                         "filter = five filter launches on a prebuilt pyramid; separate build + filter = filter_ms + pyramid_build_ms"}
             del bigs, lv, hp, fp3
+        if ws > 1 and not test_backend:
+            # BASELINE config 3 over the ranks (one large image, every level split into row bands): the native
+            # entry cvs_batch_pyramid_setup -- ncclBroadcast of the 8192^2 image from rank 0, every rank builds the (cheap)
+            # pyramid and filters its band of every level, the bands are gathered into rank 0's state planes.  Phase times
+            # are HIP events on the ranks' streams (slowest rank).  Never run on more than one GPU before the driver's node.
+            try:
+                pb = batch.NativeBatch.from_torch_distributed(local_rank)
+                big = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32) if rank == 0 else None
+                reps, acc, wall3 = 3, {"broadcast": 0.0, "compute": 0.0, "gather": 0.0}, 0.0
+                for rep in range(reps + 1):
+                    torch.cuda.synchronize(); barrier(); t0 = time.perf_counter()
+                    tm = pb.pyramid_setup(big, 8192, 8192, 5, flags=cv.SETUP_BASIS, root=0)
+                    barrier(); dt = time.perf_counter() - t0
+                    if rep:
+                        wall3 += dt / reps
+                        for k in acc:
+                            acc[k] += tm[k] / reps
+                acc = dict(zip(acc.keys(), max_over_ranks(*acc.values())))
+                (wall3,) = max_over_ranks(wall3)
+                ppix3 = sum((8192 >> l) ** 2 for l in range(5))
+                extra["C3_pyramid_8192_5_levels_band_split"] = {
+                    "ranks": ws, "ms": {k: round(v, 3) for k, v in acc.items()}, "ms_wall": round(wall3 * 1e3, 3),
+                    "compute_only_Mpix/s": round(ppix3 / (acc["compute"] * 1e-3) / 1e6, 1), "end_to_end_Mpix/s": round(ppix3 / wall3 / 1e6, 1),
+                    "entry": "cvs_batch_pyramid_setup", "transport": pb.transport,
+                    "note": "image on rank 0 -> ncclBroadcast -> every rank: pyramid + its row band of every level -> bands gathered into rank 0's state"}
+                pb.close()
+                del big
+            except Exception as ex:
+                extra["C3_pyramid_8192_5_levels_band_split"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if timer is not None:
         timer.cancel()
 
-    if rank == 0 and ws == 1 and not args.no_cpu:
+    # the CPU baseline runs on rank 0's host cores (the other ranks wait in the final barrier)
+    if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = _cpu_baseline(THETA)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -369,7 +369,8 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
             h->state_elems = 0;
         }
         const size_t elems = stride * nplanes * (size_t)nframes;
-        if (!pool_take(h->device, elems, want_planes, stride * sizeof(float), nplanes, h->sb)) {
+        const bool from_pool = pool_take(h->device, elems, want_planes, stride * sizeof(float), nplanes, h->sb);
+        if (!from_pool) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(h->stream, &cap);
             if (want_planes && cap == hipStreamCaptureStatusNone) HIP_TRY(h, state_block_alloc_planes(h->device, nplanes, rows, pitch, h->stream, h->placement, h->sb));
@@ -380,7 +381,7 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
             g_no_window.insert(geo);
         }
         h->window_found = h->sb.vmm ? 1 : 0;
-        h->probe_ms = h->sb.probed ? h->sb.probe_ms : 0.f;
+        h->probe_ms = (!from_pool && h->sb.probed) ? h->sb.probe_ms : 0.f;  // a parked block was paid for by an earlier handle
         h->state = h->sb.base;
         h->state_elems = h->sb.elems;
         h->placed_stride = want_planes ? stride : 0;
