@@ -41,6 +41,7 @@ BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56}
 # that one line shows what a window is worth on the box it ran on).  `M2_untuned` / `M2_first_call` = no tuner either.
 INIT_CALLS = 4
 EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
+EXIT_LEGS_FAILED = 5  # a secondary leg raised: headline + the legs finished so far are printed first
 EXIT_TERMINATED = 4   # SIGTERM (another rank failed / the launcher gave up): whatever was measured is printed first
 
 
@@ -347,7 +348,9 @@ def main():
         timer = threading.Timer(args.extra_timeout, watchdog)
         timer.daemon = True
         timer.start()
-    if not args.no_extra:
+    def run_extras():
+        if os.environ.get("CVS_BENCH_TEST_CRASH_RANK") == str(rank):   # tests only: a rank that dies inside the secondary legs
+            os._exit(17)
         ksteps, kwarm = args.steps, max(10, args.warmup // 2)
         WARM_NEW = 6   # a new handle / new shape: first call + the one tuning call happen in here
 
@@ -731,6 +734,14 @@ def main():
                 del big
             except Exception as ex:
                 extra["C3_pyramid_8192_5_levels_band_split"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    if not args.no_extra:
+        try:
+            run_extras()
+        except Exception as ex:   # a failing leg must not take the headline with it: print what exists, leave non-zero
+            import traceback
+            traceback.print_exc()
+            emit(False, "secondary legs failed on rank %d: %s: %s; headline unaffected" % (rank, type(ex).__name__, ex))
+            os._exit(EXIT_LEGS_FAILED)
     if timer is not None:
         timer.cancel()
 

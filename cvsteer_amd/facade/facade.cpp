@@ -10,6 +10,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <typeinfo>
 
 #include "cvsteer_hip.h"
 
@@ -68,7 +69,7 @@ Mat1f taps_of(cvs_handle h, int idx, int width)
 }  // namespace
 
 // --------------------------------------------------------------------------- base
-SteerableFilters::SteerableFilters(int kind, int width, float spacing, int device) : m_handle(0), m_device(device)
+SteerableFilters::SteerableFilters(int kind, int width, float spacing, int device) : m_memberSync(true), m_handle(0), m_device(device)
 {
     int rc = cvs_create(kind, width, spacing, device, &m_handle);
     if (rc != CVS_OK) throw_status(0, rc, "cvs_create (is a HIP device present? there is no CPU fallback)");
@@ -82,6 +83,14 @@ SteerableFilters::~SteerableFilters()
 void SteerableFilters::check(int status, const char* where) const
 {
     if (status != CVS_OK) throw_status(m_handle, status, where);
+}
+
+// Only a subclass can read the protected plane members, so only objects whose dynamic type is NOT the facade class
+// itself get them filled after setup().  (Inside a base-class constructor typeid(*this) is the base class: a subclass
+// constructor that wants them calls syncMembers() itself.)
+bool SteerableFilters::memberSyncWanted(const void* exact_type_info) const
+{
+    return m_memberSync && typeid(*this) != *static_cast<const std::type_info*>(exact_type_info);
 }
 
 void SteerableFilters::synchronize() { check(cvs_sync(m_handle), "cvs_sync"); }
@@ -142,6 +151,19 @@ void SteerableFiltersG2::setup(const Mat1f& image)
     m_thetaValid = m_strengthValid = false;
     cvs_plane p = view(image);
     check(cvs_setup(m_handle, &p, CVS_SETUP_FULL), "cvs_setup");
+    if (memberSyncWanted(&typeid(SteerableFiltersG2))) syncMembers();
+}
+
+// SteerableFiltersG2.h:64-66 of the reference: m_g2a..m_h2d, m_c1..m_c3, m_theta, m_orientationStrength
+void SteerableFiltersG2::syncMembers()
+{
+    Mat1f* basis[7] = {&m_g2a, &m_g2b, &m_g2c, &m_h2a, &m_h2b, &m_h2c, &m_h2d};
+    for (int i = 0; i < 7; ++i) fetch(CVS_PLANE_BASIS0 + i, *basis[i]);
+    fetch(CVS_PLANE_C1, m_c1);
+    fetch(CVS_PLANE_C2, m_c2);
+    fetch(CVS_PLANE_C3, m_c3);
+    (void)getDominantOrientationAngle();
+    (void)getDominantOrientationStrength();
 }
 
 const Mat1f& SteerableFiltersG2::getDominantOrientationAngle() const
@@ -302,6 +324,14 @@ void SteerableFiltersG4::setup(const Mat1f& image)
 {
     cvs_plane p = view(image);
     check(cvs_setup(m_handle, &p, CVS_SETUP_BASIS), "cvs_setup");
+    if (memberSyncWanted(&typeid(SteerableFiltersG4))) syncMembers();
+}
+
+// SteerableFiltersG4.h:53-54 of the reference: m_g4a..m_g4e, m_h4a..m_h4f
+void SteerableFiltersG4::syncMembers()
+{
+    Mat1f* basis[11] = {&m_g4a, &m_g4b, &m_g4c, &m_g4d, &m_g4e, &m_h4a, &m_h4b, &m_h4c, &m_h4d, &m_h4e, &m_h4f};
+    for (int i = 0; i < 11; ++i) fetch(CVS_PLANE_BASIS0 + i, *basis[i]);
 }
 
 void SteerableFiltersG4::steer(const Mat1f& theta, Mat1f& g4, Mat1f& h4)

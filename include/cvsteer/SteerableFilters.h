@@ -36,6 +36,20 @@ protected:
     // copy state plane `which` (CVS_PLANE_*) into a host Mat1f
     void fetch(int which, Mat1f& dst) const;
 
+    // The reference keeps every intermediate plane in protected cv::Mat1f members (m_g2a.., m_c1.., SteerableFiltersG2.h:62-66,
+    // SteerableFiltersG4.h:50-56) that a subclass may read.  Here those planes live on the GPU; the members of the same names
+    // exist and are host COPIES, filled
+    //   * after every setup() that runs on an object whose dynamic type is a SUBCLASS of the facade classes (nobody but a
+    //     subclass can read protected members, so plain G2 / G4 objects never pay for the download), and
+    //   * on demand by syncMembers() -- for a subclass constructor that reads them right after the base constructor ran
+    //     (inside the base constructor the object is not yet a subclass, as in any C++ class).
+    // setMemberSync(false) switches the automatic copy off for subclasses that never read them (12 planes of 64 MiB per
+    // 4096^2 image cross the host link otherwise).
+    virtual void syncMembers() {}
+    void setMemberSync(bool on) { m_memberSync = on; }
+    bool memberSyncWanted(const void* exact_type_info) const;  // true when *this is a subclass and the copy is on
+    bool m_memberSync;
+
     cvs_context* m_handle;
     int m_device;
 

@@ -48,9 +48,16 @@ public:
                   Mat1f& edges, Mat1f& linesDark, Mat1f& linesBright);
 
 protected:
-    Mat1f m_g1, m_g2, m_g3, m_h1, m_h2, m_h3, m_h4;  // the 7 tap vectors (G2.h:63)
-    mutable Mat1f m_theta, m_orientationStrength;    // host copies, fetched lazily
+    // the reference's protected members, same names (SteerableFiltersG2.h:62-66).  m_g1..m_h4 are the 7 tap vectors; the
+    // planes m_g2a..m_h2d, m_c1..m_c3 are host copies of the GPU state, filled for subclasses (see SteerableFilters.h:
+    // after setup() on a subclass object, or by syncMembers()); m_dx / m_dy are declared and never used, as in the reference
+    Mat1f m_dx, m_dy;
+    Mat1f m_g1, m_g2, m_g3, m_h1, m_h2, m_h3, m_h4;
+    Mat1f m_g2a, m_g2b, m_g2c, m_h2a, m_h2b, m_h2c, m_h2d;
+    Mat1f m_c1, m_c2, m_c3;
+    mutable Mat1f m_theta, m_orientationStrength;    // host copies, fetched lazily by the getters
     mutable bool m_thetaValid, m_strengthValid;
+    void syncMembers();  // download m_g2a..m_h2d, m_c1..m_c3, m_theta, m_orientationStrength now
 
 private:
     void init(const Mat1f& image);

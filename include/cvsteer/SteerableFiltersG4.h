@@ -28,9 +28,15 @@ public:
     void getBasis(int index, Mat1f& dst) const;
 
 protected:
+    // the reference's protected members, same names (SteerableFiltersG4.h:50-56): 11 tap vectors; the planes m_g4a..m_h4f
+    // are host copies of the GPU state, filled for subclasses (see SteerableFilters.h); m_c1..m_c3, m_theta and
+    // m_orientationStrength are declared and never assigned, as in the reference
     Mat1f m_g1, m_g2, m_g3, m_g4, m_g5;
     Mat1f m_h1, m_h2, m_h3, m_h4, m_h5, m_h6;
-    Mat1f m_theta, m_orientationStrength;  // never assigned, as in the reference
+    Mat1f m_g4a, m_g4b, m_g4c, m_g4d, m_g4e;
+    Mat1f m_h4a, m_h4b, m_h4c, m_h4d, m_h4e, m_h4f;
+    Mat1f m_c1, m_c2, m_c3, m_theta, m_orientationStrength;
+    void syncMembers();  // download m_g4a..m_h4f now
 
 private:
     void init(const Mat1f& image);

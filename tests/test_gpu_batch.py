@@ -399,25 +399,58 @@ def test_two_processes_hip_frame_function(n_frames):
     assert q.get(timeout=5) == "ok"
 
 
+def _json_line(stdout):
+    import json
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
 def test_bench_starts_its_own_ranks_and_watchdog_emits_the_headline(tmp_path):
     """bench.py --gpus 2 without a launcher: the parent starts two rank processes before it touches the GPU (rehearsal on one
     device: CVS_BENCH_TEST_BACKEND=gloo puts both ranks on device 0), rank 0 prints ONE JSON line with n_gpus = 2; and with
-    a watchdog too short for the secondary legs every rank still exits 0 and the line carries the headline + extra_error."""
-    import json
+    a watchdog too short for the secondary legs the line still carries the headline + extra_error -- and the exit status is
+    NOT zero (a hung set of secondary legs must not look like a clean run)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CVS_BENCH_TEST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extra"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extra", "--repeats", "3"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["config"]["ranks_started_by"] == "bench.py"
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.2
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--extra-timeout", "1"],
+    assert d["repeats"]["repeats"] == 3 and d["repeats"]["Mpix/s"]["min"] <= d["value"] <= d["repeats"]["Mpix/s"]["max"]
+    assert d["config"]["placement"] == {"mode": 0, "window_found": False, "probe_ms": 0.0, "note": d["config"]["placement"]["note"]}
+    assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"        # rank 0 measures it for N > 1 as well
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--extra-timeout", "1", "--repeats", "3"],
                        env=os.environ, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and "extra_error" in d
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "watchdog" in d["extra_error"]
+
+
+def test_bench_two_ranks_with_the_secondary_legs_and_a_crashing_rank(tmp_path):
+    """the N > 1 rehearsal WITH the secondary legs (round-2 verdict: the rehearsal passed --no-extra): both ranks on device 0,
+    gloo for the collectives, every leg that does not need an RCCL communicator runs with its barriers and its
+    max-over-ranks reductions; then the same with rank 1 dying inside the legs -- the parent stops rank 0 with SIGTERM, whose
+    watcher thread still prints the line (headline + extra_error), and the parent's status is non-zero."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVS_BENCH_TEST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "3", "--leg-repeats", "1", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and "extra_error" not in d
+    ex = d["extra"]
+    for leg in ("M2_rotating_8_inputs", "M2_untuned", "M2_first_call", "M2_placement_search", "C4_32x1080p_pipeline_batch", "C4_32x1080p_feature_maps_only"):
+        assert leg in ex and "error" not in ex[leg], (leg, ex.get(leg))
+    assert ex["C4_32x1080p_pipeline_batch"]["frames_per_gpu"] == 32 and ex["C4_32x1080p_pipeline_batch"]["Mpix/s"] > 0
+    r = subprocess.run(cmd, env=dict(env, CVS_BENCH_TEST_CRASH_RANK="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+    d = _json_line(r.stdout)
+    # rank 0 learns of it either from the parent's SIGTERM or from its own collective failing (gloo notices a dead peer)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and ("SIGTERM" in d["extra_error"] or "secondary legs failed" in d["extra_error"])

@@ -56,6 +56,18 @@ def test_cpp_facade_protected_create_and_wrap():
     assert "cvsteer.protected OK" in r.stdout
 
 
+def test_cpp_subclass_written_like_the_reference_reads_protected_members():
+    """code that EXTENDS the reference: tests/cpp/test_subclass.cpp is written inside _STEER_BEGIN / _STEER_END
+    (cvsteer/cvsteer.h:12-15) and reads m_g2a..m_h2d, m_c1..m_c3, m_theta (SteerableFiltersG2.h:62-66) and m_g4a..m_h4f
+    (SteerableFiltersG4.h:53-54) from subclasses; the facade fills those host copies for subclass objects."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_subclass")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cvsteer_amd", "facade"), "-s"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cvsteer.subclass OK" in r.stdout
+
+
 def test_cpp_batch_driver_matches_goldens_and_python_driver(tmp_path):
     """cvsteer_amd/cvsteer-run (facade/cvsteer_run.cpp): the reference's example/steer.cpp flow in C++ over the C ABI --
     host planes into cvs_batch_run, maps kept on the GPUs, 8-bit conversion on the GPU.  Checked against the reference's
