@@ -117,6 +117,36 @@ __device__ __forceinline__ float phase_lambda(float phase, float phi, bool signu
     return l;
 }
 
+// findEdges / findDarkLines / findBrightLines (G2.cpp:194-212) for ONE phase value: the three phaseWeights of the callers'
+// sequence (test/test.cpp:88-90) -- phi = pi/2 unsigned, phi = 0 signed, phi = pi signed -- from one cosine / sine pair.
+// phaseWeights forms err_phi, folds it with min(err, 2 pi - err), and takes cos^2(err); cos^2 does not see that fold, and
+//   phi = pi/2, unsigned:  cos^2(| |p| - pi/2 |) = sin^2(|p|)
+//   phi = 0,    signed:    cos^2(| p |)          = cos^2(|p|)     (the very evaluation phaseWeights makes: bit-identical)
+//   phi = pi,   signed:    cos^2(| p - pi |)     = cos^2(|p|)
+// for every p, so one sincos(|p|) serves all three; the gates (lambda = 0 where the folded error exceeds pi/2) are
+// evaluated exactly as phaseWeights evaluates them.  Against the one-at-a-time evaluation the values differ by what the
+// reference's own float steps (|p| - float(pi/2), p - float(pi), 2 float(pi) - err) round away: <= 4e-7 for p in
+// [-pi, pi], inside the 1e-6 stage tolerance (round-2 verdict item 5; tests/test_gpu_parity.py).  Two of the three
+// bounded cos / sin evaluations per pixel go away -- the stateless pipeline launch is VALU-bound.
+// BOUNDED: the caller guarantees |phase| <= 8 (the engine's own phase planes lie in (-pi, pi]).
+template <bool BOUNDED = false>
+__device__ __forceinline__ void phase_lambda3(float phase, float& l_edges, float& l_dark, float& l_bright)
+{
+    const float ap = fabsf(phase);
+    float s, c;
+    if constexpr (BOUNDED) sincos_small(ap, s, c);
+    else sincos_any(ap, s, c);
+    const float s2 = __fmul_rn(s, s), c2 = __fmul_rn(c, c);
+    float ee = fabsf(__fsub_rn(ap, fabsf(kHalfPiF)));       // signum = false: | |phase| - |phi| |
+    ee = fminf(ee, __fsub_rn(kTwoPiF, ee));
+    const float ed = fminf(ap, __fsub_rn(kTwoPiF, ap));     // signum = true, phi = 0: |phase - 0|
+    float eb = fabsf(__fsub_rn(phase, kPiF));               // signum = true, phi = pi
+    eb = fminf(eb, __fsub_rn(kTwoPiF, eb));
+    l_edges = fabsf(ee) > kHalfPiF ? 0.f : s2;
+    l_dark = fabsf(ed) > kHalfPiF ? 0.f : c2;
+    l_bright = fabsf(eb) > kHalfPiF ? 0.f : c2;
+}
+
 // G2.cpp:70-99: products, C1..C3, cartToPolar, wrap, *0.5.  b = {g2a,g2b,g2c,h2a,h2b,h2c,h2d}.
 // need_c1 = false skips C1 (only the oriented energy e uses it); callers that store C1 pass true
 __device__ inline void g2_orientation(const float b[7], int mode, float& c1, float& c2, float& c3,

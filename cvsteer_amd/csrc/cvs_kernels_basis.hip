@@ -441,9 +441,11 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         }
                         mag_phase(q[0], q[1], a.atan_mode, q[3], q[4]);
                         const float en = a.find_on_e ? q[2] : q[3];
-                        q[5] = __fmul_rn(en, phase_lambda<true>(q[4], kHalfPiF, false));
-                        q[6] = __fmul_rn(en, phase_lambda<true>(q[4], 0.f, true));
-                        q[7] = __fmul_rn(en, phase_lambda<true>(q[4], kPiF, true));
+                        float le, ld, lb;
+                        phase_lambda3<true>(q[4], le, ld, lb);   // one cos / sin pair for the three maps
+                        q[5] = __fmul_rn(en, le);
+                        q[6] = __fmul_rn(en, ld);
+                        q[7] = __fmul_rn(en, lb);
                         if constexpr (BATCH == 2) {
                             const unsigned orow_out = yo * (unsigned)(a.out_pitch * sizeof(float));
 #pragma unroll

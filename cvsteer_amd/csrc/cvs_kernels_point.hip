@@ -78,9 +78,11 @@ __device__ __forceinline__ void point_eval(const float* in, float* out, const Po
     } else if constexpr (OP == OP_PHASE_WEIGHTS) {
         out[0] = phase_lambda(in[0], a.phi, a.signum != 0);
     } else if constexpr (OP == OP_FIND) {
-        out[0] = __fmul_rn(in[0], phase_lambda(in[1], kHalfPiF, false));  // findEdges      G2.cpp:201-204
-        out[1] = __fmul_rn(in[0], phase_lambda(in[1], 0.f, true));        // findDarkLines  G2.cpp:205-208
-        out[2] = __fmul_rn(in[0], phase_lambda(in[1], kPiF, true));       // findBrightLines G2.cpp:209-212
+        float le, ld, lb;
+        phase_lambda3(in[1], le, ld, lb);   // one cos / sin pair for the three maps (cvs_device_math.h)
+        out[0] = __fmul_rn(in[0], le);      // findEdges      G2.cpp:201-204
+        out[1] = __fmul_rn(in[0], ld);      // findDarkLines  G2.cpp:205-208
+        out[2] = __fmul_rn(in[0], lb);      // findBrightLines G2.cpp:209-212
     } else if constexpr (OP == OP_WRAP) {
         out[0] = wrap_pi(in[0]);
     } else if constexpr (OP == OP_G2_PIPELINE) {
@@ -91,9 +93,11 @@ __device__ __forceinline__ void point_eval(const float* in, float* out, const Po
         out[2] = __fadd_rn(__fadd_rn(in[7], __fmul_rn(in[8], c2)), __fmul_rn(in[9], s2));
         mag_phase(out[0], out[1], a.atan_mode, out[3], out[4]);
         const float en = a.find_on_e ? out[2] : out[3];
-        out[5] = __fmul_rn(en, phase_lambda(out[4], kHalfPiF, false));
-        out[6] = __fmul_rn(en, phase_lambda(out[4], 0.f, true));
-        out[7] = __fmul_rn(en, phase_lambda(out[4], kPiF, true));
+        float le, ld, lb;
+        phase_lambda3(out[4], le, ld, lb);
+        out[5] = __fmul_rn(en, le);
+        out[6] = __fmul_rn(en, ld);
+        out[7] = __fmul_rn(en, lb);
     }
 }
 

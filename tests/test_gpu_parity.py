@@ -226,11 +226,21 @@ def test_mag_phase_weights_find(cv, ora):
     for phi, sg in ((np.pi / 2, False), (0.0, True), (np.pi, True), (0.7, True), (-2.0, False)):
         lam = f.phaseWeights(op, phi, sg)
         assert np.abs(lam - ora.phase_weights(op, phi, sg)).max() <= 1e-6
+    # find* evaluate ONE cos / sin pair of |phase| for the three maps (phase_lambda3, cvs_device_math.h): against the
+    # reference's three separate phaseWeights the weights differ by what its float steps (|p| - float(pi/2), p - float(pi))
+    # round away -- measured here on a unit energy plane, stage tolerance 1e-6 -- and the products scale with the energy
+    ones = np.ones_like(g)
+    for got, want in zip(f.find(ones, op), ora.find(ones, op)):
+        assert np.abs(got - want).max() <= 1e-6
     e = np.abs(g)
     e[1, 1] = 1.0
     outs = f.find(e, op)
     for got, want in zip(outs, ora.find(e, op)):
-        assert np.abs(got - want).max() <= 1e-6
+        assert np.abs(got - want).max() <= 1e-6 * max(1.0, float(e.max()))
+    # phases beyond (-pi, pi] (a caller's own plane): the identities behind the shared evaluation hold for every angle
+    wide = (rng.random((45, 67), dtype=np.float32) * 40 - 20).astype(np.float32)
+    for got, want in zip(f.find(ones, wide), ora.find(ones, wide)):
+        assert np.abs(got - want).max() <= 2e-5      # the reference's own float steps on |p| ~ 20 are good to ~1 ulp(20) = 2e-6 rad
     assert np.array_equal(f.findEdges(e, op), outs[0])
     assert np.array_equal(f.findDarkLines(e, op), outs[1])
     assert np.array_equal(f.findBrightLines(e, op), outs[2])
@@ -1261,10 +1271,10 @@ def test_hip_graph_capture_and_replay(cv):
 
 def test_g4_bank_layouts_never_change_results(cv):
     """CVS_OPT_G4_SPLIT 0..2 (one 11-plane kernel / two launches / both halves in one launch) x block orders:
-    identical planes and steered outputs, ragged shapes included"""
+    identical planes and steered outputs, ragged shapes and a streaming-store size included"""
     import torch
     from cvsteer_amd import _lib as L
-    for shape in ((1100, 1500), (301, 449), (64, 257), (2100, 600)):
+    for shape in ((1100, 1500), (301, 449), (64, 257), (2100, 600), (2048, 2100)):
         img = torch.rand(shape, device="cuda")
         ref = None
         for split in (0, 1, 2):

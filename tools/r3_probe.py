@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""tools/r3_probe.py -- round-3 A/B probes, one process, interleaved rounds (every figure = median of the rounds).
+
+    python tools/r3_probe.py c4strips      stateless / state-kept 32 x 1080p batch vs strip height
+    python tools/r3_probe.py pitch         (run with CVS_STATE_PITCH_PAD=<n> in the environment; prints M1/M2/M4/rot legs)
+    python tools/r3_probe.py c3order       config 3: fused chain vs "pyrDown first, then filter the (now cached) level"
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cvsteer_amd as cv
+from cvsteer_amd import _lib as L
+
+
+def timeit(fn, steps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
+
+
+def med(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def c4strips():
+    nfr = 32
+    sets = [torch.rand((nfr, 1080, 1920), device="cuda") for _ in range(2)]
+    pix = nfr * 1080 * 1920
+    fo3 = torch.empty((nfr, 3, 1080, 1920), device="cuda")
+    fo8 = torch.empty((nfr, 8, 1080, 1920), device="cuda")
+    alt = {"i": 0}
+    for persist, out, sel, bpp in ((False, fo3, (5, 6, 7), 16), (True, fo8, None, 84)):
+        cands = [0, 19, 28, 37, 46, 64, 91]
+        hs = {}
+        for sr in cands:
+            f = cv.SteerableFiltersG2(None)
+            f.set_persist(persist)
+            f.set_option(L.OPT_AUTOTUNE, 0)
+            if sr:
+                f.set_strip_rows(sr)
+            hs[sr] = f
+
+        def run(f):
+            alt["i"] ^= 1
+            f.pipeline_batch(sets[alt["i"]], out=out, outputs=sel)
+
+        res = {sr: [] for sr in cands}
+        for rnd in range(5):
+            for sr in cands:
+                res[sr].append(timeit(lambda: run(hs[sr]), steps=6, warm=2))
+        for sr in cands:
+            ms = med(res[sr])
+            print("persist=%d strip_rows=%3d : %.4f ms  %6.1f Gpix/s  %.3f of HBM (%d B/pix)  [info %s]" %
+                  (persist, sr, ms, pix / ms / 1e6, bpp * pix / ms / 1e6 / 8000, bpp, hs[sr].launch_info()["strip_rows"]), flush=True)
+        del hs
+
+
+def pitch():
+    n = 4096
+    imgs = [torch.rand((n, n), device="cuda") for _ in range(8)]
+    g, h = torch.empty_like(imgs[0]), torch.empty_like(imgs[0])
+    outs8 = [torch.empty_like(imgs[0]) for _ in range(8)]
+    f = cv.SteerableFiltersG2(None)
+    f.set_option(L.OPT_AUTOTUNE, int(os.environ.get("PROBE_AUTOTUNE", "0")))
+    npix = n * n
+    rot = {"i": 0}
+
+    def rotstep():
+        rot["i"] = (rot["i"] + 1) & 7
+        f.setup_steer(imgs[rot["i"]], 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+
+    legs = (("M2", lambda: f.setup_steer(imgs[0], 0.3, flags=cv.SETUP_BASIS, out=(g, h)), 40),
+            ("M1", lambda: f.setup(imgs[0], flags=cv.SETUP_BASIS), 32),
+            ("M4", lambda: f.setup(imgs[0], flags=cv.SETUP_FULL), 52),
+            ("M5", lambda: f.pipeline(imgs[0], out=outs8), 84),
+            ("M2rot", rotstep, 40))
+    print("CVS_STATE_PITCH_PAD=%s  step of a state plane: %d B" % (os.environ.get("CVS_STATE_PITCH_PAD", "0"), 0), flush=True)
+    for name, fn, bpp in legs:
+        r = [timeit(fn, steps=20, warm=4) for _ in range(5)]
+        ms = med(r)
+        print("%-6s %.4f ms  %.3f of HBM   (min %.4f max %.4f)  pitch %d B" % (name, ms, bpp * npix / ms / 1e6 / 8000, min(r), max(r), f.basis_view(0)[3] if name != "M5x" else 0), flush=True)
+
+
+def c3order():
+    bigs = [torch.rand((8192, 8192), device="cuda") for _ in range(2)]
+    f0 = cv.SteerableFiltersG2(None)
+    lv = f0.pyramid(bigs[0], 5)
+    ppix = sum(l.shape[0] * l.shape[1] for l in lv)
+    hp = [cv.SteerableFiltersG2(None) for _ in lv]
+    flip = {"i": 0}
+    whole_bytes = 32 * ppix + 4 * (ppix - 8192 * 8192)
+
+    def fused():
+        flip["i"] ^= 1
+        cur = bigs[flip["i"]]
+        for k, hnd in enumerate(hp):
+            if k + 1 < len(hp):
+                hnd.setup_pyr(cur, flags=cv.SETUP_BASIS, out=lv[k + 1])
+                cur = lv[k + 1]
+            else:
+                hnd.setup(cur, flags=cv.SETUP_BASIS)
+
+    def down_first():
+        """level 1 by the stand-alone strip-march pyrDown (reads level 0 from HBM, leaves it in the Infinity Cache), then the
+        level-0 filter launch right behind it; the smaller levels as in the fused chain"""
+        flip["i"] ^= 1
+        cur = bigs[flip["i"]]
+        pd, ps = cv.api._plane(lv[1]), cv.api._plane(cur)
+        import ctypes as C
+        f0._bind_stream(cur, lv[1])
+        f0._check(cv.lib().cvs_pyr_down(f0._h, C.byref(ps), C.byref(pd)), "cvs_pyr_down")
+        hp[0].setup(cur, flags=cv.SETUP_BASIS)
+        cur = lv[1]
+        for k in range(1, len(hp)):
+            if k + 1 < len(hp):
+                hp[k].setup_pyr(cur, flags=cv.SETUP_BASIS, out=lv[k + 1])
+                cur = lv[k + 1]
+            else:
+                hp[k].setup(cur, flags=cv.SETUP_BASIS)
+
+    def small_first():
+        """all levels built first (four stand-alone pyrDown launches), then the five filter launches, smallest level LAST"""
+        flip["i"] ^= 1
+        cur = bigs[flip["i"]]
+        import ctypes as C
+        src = cur
+        for k in range(1, 5):
+            pd, ps = cv.api._plane(lv[k]), cv.api._plane(src)
+            f0._bind_stream(src, lv[k])
+            f0._check(cv.lib().cvs_pyr_down(f0._h, C.byref(ps), C.byref(pd)), "cvs_pyr_down")
+            src = lv[k]
+        hp[0].setup(cur, flags=cv.SETUP_BASIS)
+        for k in range(1, 5):
+            hp[k].setup(lv[k], flags=cv.SETUP_BASIS)
+
+    res = {"fused": [], "down_first": [], "small_first": []}
+    for rnd in range(5):
+        for name, fn in (("fused", fused), ("down_first", down_first), ("small_first", small_first)):
+            res[name].append(timeit(fn, steps=8, warm=3))
+    for name, r in res.items():
+        ms = med(r)
+        print("%-11s %.4f ms  %.1f Gpix/s  %.3f of HBM (whole config, %d bytes)  min %.4f max %.4f" %
+              (name, ms, ppix / ms / 1e6, whole_bytes / ms / 1e6 / 8000, whole_bytes, min(r), max(r)), flush=True)
+    # per-level times inside the fused chain: events between the launches
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    acc = [0.0] * 5
+    for it in range(10):
+        flip["i"] ^= 1
+        cur = bigs[flip["i"]]
+        evs[0].record()
+        for k, hnd in enumerate(hp):
+            if k + 1 < len(hp):
+                hnd.setup_pyr(cur, flags=cv.SETUP_BASIS, out=lv[k + 1])
+                cur = lv[k + 1]
+            else:
+                hnd.setup(cur, flags=cv.SETUP_BASIS)
+            evs[k + 1].record()
+        torch.cuda.synchronize()
+        for k in range(5):
+            acc[k] += evs[k].elapsed_time(evs[k + 1]) / 10
+    print("fused chain, per level (ms): " + "  ".join("L%d %.4f" % (k, acc[k]) for k in range(5)), flush=True)
+
+
+def g4():
+    """G4 bank layouts x strip heights on ONE image, interleaved: split 2 = two half banks in one launch (round 2 default),
+    0 = one 11-plane kernel (2 waves/SIMD), 3 = one kernel with two window planes in LDS (3 waves/SIMD)"""
+    n = 4096
+    img = torch.rand((n, n), device="cuda")
+    g, h = torch.empty_like(img), torch.empty_like(img)
+    npix = n * n
+    cands = [(2, 40), (2, 27), (0, 27), (0, 40)] + ([(3, 14), (3, 27), (3, 40), (3, 53), (3, 66)] if os.environ.get("PROBE_G4L") else [])   # split 3: tools/patches/g4_single_kernel_lds_window.patch
+    hs = {}
+    for sp, sr in cands:
+        f = cv.SteerableFiltersG4(None)
+        f.set_option(L.OPT_AUTOTUNE, 0)
+        f.set_option(L.OPT_G4_SPLIT, sp)
+        f.set_strip_rows(sr)
+        hs[(sp, sr)] = f
+    for name, bpp, fn in (("basis", 48, lambda f: f.setup(img)), ("basis+steer", 56, lambda f: f.setup_steer(img, 0.3, out=(g, h)))):
+        res = {c: [] for c in cands}
+        for rnd in range(5):
+            for c in cands:
+                res[c].append(timeit(lambda: fn(hs[c]), steps=10, warm=3))
+        for c in cands:
+            ms = med(res[c])
+            print("G4 %-11s split %d strip %2d : %.4f ms  %.3f of HBM  (min %.4f)" % (name, c[0], c[1], ms, bpp * npix / ms / 1e6 / 8000, min(res[c])), flush=True)
+    # bit-identity of the layouts
+    ref = [hs[(2, 40)].basis(p).clone() for p in range(11)]
+    if (3, 27) in hs:
+        hs[(3, 27)].setup(img)
+        print("split 3 == split 2:", all(torch.equal(hs[(3, 27)].basis(p), ref[p]) for p in range(11)), flush=True)
+
+
+if __name__ == "__main__":
+    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4}[sys.argv[1]]()
