@@ -202,5 +202,51 @@ def g4():
         print("split 3 == split 2:", all(torch.equal(hs[(3, 27)].basis(p), ref[p]) for p in range(11)), flush=True)
 
 
+def host():
+    """(needs tools/patches/host_register_option.patch applied: CVS_OPT_HOST_REGISTER was measured and not adopted)
+    M2 with HOST planes (stream of 8 images, g/h back to the host) for CVS_OPT_HOST_REGISTER = 0 / 1 / 2, and the raw cost of
+    hipHostRegister + hipHostUnregister of one 64 MiB plane"""
+    import numpy as np
+    n = 4096
+    himgs = [np.random.default_rng(500 + i).random((n, n), dtype=np.float32) for i in range(8)]
+    hg, hh = np.empty_like(himgs[0]), np.empty_like(himgs[0])
+    rt = torch.cuda.cudart()
+    probe = np.random.default_rng(1).random((n, n), dtype=np.float32)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        rc = rt.cudaHostRegister(probe.ctypes.data, probe.nbytes, 0)
+        t1 = time.perf_counter()
+        rt.cudaHostUnregister(probe.ctypes.data)
+        t2 = time.perf_counter()
+        print("hipHostRegister 64 MiB: %.3f ms (rc %s), unregister %.3f ms" % ((t1 - t0) * 1e3, rc, (t2 - t1) * 1e3), flush=True)
+    fs = {}
+    for mode in (0, 1, 2):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(14, mode)   # CVS_OPT_HOST_REGISTER of the patch
+        f.setup_steer(himgs[0], 0.3, flags=cv.SETUP_BASIS, out=(hg, hh))
+        fs[mode] = f
+    torch.cuda.synchronize()
+    time.sleep(2.5)
+    best = {m: 1e9 for m in fs}
+    for rnd in range(4):
+        for m, f in fs.items():
+            t0 = time.perf_counter()
+            for im in himgs:
+                f.setup_steer(im, 0.3, flags=cv.SETUP_BASIS, out=(hg, hh))
+            best[m] = min(best[m], (time.perf_counter() - t0) / len(himgs))
+    for m in fs:
+        print("host planes, register mode %d: %.3f ms per image  %.2f Gpix/s  (link floor 2.4 ms)" % (m, best[m] * 1e3, n * n / best[m] / 1e9), flush=True)
+    # the whole pipeline with 8 host outputs
+    outs = [np.empty_like(himgs[0]) for _ in range(8)]
+    for m, f in fs.items():
+        b = 1e9
+        for rnd in range(3):
+            t0 = time.perf_counter()
+            for im in himgs[:4]:
+                f.pipeline(im, out=outs)
+            b = min(b, (time.perf_counter() - t0) / 4)
+        print("pipeline host in, 8 host planes out, mode %d: %.3f ms per image (floor 9.6 ms)" % (m, b * 1e3), flush=True)
+
+
 if __name__ == "__main__":
-    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4}[sys.argv[1]]()
+    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host}[sys.argv[1]]()
