@@ -338,21 +338,9 @@ void pool_give(StateBlock& blk)
     for (StateBlock& d : drop) state_block_free(d);
 }
 
-// tuning aid (A/B tools only): extra elements per state row, a multiple of 64 -- does a row pitch that is not a power of
-// two change how the planes' rows fall onto the memory channels?  (measured round 3: see DESIGN.md section 3)
-size_t state_pitch_pad()
-{
-    static const size_t pad = [] {
-        const char* e = std::getenv("CVS_STATE_PITCH_PAD");
-        const long v = e ? std::atol(e) : 0;
-        return v > 0 ? round_up((size_t)v, 64) : (size_t)0;
-    }();
-    return pad;
-}
-
 int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
 {
-    const size_t pitch = round_up((size_t)cols, 64) + state_pitch_pad();
+    const size_t pitch = round_up((size_t)cols, 64);
     size_t stride = round_up(pitch * rows, 64);
     const int nplanes = h->nb + 5;
     // Large single-image states get one physical allocation per plane, placed by a bounded search (cvs_state.cpp);
@@ -764,7 +752,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         for (const cvs_plane* o : outs_chk)
             if (o && o->data == image->data) return fail(h, CVS_E_BADARG, "an output plane aliases the input image");
     }
-    const size_t pitch = round_up((size_t)image->cols, 64) + state_pitch_pad();
+    const size_t pitch = round_up((size_t)image->cols, 64);
     size_t max_pitch = std::max(pitch, is_u8(image) ? pitch : image->step / sizeof(float));
     if (steer) max_pitch = std::max(max_pitch, std::max(g->step, hq->step) / sizeof(float));
     if (pipe_outs)
