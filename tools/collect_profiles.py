@@ -33,16 +33,17 @@ if stats:
     trace = newest(os.path.join(G, "prof_stats", "*", "*_kernel_trace.csv"))
     line = [l for l in open(os.path.join(G, "prof_stats.log")) if l.startswith("{")]
     if trace and line:
-        steps = json.loads(line[-1])["steps"]
+        jl = json.loads(line[-1])
+        steps = jl["steps"] * int(jl.get("repeats", {}).get("repeats", 1))   # every repeat of the timed region
         durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace[0]))
                 if "k_basis<cvs::BankG2, 2" in r["Kernel_Name"] or "k_basisINS_6BankG2ELi2" in r["Kernel_Name"]]
         durs = [d for _, d in sorted(durs)][-steps:]
         if durs:
-            starts = sorted(int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace[0])) if "BankG2, 2" in r["Kernel_Name"])[-steps:]
+            starts = sorted(int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace[0])) if "BankG2, 2" in r["Kernel_Name"])[-jl["steps"]:]
             with open(os.path.join(P, "%s_kernel_stats.csv" % rnd), "a") as f:
                 w = csv.writer(f)
                 w.writerow(["# timed region: last %d launches of the headline kernel" % len(durs), len(durs), sum(durs), "%.1f" % (sum(durs) / len(durs)),
-                            min(durs), max(durs), "launch-to-launch %.1f ns" % ((starts[-1] - starts[0]) / max(1, len(starts) - 1))])
+                            min(durs), max(durs), "launch-to-launch %.1f ns (last repeat)" % ((starts[-1] - starts[0]) / max(1, len(starts) - 1))])
     if line:
         open(os.path.join(P, "%s_bench_under_rocprof.json" % rnd), "w").write(line[-1])
 allst = newest(os.path.join(G, "prof_stats_all", "*", "*_kernel_stats.csv"))

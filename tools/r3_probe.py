@@ -248,5 +248,40 @@ def host():
         print("pipeline host in, 8 host planes out, mode %d: %.3f ms per image (floor 9.6 ms)" % (m, b * 1e3), flush=True)
 
 
+def firstcall():
+    """the reference's pattern -- one new object per image, a different image each time, wait after every call -- for a few
+    launch configurations: which one suits an ISOLATED launch on a fresh image?"""
+    n = 4096
+    imgs = [torch.rand((n, n), device="cuda") for _ in range(8)]
+    g, h = torch.empty_like(imgs[0]), torch.empty_like(imgs[0])
+    npix = n * n
+    confs = [("default", None, None), ("order 0, strip 10", 0, 10), ("order 0, strip 19", 0, 19), ("order 1 (4:3), strip 10", 1, 10),
+             ("order 1 (4:3), strip 19", 1, 19), ("xcd columns, strip 10", 1000000, 10), ("xcd columns, strip 19", 1000000, 19), ("order 0, strip 28", 0, 28)]
+
+    def one(image, order, strip):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f = cv.SteerableFiltersG2(None)
+        if order is not None:
+            f.set_option(L.OPT_BLOCK_ORDER, order)
+            f.set_strip_rows(strip)
+        e0.record()
+        f.setup_steer(image, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        e1.record()
+        torch.cuda.synchronize()
+        del f
+        return e0.elapsed_time(e1)
+
+    res = {c[0]: [] for c in confs}
+    i = 0
+    for rnd in range(12):
+        for name, order, strip in confs:
+            i += 1
+            res[name].append(one(imgs[i & 7], order, strip))
+    for name, _, _ in confs:
+        r = sorted(res[name][2:])
+        ms = r[len(r) // 2]
+        print("%-26s %.4f ms  %.3f of HBM  (min %.4f)" % (name, ms, 40 * npix / ms / 1e6 / 8000, r[0]), flush=True)
+
+
 if __name__ == "__main__":
-    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host}[sys.argv[1]]()
+    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall}[sys.argv[1]]()
