@@ -91,7 +91,7 @@ summary["rotating_inputs"] = {k: {"FETCH_SIZE_bytes_raw": rf.get(k), "read_bytes
 json.dump(summary, open(os.path.join(P, "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 
 # the headline kernel: G2 bank, F_STEER (2), streaming stores, not batched
-keys = [k for k in summary["kernels"] if k.startswith("cvs::k_basis<cvs::BankG2, 2, true, false")]
+keys = [k for k in summary["kernels"] if k.startswith("cvs::k_basis<cvs::BankG2, 2, true, 0, true")]
 key = keys[0] if keys else None
 if key:
     t = summary["kernels"][key]
