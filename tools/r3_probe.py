@@ -283,5 +283,47 @@ def firstcall():
         print("%-26s %.4f ms  %.3f of HBM  (min %.4f)" % (name, ms, 40 * npix / ms / 1e6 / 8000, r[0]), flush=True)
 
 
+def sc1():
+    """(probe build only: bst() issuing aux 18 when BasisArgs::nt_stores == 2, switched by CVS_PROBE_SC1; result in
+    profiles/r03_nt_sc1_one_allocation_probe.txt: <= +1.5 points where the allocation is in its slow mode, -6 in its fast mode) streaming stores as `nt` vs `nt sc1`, alternating on ONE handle = one
+    allocation, for several handles in a row: is sc1 the better policy where the allocation is in its slow mode?"""
+    import ctypes as C
+    n = 4096
+    img = torch.rand((n, n), device="cuda")
+    imgs = [img] + [torch.rand((n, n), device="cuda") for _ in range(3)]
+    g, h = torch.empty_like(img), torch.empty_like(img)
+    outs8 = [torch.empty_like(img) for _ in range(8)]
+    npix = n * n
+    for hnd in range(5):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_AUTOTUNE, 0)
+        f.set_option(L.OPT_STORE_POLICY, 2)
+        rot = {"i": 0}
+
+        def rotstep():
+            rot["i"] = (rot["i"] + 1) & 3
+            f.setup_steer(imgs[rot["i"]], 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+
+        legs = (("M1", lambda: f.setup(img, flags=cv.SETUP_BASIS), 32), ("M2", lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h)), 40),
+                ("M4", lambda: f.setup(img, flags=cv.SETUP_FULL), 52), ("M5", lambda: f.pipeline(img, out=outs8), 84), ("M2rot", rotstep, 40))
+        line = "handle %d:" % hnd
+        for name, fn, bpp in legs:
+            r = {0: [], 1: []}
+            for rnd in range(4):
+                for pol in (0, 1):
+                    torch.cuda.synchronize()
+                    if pol:
+                        os.environ["CVS_PROBE_SC1"] = "1"
+                    else:
+                        os.environ.pop("CVS_PROBE_SC1", None)
+                    r[pol].append(timeit(fn, steps=20, warm=3))
+            a, b = med(r[0]), med(r[1])
+            line += "  %s nt %.3f | nt sc1 %.3f" % (name, bpp * npix / a / 1e6 / 8000, bpp * npix / b / 1e6 / 8000)
+        print(line, flush=True)
+        del f
+        keep = torch.empty((64 << 20,), device="cuda")   # shift the next handle's allocation
+        cv.lib().cvs_release_cached_memory()
+
+
 if __name__ == "__main__":
-    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall}[sys.argv[1]]()
+    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall, "sc1": sc1}[sys.argv[1]]()
