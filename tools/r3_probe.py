@@ -325,5 +325,30 @@ def sc1():
         cv.lib().cvs_release_cached_memory()
 
 
+def planepad():
+    """(probe build: CVS_PROBE_PLANE_PAD_KB) M1 / M4 / M5 on five handles in a row (each its own allocation, a spacer kept in
+    between) -- does a large pad between the state planes take the allocation's slow mode away?"""
+    n = 4096
+    img = torch.rand((n, n), device="cuda")
+    outs8 = [torch.empty_like(img) for _ in range(8)]
+    npix = n * n
+    print("CVS_PROBE_PLANE_PAD_KB=%s" % os.environ.get("CVS_PROBE_PLANE_PAD_KB", "0"), flush=True)
+    keep = []
+    for hnd in range(6):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_AUTOTUNE, 0)
+        legs = (("M1", lambda: f.setup(img, flags=cv.SETUP_BASIS), 32), ("M4", lambda: f.setup(img, flags=cv.SETUP_FULL), 52), ("M5", lambda: f.pipeline(img, out=outs8), 84))
+        line = "handle %d:" % hnd
+        for name, fn, bpp in legs:
+            r = [timeit(fn, steps=20, warm=3) for _ in range(3)]
+            line += "  %s %.3f" % (name, bpp * npix / med(r) / 1e6 / 8000)
+        p0 = f.basis_view(0)[0]
+        p1 = f.basis_view(1)[0]
+        print(line + "   plane stride %.2f MiB" % ((p1 - p0) / 2 ** 20), flush=True)
+        del f
+        keep = [torch.empty((64 << 20,), device="cuda")]   # 256 MiB spacer: shifts the next handle's block
+        cv.lib().cvs_release_cached_memory()
+
+
 if __name__ == "__main__":
-    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall, "sc1": sc1}[sys.argv[1]]()
+    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall, "sc1": sc1, "planepad": planepad}[sys.argv[1]]()
