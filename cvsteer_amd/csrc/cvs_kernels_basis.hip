@@ -49,6 +49,9 @@ struct BankG2 {  // SteerableFiltersG2.cpp:62-68
     static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3, 5}; return t[r]; }
     static constexpr int dup_a = 1, dup_b = 4;  // m_g2 == m_h2 bit for bit
     static constexpr int PLANE0 = 0, HALF = 0;  // first basis plane written; 0 = whole bank
+    static constexpr bool VOFF = false;         // plane offsets of the single-resource form in per-lane registers (see BankG4G)
+    static constexpr bool SRED = false;         // strength-reduced scalar bookkeeping of the row loop (see basis_body): the G2
+                                                // kernels are memory-bound and short of SGPRs -- the extra live scalars spill
 };
 
 struct BankG4 {  // SteerableFiltersG4.cpp:69-80
@@ -61,6 +64,8 @@ struct BankG4 {  // SteerableFiltersG4.cpp:69-80
     static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3, 5, 8, 9}; return t[r]; }
     static constexpr int dup_a = 1, dup_b = 6;  // m_g2 == m_h2
     static constexpr int PLANE0 = 0, HALF = 0;
+    static constexpr bool VOFF = false;
+    static constexpr bool SRED = true;
 };
 
 // The 11-plane bank needs a 10 x 13 register window (187 VGPRs, 2 waves/SIMD).  Its G and H
@@ -76,6 +81,11 @@ struct BankG4G {  // planes g4a..g4e, SteerableFiltersG4.cpp:69-73
     static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3}; return t[r]; }
     static constexpr int dup_a = 1, dup_b = 6;
     static constexpr int PLANE0 = 0, HALF = 1;
+    // single-resource form: the plane's byte offset sits in one per-lane register per plane (fixed for the strip) instead of
+    // being added to the scalar row offset before every store -- 5 / 6 scalar instructions per row less; the G4 half banks
+    // have the registers to spare (131 -> 137 VGPRs, still three waves per SIMD) and are sensitive to the scalar unit
+    static constexpr bool VOFF = true;
+    static constexpr bool SRED = true;
 };
 
 struct BankG4H {  // planes h4a..h4f, SteerableFiltersG4.cpp:75-80
@@ -88,6 +98,8 @@ struct BankG4H {  // planes h4a..h4f, SteerableFiltersG4.cpp:75-80
     static constexpr int odd_member(int r) { constexpr int t[NO] = {5, 8, 9}; return t[r]; }
     static constexpr int dup_a = 1, dup_b = 6;
     static constexpr int PLANE0 = 5, HALF = 2;
+    static constexpr bool VOFF = true;
+    static constexpr bool SRED = true;
 };
 
 // folded taps: ev[r][i] = tap at offset +/-i (i = 0..W); od[r][i-1] = tap at offset +i (i = 1..W)
@@ -306,6 +318,23 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 
     const int nrows_in = (yend - y0) + 2 * W;
     const int ngroups = (nrows_in + NT - 1) / NT;
+    // Scalar bookkeeping of the row loop, strength-reduced for the banks that ask for it (B::SRED; round 3: the scalar unit
+    // is shared by the CU's SIMDs and the G4 kernels feel every scalar instruction -- the pair kernel went from 1574 to 1213
+    // scalar and from 3461 to 3347 vector instructions per 13 rows, its SGPR spills from 170 to 46 lane moves): the prefetch row offset and the output row offset advance by one pitch per
+    // row instead of being rebuilt from the row number (reflect + multiply: 7 scalar instructions), and "is this an output
+    // row" is one unsigned compare.  In the loop the prefetched row y0 - W + (g + 1) NT + j is never above the image
+    // (>= y0 + W + 1), so only the lower border reflects: rows >= a.rows mirror to 2 rows - 2 - row, i.e. ro_mir - ro_lin.
+    [[maybe_unused]] unsigned ro_lin = (unsigned)(y0 - W + NT - rbase) * in_pitch_b;
+    [[maybe_unused]] const unsigned ro_lim = (unsigned)(a.rows - rbase) * in_pitch_b;
+    [[maybe_unused]] const unsigned ro_mir = (unsigned)(2 * a.rows - 2 - 2 * rbase) * in_pitch_b;
+    [[maybe_unused]] unsigned oi_run = 0u - (unsigned)(2 * W);                   // output row relative to y0 (wraps below 0)
+    [[maybe_unused]] unsigned orow_run = ((unsigned)(y0 - rbase) - (unsigned)(2 * W)) * pitch_b;  // its byte offset in a state plane
+    const unsigned nout = (unsigned)(yend - y0);
+    [[maybe_unused]] unsigned xbp[NB];
+    if constexpr (ONE && B::VOFF) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p) xbp[p] = xb + (unsigned)(B::PLANE0 + p) * pstride_b;   // kLaneOff + offset stays out of range
+    }
 
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -326,7 +355,13 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             // the register just consumed is refilled at once with the same row of the next group:
             // a full group (2W+1 rows) of loads stays in flight with a single set of registers
             {
-                const unsigned ro = (unsigned)(reflect1(y0 - W + (g + 1) * NT + j, a.rows) - rbase) * in_pitch_b;
+                unsigned ro;
+                if constexpr (B::SRED) {
+                    ro = ro_lin >= ro_lim ? ro_mir - ro_lin : ro_lin;
+                    ro_lin += in_pitch_b;
+                } else {
+                    ro = (unsigned)(reflect1(y0 - W + (g + 1) * NT + j, a.rows) - rbase) * in_pitch_b;
+                }
                 pre[j] = bld(r_in, nxmb, ro);
                 preh[j] = bld(r_in, nxhb, ro);
             }
@@ -376,8 +411,20 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             }
 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----
-            const int yout = y0 + g * NT + j - 2 * W;
-            const bool row_ok = yout >= y0 && yout < yend;  // wave-uniform
+            // which output row this is, and whether the strip owns it (wave-uniform)
+            unsigned oi = 0, orow_s = 0;
+            bool row_ok;
+            [[maybe_unused]] int yout = 0;
+            if constexpr (B::SRED) {
+                oi = oi_run;
+                orow_s = orow_run;
+                ++oi_run;
+                orow_run += pitch_b;
+                row_ok = oi < nout;  // y0 <= y0 + oi < yend
+            } else {
+                yout = y0 + g * NT + j - 2 * W;
+                row_ok = yout >= y0 && yout < yend;
+            }
             const unsigned xbr = xb;
             if (row_ok) {
 #ifdef CVS_DIAG_STAMPS
@@ -406,12 +453,20 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     b[p] = acc;
                 }
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
-                const unsigned yo = row_ok ? (unsigned)(yout - rbase) : 0u;
-                const unsigned orow = yo * pitch_b;
+                // output row relative to the plane pointers, and its byte offset in a state plane
+                unsigned yo, orow;
+                if constexpr (B::SRED) {
+                    yo = (unsigned)(y0 - rbase) + oi;
+                    orow = orow_s;
+                } else {
+                    yo = row_ok ? (unsigned)(yout - rbase) : 0u;
+                    orow = yo * pitch_b;
+                }
                 if constexpr ((FLAGS & F_NOSTATE) == 0) {
 #pragma unroll
                     for (int p = 0; p < NB; ++p)
-                        if constexpr (ONE) bst<STREAM>(r_state, xbr, orow + (unsigned)(B::PLANE0 + p) * pstride_b, b[p]);
+                        if constexpr (ONE && B::VOFF) bst<STREAM>(r_state, xbp[p], orow, b[p]);
+                        else if constexpr (ONE) bst<STREAM>(r_state, xbr, orow + (unsigned)(B::PLANE0 + p) * pstride_b, b[p]);
                         else bst<STREAM>(plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orow, b[p]);
                 }
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
