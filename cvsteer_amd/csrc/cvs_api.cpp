@@ -975,10 +975,9 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
     h->device = device;
     std::memset(h->taps, 0, sizeof(h->taps));
     for (int i = 0; i < nb; ++i) host_make_taps(kind, i, width, spacing, h->taps[i]);
-    if (hipMalloc(&h->minmax, 2 * sizeof(float)) != hipSuccess) {
-        delete h;
-        return CVS_E_NOMEM;
-    }
+    // (nothing is allocated on the device here: the reference's callers build one short-lived object per image,
+    // example/steer.cpp:86, and a hipMalloc + hipFree pair per object costs ~20 us of the ~150 us such an object lives;
+    // the 8 bytes of min / max scratch are allocated by the first 8-bit conversion that needs them)
     if (const char* e = std::getenv("CVS_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("CVS_PYR_STRIP")) h->pyr_strip = std::atoi(e) != 0;
     if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::max(0, std::min(2, std::atoi(e)));  // opt-in for new handles
@@ -1601,6 +1600,7 @@ static int to_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_st
         dstep = dpitch;
     }
     if (minmax) {
+        if (!h->minmax) HIP_TRY(h, hipMalloc(&h->minmax, 2 * sizeof(float)));
         HIP_TRY(h, launch_minmax(in.p, in.pitch, src->rows, src->cols, h->minmax, h->stream));
         HIP_TRY(h, launch_quantize_u8(in.p, in.pitch, src->rows, src->cols, h->minmax, d, dstep, h->stream));
     } else {
