@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (M1/M4/M5/G4/C3/C4)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--strip-rows", type=int, default=0)
-    ap.add_argument("--extra-timeout", type=int, default=900, help="seconds the secondary legs may take before every rank gives up on them (0 = no watchdog)")
+    ap.add_argument("--extra-timeout", type=int, default=300, help="seconds the secondary legs may take before every rank gives up on them (0 = no watchdog)")
     ap.add_argument("--repeats", type=int, default=11, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
     ap.add_argument("--leg-repeats", type=int, default=5, help="repeats of every secondary leg's timed region (median reported)")
     args = ap.parse_args()
