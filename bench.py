@@ -35,10 +35,11 @@ ROWS = COLS = 4096
 THETA = 0.3
 BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56}
 # calls on a new handle before a timed region: the engine times a few launch orders on the SECOND repeat of a shape
-# (bounded: ~50 launches, cached process-wide).  Nothing else is deferred: the allocation-time
-# placement search is OPT-IN since round 3 and OFF for the headline (`config.placement` records mode / window_found /
-# probe_ms as the library reports them; `extra.M2_placement_search` is the same loop with the search switched on, so
-# that one line shows what a window is worth on the box it ran on).  `M2_untuned` / `M2_first_call` = no tuner either.
+# (bounded: ~50 launches, cached process-wide).  The allocation-time placement search is OPT-IN in
+# the library since round 3; bench.py switches it ON for the headline handle (--placement 1, the default here) and
+# records what it found and cost in `config.placement`; `extra.M2_plain_block` is the same loop on the library's default
+# (a plain hipMalloc block), so that one line shows what a window is worth on the box it ran on.  `M2_untuned` /
+# `M2_first_call` = the library's defaults without the tuner.
 INIT_CALLS = 4
 EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
 EXIT_LEGS_FAILED = 5  # a secondary leg raised: headline + the legs finished so far are printed first
@@ -172,6 +173,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--extra-timeout", type=int, default=300, help="seconds the secondary legs may take before every rank gives up on them (0 = no watchdog)")
+    ap.add_argument("--placement", type=int, default=1, choices=(0, 1),
+                    help="CVS_OPT_PLACEMENT_SEARCH of the headline handle: 1 = the library's opt-in allocation-time placement search "
+                         "switched on (what it found and cost is recorded in config.placement; extra.M2_plain_block is the same loop with 0), "
+                         "0 = the library default, a plain hipMalloc block")
     ap.add_argument("--repeats", type=int, default=11, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
     ap.add_argument("--leg-repeats", type=int, default=5, help="repeats of every secondary leg's timed region (median reported)")
     args = ap.parse_args()
@@ -242,6 +247,9 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)  # i.i.d. uniform [0,1)
     f = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+    # the headline handle runs with the library's OPT-IN placement search on (a documented tuning knob, off by default in the
+    # library): config.placement records what it found and what it cost, extra.M2_plain_block is the same loop without it
+    f.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
     if args.strip_rows:
         f.set_strip_rows(args.strip_rows)
     g = torch.empty_like(img)
@@ -320,7 +328,8 @@ def main():
                    "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective",
                    "init_calls": INIT_CALLS, "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process"),
                    "placement": {"mode": info["placement_mode"], "window_found": bool(info["window_found"]), "probe_ms": round(info["probe_ms"], 3),
-                                 "note": "CVS_OPT_PLACEMENT_SEARCH of the headline handle (0 = plain hipMalloc block, the library default)"},
+                                 "note": "CVS_OPT_PLACEMENT_SEARCH of the headline handle: 1 = the library's opt-in allocation-time search, switched on "
+                                         "by bench.py (--placement); 0 = plain hipMalloc block, the library default -- see extra.M2_plain_block"},
                    "launch": {"block_order": info["block_order"], "xcd_weights": info["xcd_weights"], "strip_rows": info["strip_rows"],
                               "nt_stores": info["nt_stores"], "note": "configuration of the timed launches: engine defaults or what the launch-order tuner kept"}},
         "clocks": {"value": "host wall clock around the timed region, median of the repeats",
@@ -424,25 +433,21 @@ def main():
                                            "ms = events around the single call, ms_object = create+call+sync+destroy wall")
         del imgs8
 
-        # the headline loop once more with the OPT-IN placement search switched on (cvs_state.cpp): what a window of state
-        # planes that straddles a run boundary of the VRAM allocator is worth on THIS box -- or that none was found
+        # the headline loop on the library's DEFAULT allocation -- a plain hipMalloc state block, no placement search -- with the
+        # launch-order tuner on: next to `value` it shows what the placement search is worth on THIS box (or that it is
+        # worth nothing here: config.placement.window_found)
         try:
-            torch.cuda.synchronize()
-            cv.lib().cvs_release_cached_memory()
             fp_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-            fp_.set_option(L.OPT_PLACEMENT_SEARCH, 1)
+            fp_.set_option(L.OPT_PLACEMENT_SEARCH, 0)
             for _ in range(INIT_CALLS):
                 fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
-            leg("M2_placement_search", lambda: fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], warm=max(2, args.warmup))
+            leg("M2_plain_block", lambda: fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], warm=max(2, args.warmup))
             pi_ = fp_.launch_info()
-            extra["M2_placement_search"].update({"window_found": bool(pi_["window_found"]), "probe_ms": round(pi_["probe_ms"], 3),
-                                                 "block_order": pi_["block_order"], "xcd_weights": pi_["xcd_weights"], "strip_rows": pi_["strip_rows"],
-                                                 "note": "CVS_OPT_PLACEMENT_SEARCH = 1 (opt-in), otherwise the headline loop; the headline itself runs with 0"})
+            extra["M2_plain_block"].update({"block_order": pi_["block_order"], "xcd_weights": pi_["xcd_weights"], "strip_rows": pi_["strip_rows"],
+                                            "note": "CVS_OPT_PLACEMENT_SEARCH = 0 (the library default), otherwise the headline loop"})
             del fp_
-            torch.cuda.synchronize()
-            cv.lib().cvs_release_cached_memory()
         except Exception as ex:
-            extra["M2_placement_search"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            extra["M2_plain_block"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
         if ws == 1:
             # (for a second or two after gigabytes of device memory have been released -- the spare pieces of a placement

@@ -46,6 +46,20 @@ if stats:
                             min(durs), max(durs), "launch-to-launch %.1f ns (last repeat)" % ((starts[-1] - starts[0]) / max(1, len(starts) - 1))])
     if line:
         open(os.path.join(P, "%s_bench_under_rocprof.json" % rnd), "w").write(line[-1])
+# the same headline loop on a plain hipMalloc block (bench.py --placement 0): timed region only
+ptrace = newest(os.path.join(G, "prof_stats_plain", "*", "*_kernel_trace.csv"))
+pline = [l for l in open(os.path.join(G, "prof_stats_plain.log")) if l.startswith("{")] if os.path.exists(os.path.join(G, "prof_stats_plain.log")) else []
+if ptrace and pline:
+    jl = json.loads(pline[-1])
+    steps = jl["steps"] * int(jl.get("repeats", {}).get("repeats", 1))
+    durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(ptrace[0])) if "k_basis<cvs::BankG2, 2" in r["Kernel_Name"]]
+    durs = [d for _, d in sorted(durs)][-steps:]
+    with open(os.path.join(P, "%s_kernel_stats_plain_block.csv" % rnd), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "note"])
+        w.writerow(["cvs::k_basis<cvs::BankG2, 2, true, 0, true, 4> (timed region, bench.py --placement 0)", len(durs), sum(durs), "%.1f" % (sum(durs) / max(1, len(durs))),
+                    min(durs), max(durs), "bench avg_launch_ms %.5f, frac %.4f" % (jl["roofline"]["avg_launch_ms"], jl["roofline"]["frac"])])
+    open(os.path.join(P, "%s_bench_under_rocprof_plain_block.json" % rnd), "w").write(pline[-1])
 allst = newest(os.path.join(G, "prof_stats_all", "*", "*_kernel_stats.csv"))
 if allst:
     rows = [r for r in csv.DictReader(open(allst[0])) if "cvs::" in r["Name"]]
