@@ -414,6 +414,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             fo = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            fo.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)   # like the headline handle; the first (cold) object pays for the probe
             e0.record()
             fo.setup_steer(image, THETA, flags=cv.SETUP_BASIS, out=(g, h))
             e1.record()
@@ -429,8 +430,10 @@ def main():
         ms_obj = sorted(r[0] for r in runs)[len(runs) // 2]
         extra["M2_first_call"] = dict(rate(ms_call, BYTES_PER_PIX["M2"], npix), ms_object=round(ms_obj, 4),
                                       ms_call_cold=round(cold[1], 4), ms_object_cold=round(cold[0], 4),
+                                      placement_mode=args.placement,
                                       note="one new handle per image, a different image each time; median of 10; "
-                                           "ms = events around the single call, ms_object = create+call+sync+destroy wall")
+                                           "ms = events around the single call, ms_object = create+call+sync+destroy wall; "
+                                           "cold = block cache emptied first (with placement 1 the cold object runs the probe, the others take the parked window)")
         del imgs8
 
         # the headline loop on the library's DEFAULT allocation -- a plain hipMalloc state block, no placement search -- with the

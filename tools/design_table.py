@@ -18,7 +18,11 @@ def load(path):
     return d
 
 cols = [(a.split("=", 1)[0], load(a.split("=", 1)[1])) for a in sys.argv[1:]]
-rows = [("**M2 filter+steer (headline `value`)**", 40, lambda p: "%.1f Gpix/s, **%.1f %%**" % (p["value"] / 1e3, 100 * p["roofline"]["frac"]))]
+def headline(p):
+    pl = p.get("config", {}).get("placement")
+    tag = "" if not pl else (" (search %s%s)" % ("on" if pl["mode"] else "off", (", window %s, %.1f ms" % ("found" if pl["window_found"] else "not found", pl["probe_ms"])) if pl["mode"] else ""))
+    return "%.1f Gpix/s, **%.1f %%**%s" % (p["value"] / 1e3, 100 * p["roofline"]["frac"], tag)
+rows = [("**M2 filter+steer (headline `value`)**", 40, headline)]
 def leg(name, key="frac_hbm", fmt=None):
     def f(p):
         e = p.get("extra", {}).get(name)
@@ -32,7 +36,9 @@ rows += [
     ("M2, 8 rotating inputs (every input read from HBM)", 40, leg("M2_rotating_8_inputs")),
     ("M2, fresh handle, tuner off (`M2_untuned`)", 40, leg("M2_untuned")),
     ("M2, one new handle per image (`M2_first_call`)", 40, leg("M2_first_call", fmt=lambda e: "%.1f %%, %.2f ms per object" % (100 * e["frac_hbm"], e["ms_object"]))),
-    ("M2 with the opt-in placement search (`M2_placement_search`)", 40, leg("M2_placement_search", fmt=lambda e: "%.1f %% (window %s, probe %.1f ms)" % (100 * e["frac_hbm"], "found" if e.get("window_found") else "not found", e.get("probe_ms", 0)))),
+    ("the headline loop with the placement search the other way round (`M2_plain_block` = off / `M2_placement_search` = on)", 40,
+     lambda p: leg("M2_plain_block", fmt=lambda e: "off: %.1f %%" % (100 * e["frac_hbm"]))(p) if "M2_plain_block" in p.get("extra", {}) else
+               leg("M2_placement_search", fmt=lambda e: "on: %.1f %% (window %s, probe %.1f ms)" % (100 * e["frac_hbm"], "found" if e.get("window_found") else "not found", e.get("probe_ms", 0)))(p)),
     ("M1 basis only", 32, leg("M1_basis_only")),
     ("M4 full setup (12 planes)", 52, leg("M4_full_setup")),
     ("M5 whole caller pipeline (20 planes)", 84, leg("M5_pipeline")),
