@@ -567,6 +567,7 @@ def main():
         fsets = [torch.rand((nfr, 1080, 1920), generator=gen, device=dev, dtype=torch.float32) for _ in range(2)]
         fout = torch.empty((nfr, 8, 1080, 1920), device=dev)
         ff = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+        ff.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)   # batches: the real launch is timed on up to six candidate state blocks, once
         csteps = max(10, args.steps // 10)
         alt = {"i": 0}
 
@@ -577,7 +578,9 @@ def main():
         ms, ms_lo, ms_hi = timed(step_c4, csteps, WARM_NEW)
         fp = nfr * 1080 * 1920
         extra["C4_32x1080p_pipeline_batch"] = dict(rate(ms, 84, ws * fp), ms_per_frame=round(ms / nfr, 5), launches_per_batch=1,
-                                                   frames_per_gpu=nfr, timed_steps=csteps, frame_sets=2, ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR)
+                                                   frames_per_gpu=nfr, timed_steps=csteps, frame_sets=2, ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR,
+                                                   placement={"mode": args.placement, "better_block_found": bool(ff.launch_info()["window_found"]),
+                                                              "search_ms": round(ff.launch_info()["probe_ms"], 2)})
         ff.set_persist(False)
         fo3 = torch.empty((nfr, 3, 1080, 1920), device=dev)
 

@@ -42,6 +42,7 @@ struct cvs_context {
     size_t state_elems = 0;      // = sb.elems
     StateBlock sb;               // owner of the state memory (cvs_state.cpp)
     size_t placed_stride = 0;    // plane size the placement search has already run for (its answer may be "plain block")
+    size_t batch_searched_elems = 0;  // frame-batch state: block size the candidate search has already run for
     bool have_basis = false, have_orient = false;
     // batched state: num_frames blocks of (nb+5) planes; cur_frame selects the block all state
     // accessors and steer calls address
@@ -873,6 +874,75 @@ int need_state(cvs_handle h, bool orient)
     return CVS_OK;
 }
 
+// Frame batches (cvs_pipeline_batch with state kept; BASELINE config 4), opt-in with CVS_OPT_PLACEMENT_SEARCH = 1: which
+// plain block the batch state lives in decides the launch's speed by 7-9 % (tools/r3_probe.py c4modes: eight blocks of 3.2 GB
+// allocated one after the other in one process, the same frames and outputs -- blocks 0 and 5..7 run the launch at 0.73 of
+// the HBM roofline, blocks 1..4 at 0.67-0.68, the same in every process: runs of the VRAM allocator again, see cvs_state.cpp).
+// The per-plane windows of cvs_state.cpp do not fit a batch (hundreds of small planes), but the question can be put to the
+// launch itself: up to kCand plain candidate blocks are allocated, the REAL launch is timed on each (it rewrites the same
+// outputs with the same values), the fastest block is kept and the others are freed.  Once per (handle, block size), never
+// under stream capture, bounded by the free memory; results do not depend on it.
+int batch_block_search(cvs_handle h, BasisArgs& a)
+{
+    constexpr int kCand = 6;
+    const size_t elems = h->state_elems, bytes = elems * sizeof(float);
+    if (h->placement != 1 || h->sb.vmm || a.no_state || h->batch_searched_elems == elems || bytes < ((size_t)256 << 20)) return CVS_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return CVS_OK;
+    h->batch_searched_elems = elems;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return CVS_OK;
+    int ncand = 1;
+    while (ncand < kCand && (size_t)ncand * bytes + ((size_t)8 << 30) < free_b) ++ncand;   // candidate 0 is the block the handle has
+    if (ncand < 2) return CVS_OK;
+    const auto t_start = std::chrono::steady_clock::now();
+    std::vector<StateBlock> cand(ncand);
+    cand[0] = h->sb;
+    int have = 1;
+    for (; have < ncand; ++have)
+        if (state_block_alloc_plain(h->device, elems, cand[have]) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (!h->ev0) {
+        HIP_TRY(h, hipEventCreate(&h->ev0));
+        HIP_TRY(h, hipEventCreate(&h->ev1));
+    }
+    const ptrdiff_t orient_off = a.orient - a.basis;
+    std::vector<float> t(have, std::numeric_limits<float>::max());
+    hipError_t e = hipSuccess;
+    for (int round = 0; round < 2 && e == hipSuccess; ++round)          // round 0 = first touch of the fresh blocks
+        for (int c = 0; c < have && e == hipSuccess; ++c) {
+            a.basis = cand[c].base;
+            a.orient = cand[c].base + orient_off;
+            e = hipEventRecord(h->ev0, h->stream);
+            for (int k = 0; k < 2 && e == hipSuccess; ++k) e = launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream);
+            if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            if (round > 0 && e == hipSuccess) t[c] = ms / 2;
+        }
+    int best = 0;
+    if (e == hipSuccess)
+        for (int c = 1; c < have; ++c)
+            if (t[c] < t[best] * 0.98f) best = c;     // a challenger must win by 2 %
+    if (std::getenv("CVS_TUNE_VERBOSE")) {
+        std::fprintf(stderr, "[cvsteer] batch block search, %d candidates of %zu MiB (ms per launch):", have, bytes >> 20);
+        for (int c = 0; c < have; ++c) std::fprintf(stderr, " %.4f", t[c]);
+        std::fprintf(stderr, " -> candidate %d\n", best);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    for (int c = 0; c < have; ++c)
+        if (c != best) state_block_free(cand[c]);
+    h->sb = cand[best];
+    h->state = h->sb.base;
+    h->state_elems = h->sb.elems;
+    a.basis = h->state;
+    a.orient = h->state + orient_off;
+    h->window_found = best != 0;
+    h->probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    if (e != hipSuccess) return fail_hip(h, e, "batch block search");
+    return CVS_OK;
+}
+
 int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map, const cvs_plane* g, const cvs_plane* hq,
                  const cvs_plane* e, const cvs_plane* mag, const cvs_plane* phase)
 {
@@ -1532,6 +1602,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.batch = n;
     a.frame_stride = h->frame_stride;
     if ((rc = tune_block_order(h, a, nullptr, 16 | 1 | 4 | (a.no_state ? 8 : 0)))) return rc;
+    if ((rc = batch_block_search(h, a))) return rc;   // opt-in (CVS_OPT_PLACEMENT_SEARCH = 1), once per block size
     note_launch(h, a);
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream));
     h->have_basis = h->have_orient = h->persist != 0;

@@ -1234,6 +1234,40 @@ def test_placement_search_is_opt_in_and_reports_what_it_did(cv):
     cv.lib().cvs_release_cached_memory()
 
 
+def test_batch_block_search_keeps_results(cv):
+    """CVS_OPT_PLACEMENT_SEARCH = 1 on a frame batch with state kept: the first call times the REAL launch on up to six candidate
+    state blocks and keeps the fastest (cvs_api.cpp batch_block_search).  Outputs, every frame's state and later calls must not
+    notice; the search runs once per block size; stateless batches and the default (0) never search."""
+    import torch
+    from cvsteer_amd import _lib as L
+    frames = torch.rand((4, 1080, 1920), generator=torch.Generator(device="cuda").manual_seed(5), device="cuda")   # 4 x 99.5 MB of state
+    ref = cv.SteerableFiltersG2(None)
+    want = ref.pipeline_batch(frames).clone()
+    assert ref.launch_info()["probe_ms"] == 0.0
+    f = cv.SteerableFiltersG2(None)
+    f.set_option(L.OPT_PLACEMENT_SEARCH, 1)
+    got = f.pipeline_batch(frames)
+    torch.cuda.synchronize()
+    info = f.launch_info()
+    assert info["probe_ms"] > 0.0 and info["state_per_plane"] == 0      # searched; a plain block either way
+    assert torch.equal(got, want)
+    for i in (0, 3):
+        f.select_frame(i)
+        ref.select_frame(i)
+        assert torch.equal(f.basis(6), ref.basis(6)) and torch.equal(f.getDominantOrientationAngle(), ref.getDominantOrientationAngle())
+        g, h = f.steer(0.3)
+        g0, h0 = ref.steer(0.3)
+        assert torch.equal(g, g0) and torch.equal(h, h0)
+    got2 = f.pipeline_batch(frames)                                       # same block size: no second search
+    torch.cuda.synchronize()
+    assert f.launch_info()["probe_ms"] == info["probe_ms"] and torch.equal(got2, want)
+    f.set_persist(False)                                                  # nothing is kept: nothing to place
+    fo = f.pipeline_batch(frames, outputs=(5, 6, 7))
+    assert torch.equal(fo, want[:, 5:8])
+    del f, ref
+    cv.lib().cvs_release_cached_memory()
+
+
 def test_hip_graph_capture_and_replay(cv):
     """the engine's launches can be captured into a HIP graph on the caller's stream (no tuning, no allocation, no
     placement search happens under capture) and replayed on new data in the same buffers"""

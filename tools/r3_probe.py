@@ -350,5 +350,33 @@ def planepad():
         cv.lib().cvs_release_cached_memory()
 
 
+def c4modes():
+    """config 4 with state kept on eight handles that are all alive (eight state blocks of 3.2 GB from one process), the same two
+    frame sets and the same output tensor: how far apart are the allocations' modes, and how many draws find the fast one?"""
+    nfr = 32
+    sets = [torch.rand((nfr, 1080, 1920), device="cuda") for _ in range(2)]
+    out = torch.empty((nfr, 8, 1080, 1920), device="cuda")
+    pix = nfr * 1080 * 1920
+    alt = {"i": 0}
+    hs = []
+    for k in range(8):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_AUTOTUNE, 0)
+        hs.append(f)
+
+    def run(f):
+        alt["i"] ^= 1
+        f.pipeline_batch(sets[alt["i"]], out=out)
+
+    res = [[] for _ in hs]
+    for rnd in range(4):
+        for k, f in enumerate(hs):
+            res[k].append(timeit(lambda: run(f), steps=6, warm=2))
+    for k, f in enumerate(hs):
+        ms = med(res[k])
+        print("handle %d (state at %#x): %.4f ms  %.3f of HBM" % (k, f.basis_view(0)[0], ms, 84 * pix / ms / 1e6 / 8000), flush=True)
+    print("output tensor at %#x" % out.data_ptr(), flush=True)
+
+
 if __name__ == "__main__":
-    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall, "sc1": sc1, "planepad": planepad}[sys.argv[1]]()
+    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall, "sc1": sc1, "planepad": planepad, "c4modes": c4modes}[sys.argv[1]]()
