@@ -93,8 +93,12 @@ enum {
                                       process; none under stream capture; each search keeps its virtual range reserved for the
                                       life of the process (address space only, capped at 4 TiB); a chosen window is verified by
                                       a fill + sampled readback before use and is made accessible to the peer devices of the
-                                      process.  2 = always take the window in the middle of the pool (tests).  Results never
-                                      depend on it; cvs_get_launch_info reports what the last allocation did. */
+                                      process.  Frame batches with state kept (cvs_pipeline_batch; the per-plane windows do not
+                                      fit hundreds of small planes): with 1 the first call of a block size times the REAL launch
+                                      on up to six candidate plain state blocks (bounded by the free memory) and keeps the
+                                      fastest (20-30 ms once for 32 x 1080p).  2 = always take the window in the middle of the
+                                      pool (tests).  Results never depend on it; cvs_get_launch_info reports what the last
+                                      allocation did. */
     CVS_OPT_HOST_OVERLAP = 13, /* cvs_setup / cvs_setup_steer / cvs_pipeline with HOST planes on images of 1 Mpix and more:
                                   1 (default) = the image goes up, is filtered and comes down in row bands, all three at once
                                   (full-duplex host link, a second host thread for the downloads); 0 = one after the other */
