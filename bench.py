@@ -535,7 +535,8 @@ def main():
             leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36)
             leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), 64)
             del outs8
-            f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)
+            f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)   # (library default allocation: the placement probe is built on the
+            # G2 kernels' write pattern and does not help the G4 pair kernel -- same box, 0.65 with a window against 0.69 without)
             leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"])
             leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"])
             del f4
@@ -543,6 +544,7 @@ def main():
             # start-up cost of a launch (every wave primes its 8-row window before its first store) amortises
             big2 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
             fb = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            fb.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
             gb, hb = torch.empty_like(big2), torch.empty_like(big2)
             bsteps = max(5, args.steps // 4)
             leg("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
@@ -682,6 +684,8 @@ def main():
             lv = fp3.pyramid(bigs[0], 5)
             ppix = sum(l.shape[0] * l.shape[1] for l in lv)
             hp = [cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank) for _ in lv]
+            for hnd in hp:
+                hnd.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
             flip3 = {"i": 0}
 
             def pyr_filter():
@@ -713,6 +717,7 @@ def main():
                                                 "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                 "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix, "timed_steps": c3,
                                                 "whole_ms_min": round(e3_lo, 4), "whole_ms_max": round(e3_hi, 4), "repeats": LR,
+                                                "placement": {"mode": args.placement, "windows_found": [bool(hnd.launch_info()["window_found"]) for hnd in hp]},
                                                 "note": "whole = build + filter, level k+1 written by the filter launch of level k, two alternating images; "
                                                         "filter = five filter launches on a prebuilt pyramid; separate build + filter = filter_ms + pyramid_build_ms"}
             del bigs, lv, hp, fp3
