@@ -262,3 +262,29 @@ def test_oracle_mirror_transpose_and_steering_identities(ora, kind):
         gt, ht = steer(tr.astype(np.float32), theta)[:2]
         g1, h1 = steer(base.astype(np.float32), float(np.float32(np.pi / 2) - np.float32(theta)))[:2]
         assert np.abs(gt - g1.T).max() <= 1e-5 and np.abs(ht + h1.T).max() <= 1e-5
+
+
+def test_shared_phase_weight_identities_hold_against_the_oracle(ora):
+    """cvs_find and the fused pipelines evaluate ONE cos / sin pair of |phase| for the three phase weights (phase_lambda3 in
+    cvsteer_amd/csrc/cvs_device_math.h): lambda_edges = sin^2|p|, lambda_dark = lambda_bright = cos^2|p|, with the three gates
+    evaluated exactly as phaseWeights evaluates them (G2.cpp:179-186).  This restates that evaluation in numpy f32 and
+    holds it against the oracle's three separate phaseWeights: the identities are exact, the values differ by what the
+    reference's own float steps round away -- inside the 1e-6 stage tolerance, for phases in (-pi, pi] and far beyond."""
+    import numpy as np
+    f32 = np.float32
+    PI, TWO, HALF = f32(np.pi), f32(2 * np.pi), f32(np.pi / 2)
+    rng = np.random.default_rng(9)
+    for span in (np.pi, 20.0):
+        p = (rng.random(400000) * 2 * span - span).astype(f32)
+        p[:7] = [0.0, HALF, -HALF, PI, -PI, np.nextafter(HALF, f32(4)), np.nextafter(PI, f32(0))]
+        ap = np.abs(p)
+        s2 = (np.sin(ap.astype(np.float64)).astype(f32)) ** 2
+        c2 = (np.cos(ap.astype(np.float64)).astype(f32)) ** 2
+        ee = np.abs((ap - HALF).astype(f32)); ee = np.minimum(ee, (TWO - ee).astype(f32))
+        ed = np.minimum(ap, (TWO - ap).astype(f32))
+        eb = np.abs((p - PI).astype(f32)); eb = np.minimum(eb, (TWO - eb).astype(f32))
+        mine = (np.where(np.abs(ee) > HALF, f32(0), s2), np.where(np.abs(ed) > HALF, f32(0), c2), np.where(np.abs(eb) > HALF, f32(0), c2))
+        ones = np.ones_like(p)
+        for got, want in zip(mine, ora.find(ones.reshape(1, -1), p.reshape(1, -1))):
+            tol = 1e-6 if span <= 4 else 2e-5      # |p| ~ 20: one ulp of the reference's own float differences is 2e-6 rad
+            assert np.abs(got.astype(np.float64) - want.reshape(-1)).max() <= tol, span
