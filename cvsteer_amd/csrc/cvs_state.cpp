@@ -12,7 +12,7 @@
 //   * where a run ends cannot be predicted from the API (sizes, order and gaps of the allocations do not move it),
 //     but it can be SEEN: a window of consecutive pieces that straddles a run boundary is fast.
 // So the state block of a large image is a window into a range of per-plane physical allocations (HIP virtual
-// memory API: hipMemCreate / hipMemAddressReserve / hipMemMap): five blocks' worth of plane-sized pieces are created
+// memory API: hipMemCreate / hipMemAddressReserve / hipMemMap): seven blocks' worth (five until round 3) of plane-sized pieces are created
 // and mapped back to back ONCE, a streaming-store probe that writes exactly the plane sets the kernels write is slid
 // over the candidate windows (a few milliseconds, at allocation time only), and if some window straddles a run
 // boundary it becomes the state block; the pieces outside it are unmapped and released.  The kernels see an ordinary
@@ -27,7 +27,7 @@
 // blocks.  (Unrelated to correctness, but visible: for a second or two after gigabytes of device memory have been
 // released -- the spare pieces of a search, or any large hipFree -- host-link copies of the process run at about half
 // rate, 56 -> 30 GB/s in both directions, tools/d2h_probe.hip; two seconds later they are back.)
-// Bounded: four extra blocks of transient memory and never more than 8 GiB, one search at a time per process, nothing
+// Bounded: six extra blocks of transient memory and never more than 8 GiB, one search at a time per process, nothing
 // at all for states below 256 MiB (they live in the Infinity Cache), for frame batches and under stream capture.
 // OPT-IN since round 3 (CVS_OPT_PLACEMENT_SEARCH = 1 / CVS_PLACEMENT_SEARCH=1; the default 0 takes the plain block without
 // looking): on the judge's box of round 2 the probe cost its 8 ms and bought nothing, and a drop-in library must not
@@ -139,8 +139,8 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
     gran = std::max<size_t>(gran, (size_t)2 << 20);  // planes start on 2 MiB boundaries
     const size_t piece = (pitch * rows * sizeof(float) + gran - 1) / gran * gran;
     const bool verbose = std::getenv("CVS_TUNE_VERBOSE") != nullptr;
-    // the pool: the block itself plus at most four more blocks' worth of pieces, and at most 8 GiB of spare memory
-    int pool_n = 5 * nplanes;
+    // the pool: the block itself plus at most six more blocks' worth of pieces, and at most 8 GiB of spare memory
+    int pool_n = 7 * nplanes;   // round 3: seven (was five) blocks of span -- runs of the allocator are ~10 GiB long, a wider pool meets a boundary more often
     while (pool_n > nplanes && (size_t)(pool_n - nplanes) * piece > ((size_t)8 << 30)) pool_n -= nplanes / 2;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (size_t)pool_n * piece + ((size_t)4 << 30)) pool_n = nplanes;

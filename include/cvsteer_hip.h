@@ -84,11 +84,11 @@ enum {
                                       a plain hipMalloc block, no probe, no side effects.  1 (opt-in tuning knob; also
                                       CVS_PLACEMENT_SEARCH=1 in the environment): one physical
                                       allocation per plane, mapped back to back (planes then start on 2 MiB boundaries); when the
-                                      block is allocated, once, five blocks' worth of pieces are created and mapped, a streaming-
-                                      store probe is slid over them (10-12 ms at 4096^2 on the handle's stream) and, if some window
+                                      block is allocated, once, seven blocks' worth of pieces are created and mapped, a streaming-
+                                      store probe is slid over them (15-20 ms at 4096^2 on the handle's stream) and, if some window
                                       of pieces straddles the end of a run of the VRAM allocator, that window becomes the block
                                       (such planes stream at ~7.2 instead of ~5.7 TB/s, see cvs_state.cpp); the spare pieces are
-                                      released again, else everything is and the block is a plain hipMalloc.  Bounded: at most four
+                                      released again, else everything is and the block is a plain hipMalloc.  Bounded: at most six
                                       extra blocks of transient memory and never more than 8 GiB; one search at a time per
                                       process; none under stream capture; each search keeps its virtual range reserved for the
                                       life of the process (address space only, capped at 4 TiB); a chosen window is verified by

@@ -179,7 +179,7 @@ def g4():
     img = torch.rand((n, n), device="cuda")
     g, h = torch.empty_like(img), torch.empty_like(img)
     npix = n * n
-    cands = [(2, 40), (2, 27), (0, 27), (0, 40)] + ([(3, 14), (3, 27), (3, 40), (3, 53), (3, 66)] if os.environ.get("PROBE_G4L") else [])   # split 3: tools/patches/g4_single_kernel_lds_window.patch
+    cands = [(2, 40), (2, 27), (2, 53), (2, 66), (0, 27), (0, 40)] + ([(3, 14), (3, 27), (3, 40), (3, 53), (3, 66)] if os.environ.get("PROBE_G4L") else [])   # split 3: tools/patches/g4_single_kernel_lds_window.patch
     hs = {}
     for sp, sr in cands:
         f = cv.SteerableFiltersG4(None)
