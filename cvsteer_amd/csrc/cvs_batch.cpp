@@ -302,7 +302,10 @@ int run_moves(cvs_batch b, const std::vector<Move>& moves)
 // status before anything is queued) and skips this.  Returns local_rc if that is already an error.
 int agree(cvs_batch b, int local_rc, uint32_t geometry_hash)
 {
-    if (b->transport != TRANSPORT_RCCL || (int)b->slots.size() == b->world) return local_rc;
+    // CVS_BATCH_FORCE_AGREE=1 (tests): a world that lives in one process goes through the agreement too, so that the code
+    // path can be exercised on a box with one GPU (a one-rank RCCL world: the all-reduce is degenerate but real)
+    static const bool force = std::getenv("CVS_BATCH_FORCE_AGREE") != nullptr;
+    if (b->transport != TRANSPORT_RCCL || ((int)b->slots.size() == b->world && !force)) return local_rc;
     Rccl* R = rccl();
     const int h31 = (int)(geometry_hash & 0x3fffffffu);
     int mine[4] = {local_rc, h31, -h31, 0};

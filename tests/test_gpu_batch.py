@@ -270,6 +270,54 @@ def test_byte_output_planes_padded_and_mixed_rejected(cv, world):
     nb.close()
 
 
+_AGREE_SCRIPT = r"""
+import ctypes as C, sys, torch
+import cvsteer_amd as cv
+from cvsteer_amd import batch, _lib as L
+try:
+    nb = batch.NativeBatch.from_torch_distributed(0)
+except cv.CvsError as e:
+    print("SKIP", e); sys.exit(0)
+assert nb.transport == "rccl"
+gen = torch.Generator(device="cuda").manual_seed(3)
+frames = torch.rand((5, 70, 200), device="cuda", generator=gen)
+want = cv.SteerableFiltersG2(None).pipeline_batch(frames, outputs=(5, 6, 7))
+got, t = nb.run(frames, 5, (70, 200), outputs=(5, 6, 7), self_via_transport=True)     # agreement, then scatter / compute / gather
+assert torch.equal(got, want)
+# a root-only failure is an ERROR RETURN after the agreement (nothing queued, the group closed), and the object stays usable
+bad = torch.rand((5, 70, 256), device="cuda", generator=gen)[:, :, :200]               # padded rows: not dense planes
+imgs = (L.Plane * 5)(*[L.Plane(bad[i].data_ptr(), 70, 200, 256 * 4, L.MEM_DEVICE) for i in range(5)])
+outs = (L.Plane * 40)()
+cfg = L.BatchCfg(70, 200, 5, 0xE0, 0, 1, 0)
+tm = L.BatchTiming()
+rc = L.lib().cvs_batch_run(nb._b, C.byref(cfg), imgs, outs, C.byref(tm))
+assert rc == L.E_SIZE, rc
+got2, _ = nb.run(frames, 5, (70, 200), outputs=(5, 6, 7))
+assert torch.equal(got2, want)
+img = torch.rand((300, 400), device="cuda", generator=gen)
+nb.pyramid_setup(img, 300, 400, 3, flags=cv.SETUP_BASIS)
+assert torch.equal(nb.level_plane(0, L.PLANE_BASIS0 + 2), cv.SteerableFiltersG2(img).basis(2))
+nb.close()
+print("AGREE_OK")
+"""
+
+
+def test_status_agreement_path_runs_in_a_one_rank_world(tmp_path):
+    """cvs_batch.cpp agree(): ranks of a multi-process world all-reduce {status, geometry hash} before anything is queued.
+    With CVS_BATCH_FORCE_AGREE=1 a one-rank RCCL world goes through the same code (device scratch, grouped ncclAllReduce,
+    readback), the only way to exercise it on a one-GPU box; a root-side validation failure comes back as an error return
+    with the group closed and the batch still usable."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVS_BATCH_FORCE_AGREE="1", CVS_BATCH_SELF_TRANSPORT="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _AGREE_SCRIPT], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    if "SKIP" in r.stdout:
+        pytest.skip("RCCL not available: " + r.stdout)
+    assert "AGREE_OK" in r.stdout
+
+
 def test_batch_argument_errors(cv):
     import torch
     from cvsteer_amd import batch
