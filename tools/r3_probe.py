@@ -378,5 +378,32 @@ def c4modes():
     print("output tensor at %#x" % out.data_ptr(), flush=True)
 
 
+def pyrcost():
+    """what does the F_PYR emission cost the 8192^2 filter launch?  setup() vs setup_pyr() on two alternating 8192^2 images,
+    one handle each, interleaved rounds; and the same at 4096^2"""
+    for n in (8192, 4096):
+        bigs = [torch.rand((n, n), device="cuda") for _ in range(2 if n == 8192 else 8)]
+        nxt = torch.empty((n // 2, n // 2), device="cuda")
+        fa, fb = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
+        flip = {"i": 0}
+
+        def plain():
+            flip["i"] = (flip["i"] + 1) % len(bigs)
+            fa.setup(bigs[flip["i"]], flags=cv.SETUP_BASIS)
+
+        def fused():
+            flip["i"] = (flip["i"] + 1) % len(bigs)
+            fb.setup_pyr(bigs[flip["i"]], flags=cv.SETUP_BASIS, out=nxt)
+
+        r = {"plain": [], "fused": []}
+        for rnd in range(5):
+            r["plain"].append(timeit(plain, steps=10, warm=3))
+            r["fused"].append(timeit(fused, steps=10, warm=3))
+        for k, bpp in (("plain", 32), ("fused", 33)):
+            ms = med(r[k])
+            print("%d^2 fresh images, %s: %.4f ms  %.3f of HBM (%d B/pix)  strip %d order %d" % (n, k, ms, bpp * n * n / ms / 1e6 / 8000, bpp,
+                  (fa if k == "plain" else fb).launch_info()["strip_rows"], (fa if k == "plain" else fb).launch_info()["block_order"]), flush=True)
+
+
 if __name__ == "__main__":
-    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall, "sc1": sc1, "planepad": planepad, "c4modes": c4modes}[sys.argv[1]]()
+    {"c4strips": c4strips, "pitch": pitch, "c3order": c3order, "g4": g4, "host": host, "firstcall": firstcall, "sc1": sc1, "planepad": planepad, "c4modes": c4modes, "pyrcost": pyrcost}[sys.argv[1]]()
