@@ -325,6 +325,11 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // row" is one unsigned compare.  In the loop the prefetched row y0 - W + (g + 1) NT + j is never above the image
     // (>= y0 + W + 1), so only the lower border reflects: rows >= a.rows mirror to 2 rows - 2 - row, i.e. ro_mir - ro_lin.
     [[maybe_unused]] unsigned ro_lin = (unsigned)(y0 - W + NT - rbase) * in_pitch_b;
+    // 32-bit offsets: every row a launch really reads lies below 2 GiB from the (band-shifted) plane pointer, so ro_lin and a
+    // legitimate mirror offset fit; the image's END need not (a band high up in a plane of many GiB): the limit saturates,
+    // "never reflect", and ro_mir is only ever used modulo 2^32 where the true value fits
+    const unsigned long long ro_lim64 = (unsigned long long)(unsigned)(a.rows - rbase) * in_pitch_b;
+    [[maybe_unused]] const unsigned ro_lim = ro_lim64 > 0xffffffffull ? 0xffffffffu : (unsigned)ro_lim64;
     [[maybe_unused]] const unsigned ro_mir = (unsigned)(2 * a.rows - 2 - 2 * rbase) * in_pitch_b;
     [[maybe_unused]] unsigned oi_run = 0u - (unsigned)(2 * W);                   // output row relative to y0 (wraps below 0)
     [[maybe_unused]] unsigned orow_run = ((unsigned)(y0 - rbase) - (unsigned)(2 * W)) * pitch_b;  // its byte offset in a state plane
@@ -356,9 +361,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             {
                 unsigned ro;
                 if constexpr (B::SRED) {
-                    // rows >= a.rows mirror to ro_mir - ro_lin, which is then the smaller of the two (equal at the last row):
-                    // one subtract and one unsigned minimum, no compare / select
-                    ro = min(ro_lin, ro_mir - ro_lin);
+                    ro = ro_lin >= ro_lim ? ro_mir - ro_lin : ro_lin;
                     ro_lin += in_pitch_b;
                 } else {
                     ro = (unsigned)(reflect1(y0 - W + (g + 1) * NT + j, a.rows) - rbase) * in_pitch_b;

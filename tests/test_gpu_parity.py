@@ -1041,6 +1041,17 @@ def test_narrow_view_of_a_2gib_plane_small_state(cv, ora):
     assert torch.equal(g4, g4w) and torch.equal(h4, h4w)
     for p in (0, 5, 10):
         assert torch.equal(f4.basis(p), w4.basis(p)), p
+    # ... and a plane tall enough that the image's END lies beyond 4 GiB from the upper bands' shifted plane pointers (the
+    # G4 kernels keep running 32-bit row offsets: the reflection limit must saturate there, not wrap)
+    del big, out_big, view
+    rows2 = 40000                                          # 40000 x 32768 f32 = 5.2 GB, three bands
+    big2 = torch.rand((rows2, big_cols), device="cuda", generator=gen)
+    view2 = big2[:, 8192:8192 + 512]
+    g4, h4 = f4.setup_steer(view2, 0.4)
+    g4w, h4w = w4.setup_steer(view2.contiguous(), 0.4)
+    assert torch.equal(g4, g4w) and torch.equal(h4, h4w)
+    for p in (0, 5, 10):
+        assert torch.equal(f4.basis(p), w4.basis(p)), p
 
 
 def test_overlapped_host_path_matches_device_path(cv):
