@@ -122,7 +122,15 @@ hipError_t state_block_alloc_plain(int device, size_t elems, StateBlock& b)
 
 // `mode` 1 = look for a window that straddles a run boundary, else fall back to a plain block; 2 = always take the window
 // in the middle of the pool (tests).  Returns hipSuccess with b.vmm == false whenever the plain block was taken.
+static hipError_t alloc_planes_impl(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b, int attempt);
+
 hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b)
+{
+    return alloc_planes_impl(device, nplanes, rows, pitch, stream, mode, b, 1);
+}
+
+// attempt 1 takes the process-wide search lock; attempt 2 is the retry below and runs inside it
+static hipError_t alloc_planes_impl(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b, int attempt)
 {
     b = StateBlock();
     b.device = device;
@@ -144,8 +152,8 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
     while (pool_n > nplanes && (size_t)(pool_n - nplanes) * piece > ((size_t)8 << 30)) pool_n -= nplanes / 2;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < (size_t)pool_n * piece + ((size_t)4 << 30)) pool_n = nplanes;
-    std::unique_lock<std::mutex> lock(g_place_mutex, std::try_to_lock);
-    if (!lock.owns_lock()) pool_n = nplanes;  // another handle is searching right now: do not disturb its timing
+    std::unique_lock<std::mutex> lock(g_place_mutex, std::defer_lock);
+    if (attempt == 1 && !lock.try_lock()) pool_n = nplanes;  // another handle is searching right now: do not disturb its timing
     if (g_reserved_va.load() + (size_t)pool_n * piece > kMaxReservedVa) pool_n = nplanes;  // address-space budget spent
     if (pool_n <= nplanes) return state_block_alloc_plain(device, plain_elems, b);
 
@@ -290,6 +298,7 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
         (void)hipStreamSynchronize(stream);
     }
     if (mode != 2 && std::getenv("CVS_TEST_NO_WINDOW")) window = -1;  // tests: a box on which the probe finds nothing
+    if (mode != 2 && attempt == 1 && std::getenv("CVS_TEST_FIRST_POOL_EMPTY")) window = -1;  // tests: the retry on a second pool
     if (window >= 0 && !verify_window((char*)pool_va + (size_t)window * piece, nplanes, piece, stream)) {
         // never seen with pieces that are mapped exactly once -- but a window that does not hold what was stored into
         // it must not carry anybody's results: plain blocks from here on, for the life of the process
@@ -297,6 +306,22 @@ hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pi
         g_vmm_distrusted = true;
         window = -1;
         probe_complete = false;
+    }
+    if (window < 0 && attempt == 1 && mode == 1 && probe_complete && !g_vmm_distrusted.load() && !std::getenv("CVS_TEST_NO_WINDOW")) {
+        // Nothing in this pool.  The zones a fast window has to cover lie ~3 GiB apart in allocation order (DESIGN.md section 8,
+        // profiles/r03_placement_structure_probe.txt) but not every stretch of the allocator's memory has one within reach:
+        // over nine boxes one pool in nine found nothing.  ONE retry on a second pool, created while the first is still held --
+        // so that it lies elsewhere -- before the verdict "plain block" is passed and remembered.
+        StateBlock second;
+        const hipError_t e2 = alloc_planes_impl(device, nplanes, rows, pitch, stream, mode, second, 2);
+        if (e2 == hipSuccess && second.vmm) {
+            release_all();
+            b = second;
+            b.probed = true;
+            b.probe_ms = elapsed_ms();
+            return hipSuccess;
+        }
+        if (e2 == hipSuccess) state_block_free(second);   // the retry's plain block: the one below is as good
     }
     if (window < 0) {
         // only a probe that ran to the END and found no window is a verdict (then the next handle of this geometry does
