@@ -274,13 +274,21 @@ def main():
                 return
             done_flag["printed"] = True
             if rank == 0:
-                if not args.no_extra:
-                    out["extra"] = dict(extra)
-                if not final:
-                    out["extra_error"] = why or "incomplete"
-                    out.setdefault("cpu_baseline", None)
+                line = None
+                for _try in range(5):   # the main thread may be adding a leg at this very moment (watchdog / SIGTERM path)
+                    try:
+                        snap = dict(out)
+                        if not args.no_extra:
+                            snap["extra"] = dict(extra)
+                        if not final:
+                            snap["extra_error"] = why or "incomplete"
+                            snap.setdefault("cpu_baseline", None)
+                        line = json.dumps(snap)
+                        break
+                    except RuntimeError:
+                        time.sleep(0.01)
                 sys.stdout.flush()
-                os.write(json_fd, (json.dumps(out) + "\n").encode())
+                os.write(json_fd, ((line or json.dumps({"metric": out["metric"], "value": out.get("value"), "extra_error": why or "incomplete"})) + "\n").encode())
 
     def sigterm_watcher():
         signal.sigwait({signal.SIGTERM})
