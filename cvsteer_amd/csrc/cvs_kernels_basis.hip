@@ -109,7 +109,10 @@ struct Folded {
     float od[B::NO][B::W];
 };
 
-enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8, F_PYR = 16, F_PYRONLY = 32 };  // F_PIPE implies F_ORIENT; F_NOSTATE: outputs only;
+enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8, F_PYR = 16, F_PYRONLY = 32, F_FEAT3 = 64 };  // F_PIPE implies F_ORIENT; F_NOSTATE: outputs only;
+                                                                            // F_FEAT3 (with F_NOSTATE): exactly the three feature maps, find*(magnitude, phase), fastAtan2 --
+                                                                            // what example/steer.cpp keeps -- decided at COMPILE time: no per-output tests and branches in the row
+                                                                            // loop, no second arctangent path in the instruction cache (+3.5 % on 32 x 1080p; same values);
                                                                             // F_PYR: also emit cv::pyrDown(image) (next pyramid level);
                                                                             // F_PYRONLY (with F_PYR): nothing but that -- cvs_pyr_down as a strip march
 
@@ -475,10 +478,12 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 }
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
                     // stateless pipeline: the oriented energy (and with it C1) is evaluated only when asked for
-                    const bool want_e = BATCH == 2 ? (a.out_mask & 4u) != 0 : pipe_out[2].p != nullptr;
-                    const bool need_e = (FLAGS & F_NOSTATE) == 0 || want_e || a.find_on_e != 0;  // wave-uniform
+                    constexpr bool FEAT3 = (FLAGS & F_FEAT3) != 0;
+                    const bool want_e = FEAT3 ? false : (BATCH == 2 ? (a.out_mask & 4u) != 0 : pipe_out[2].p != nullptr);
+                    const bool need_e = FEAT3 ? false : ((FLAGS & F_NOSTATE) == 0 || want_e || a.find_on_e != 0);  // wave-uniform
+                    const int amode = FEAT3 ? 0 : a.atan_mode;   // FEAT3: a compile-time constant, the atan2f path is not even compiled in
                     float c1, c2, c3, th, st;
-                    g2_orientation(b, a.atan_mode, c1, c2, c3, th, st, need_e);
+                    g2_orientation(b, amode, c1, c2, c3, th, st, need_e);
                     if constexpr ((FLAGS & F_NOSTATE) == 0) {
                         const float ov[5] = {c1, c2, c3, th, st};
 #pragma unroll
@@ -498,8 +503,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                             sincos_small(__fmul_rn(th, 2.0f), s2, cc2);
                             q[2] = __fadd_rn(__fadd_rn(c1, __fmul_rn(c2, cc2)), __fmul_rn(c3, s2));
                         }
-                        mag_phase(q[0], q[1], a.atan_mode, q[3], q[4]);
-                        const float en = a.find_on_e ? q[2] : q[3];
+                        mag_phase(q[0], q[1], amode, q[3], q[4]);
+                        const float en = (!FEAT3 && a.find_on_e) ? q[2] : q[3];
                         float le, ld, lb;
                         phase_lambda3<true>(q[4], le, ld, lb);   // one cos / sin pair for the three maps
                         q[5] = __fmul_rn(en, le);
@@ -508,12 +513,12 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         if constexpr (BATCH == 2) {
                             const unsigned orow_out = yo * (unsigned)(a.out_pitch * sizeof(float));
 #pragma unroll
-                            for (int k = 0; k < 8; ++k)
-                                if (a.out_mask & (1u << k)) bst<STREAM>(r_out, xbr, orow_out + a.out_off[k], q[k]);
+                            for (int k = FEAT3 ? 5 : 0; k < 8; ++k)
+                                if (FEAT3 || (a.out_mask & (1u << k))) bst<STREAM>(r_out, xbr, orow_out + a.out_off[k], q[k]);
                         } else {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k)
-                                if (pipe_out[k].p)
+                            for (int k = FEAT3 ? 5 : 0; k < 8; ++k)
+                                if (FEAT3 || pipe_out[k].p)
                                     bst<STREAM>(plane_rsrc(pipe_out[k].p, (size_t)(a.rows - rbase) * pipe_out[k].pitch * sizeof(float)), xbr,
                                                 yo * (unsigned)(pipe_out[k].pitch * sizeof(float)), q[k]);
                         }
@@ -710,7 +715,10 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
         if constexpr (B::KIND == 2 && B::HALF == 0) {
             grid.z = a.batch;
             if (a.batch_regular && a.out_one) {
-                if (a.no_state) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE, 2);
+                // exactly the three feature maps of find*(magnitude, phase) with the compatible arctangent: the specialised instance
+                const bool feat3 = a.no_state && a.out_mask == 0xE0u && !a.find_on_e && a.atan_mode == 0;
+                if (feat3) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE | F_FEAT3, 2);
+                else if (a.no_state) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE, 2);
                 else CVS_LAUNCH_B(F_ORIENT | F_PIPE, 2);
             } else {
                 if (a.no_state) CVS_LAUNCH_B(F_ORIENT | F_PIPE | F_NOSTATE, 1);
@@ -739,10 +747,14 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
             case F_ORIENT: CVS_LAUNCH(F_ORIENT); break;
             case F_STEER: CVS_LAUNCH(F_STEER); break;
             case F_ORIENT | F_STEER: CVS_LAUNCH(F_ORIENT | F_STEER); break;
-            default:
-                if (a.no_state) CVS_LAUNCH(F_ORIENT | F_PIPE | F_NOSTATE);
+            default: {
+                bool feat3 = a.no_state && !a.find_on_e && a.atan_mode == 0;
+                for (int k = 0; k < 8; ++k) feat3 = feat3 && ((a.pipe_out[k].p != nullptr) == (k >= 5));
+                if (feat3) CVS_LAUNCH(F_ORIENT | F_PIPE | F_NOSTATE | F_FEAT3);
+                else if (a.no_state) CVS_LAUNCH(F_ORIENT | F_PIPE | F_NOSTATE);
                 else CVS_LAUNCH(F_ORIENT | F_PIPE);
                 break;
+            }
         }
     } else {
         if (steer) CVS_LAUNCH(F_STEER);

@@ -68,8 +68,8 @@ BANDS_1080 = ((0, 24), (528, 552), (1056, 1080))
 def test_config4_batched_pipeline_32x1080p_state_kept_and_outputs_only(cv, ora):
     """BASELINE config 4 as bench.py times it (legs C4_32x1080p_pipeline_batch / C4_32x1080p_feature_maps_only, C4_e2e):
     cvs::k_basis<BankG2, 5, true, 2, true, 4> (state kept: 12 state planes + 8 outputs per frame, streaming stores, regular
-    batch with one output resource per frame, single state resource) and cvs::k_basis<BankG2, 13, true, 2, true, 4>
-    (outputs only: edges / dark / bright).  32 x 1080 x 1920 in ONE launch each.  Every plane of every frame is compared bit
+    batch with one output resource per frame, single state resource) and cvs::k_basis<BankG2, 77, true, 2, true, 4> (13 | F_FEAT3: the instance specialised at compile time for
+    exactly the three feature maps; outputs only: edges / dark / bright).  32 x 1080 x 1920 in ONE launch each.  Every plane of every frame is compared bit
     for bit with the single-frame pipeline() (cvs::k_basis<BankG2, 5, false, 0, true, 4>: 99.5 MB of state, plain stores),
     and frames 0, 15, 31 with the oracle on top / middle / bottom row bands."""
     import torch
@@ -241,9 +241,9 @@ def _small_shapes():
 def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora):
     """CVS_OPT_STORE_POLICY = 2 (always nontemporal) on the small shapes of the parity fuzz, so that the STREAM = true
     instances meet the oracle in every launch form: single image with the single state resource
-    (cvs::k_basis<BankG2, 0 / 1 / 2 / 3 / 5 / 13, true, 0, true, 4>), the per-plane form of a row-range launch
+    (cvs::k_basis<BankG2, 0 / 1 / 2 / 3 / 5 / 77, true, 0, true, 4>), the per-plane form of a row-range launch
     (cvs::k_basis<BankG2, 0 / 1, true, 0, false, 4>), frames from a device table (cvs::k_basis<BankG2, 5 / 13, true, 1, true, 4>)
-    and the regular batch with one output resource per frame (cvs::k_basis<BankG2, 5 / 13, true, 2, true, 4>); G4 as
+    and the regular batch with one output resource per frame (cvs::k_basis<BankG2, 5 / 77, true, 2, true, 4>; the generic outputs-only instance 13 through a two-map request); G4 as
     cvs::k_basis_pair<BankG4G, BankG4H, 0 / 2, true, true / false>."""
     import torch
     from cvsteer_amd import _lib as L
@@ -316,6 +316,14 @@ def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora):
                     ref = cv.SteerableFiltersG2(None).pipeline(block[i])
                     for j, k in enumerate(sel):
                         assert torch.equal(ob[i, j], ref[k]), (rows, cols, i, k)
+        # the GENERIC outputs-only instance (FLAGS 13: any other subset than the three feature maps): phase + bright lines
+        fg = cv.SteerableFiltersG2(None)
+        fg.set_option(L.OPT_STORE_POLICY, 2)
+        fg.set_persist(False)
+        og = fg.pipeline_batch(block, outputs=(4, 7))
+        for i in range(nb):
+            ref = cv.SteerableFiltersG2(None).pipeline(block[i])
+            assert torch.equal(og[i, 0], ref[4]) and torch.equal(og[i, 1], ref[7]), (rows, cols, i)
         # G4: both halves in one launch, streaming, with and without the fused steer
         f4 = cv.SteerableFiltersG4(None)
         f4.set_option(L.OPT_STORE_POLICY, 2)
