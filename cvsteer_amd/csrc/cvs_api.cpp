@@ -895,16 +895,16 @@ int batch_block_search(cvs_handle h, BasisArgs& a)
     int ncand = 1;
     while (ncand < kCand && (size_t)ncand * bytes + ((size_t)8 << 30) < free_b) ++ncand;   // candidate 0 is the block the handle has
     if (ncand < 2) return CVS_OK;
+    if (!h->ev0) {   // before anything is allocated: a failure here leaves nothing behind
+        HIP_TRY(h, hipEventCreate(&h->ev0));
+        HIP_TRY(h, hipEventCreate(&h->ev1));
+    }
     const auto t_start = std::chrono::steady_clock::now();
     std::vector<StateBlock> cand(ncand);
     cand[0] = h->sb;
     int have = 1;
     for (; have < ncand; ++have)
         if (state_block_alloc_plain(h->device, elems, cand[have]) != hipSuccess) { (void)hipGetLastError(); break; }
-    if (!h->ev0) {
-        HIP_TRY(h, hipEventCreate(&h->ev0));
-        HIP_TRY(h, hipEventCreate(&h->ev1));
-    }
     const ptrdiff_t orient_off = a.orient - a.basis;
     std::vector<float> t(have, std::numeric_limits<float>::max());
     hipError_t e = hipSuccess;
