@@ -174,7 +174,9 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 // the kernel body: one wave filters one strip.  `line` = this wave's LDS line (64 + 2W + 4 floats),
 // `zframe` = frame index of a batched launch.
 // WPB = waves (adjacent 64-column strips of one row band) per workgroup.  Always 4: 8-wave workgroups were built
-// and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones.
+// and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones; one- and
+// two-wave workgroups fill the wave slots better (no slot waits for the slowest of four) but lose 3-12 % on the G2 legs and
+// 7 % on fresh images (profiles/r03_wpb_probe.txt): the four strips of a workgroup write 1 KiB of every plane row from one CU.
 template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB>
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe)
 {

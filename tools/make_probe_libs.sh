@@ -12,7 +12,7 @@
 #   XVALU / XSALU   12 extra independent v_mov / s_mov per row and wave
 #   PW1     pipeline epilogue with ONE cos/sin evaluation for the three phase weights and none for 2*theta (prices those evaluations)
 #   LDAUX<n> input loads issued with cache-policy bits n (2 = nt, 1 = sc0, 3 = nt sc0, 16 = sc1, 18 = nt sc1)
-#   WPB8    eight waves (512 columns) per workgroup instead of four
+#   WPB8    eight waves (512 columns) per workgroup instead of four; WPB1 / WPB2: one / two
 #   PAIRW<n> the G4 pair kernel compiled for n waves per SIMD (register budget 512/n)
 #   ILP     same source, machine scheduler strategy max-ilp (independent accumulation chains interleaved)
 set -eu
@@ -44,6 +44,8 @@ for v in "$@"; do
     ILP)     build $v 's/^$//' "-mllvm -amdgpu-sched-strategy=max-ilp" ;;
     PW1)     build $v 's/q\[6\] = __fmul_rn(en, phase_lambda<true>(q\[4\], 0.f, true));/q[6] = __fmul_rn(en, q[5]);/; s/q\[7\] = __fmul_rn(en, phase_lambda<true>(q\[4\], kPiF, true));/q[7] = __fmul_rn(q[5], q[6]);/; s/sincos_small(__fmul_rn(th, 2.0f), s2, cc2);/s2 = th * c2; cc2 = th * c3;/' ;;
     LDAUX*)  build $v "s/__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0)/__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, ${v#LDAUX})/" ;;
+    WPB1)    build $v 's/constexpr int wpb = 4;/constexpr int wpb = 1;/; s/#define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 4)/#define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 1)/' ;;
+    WPB2)    build $v 's/constexpr int wpb = 4;/constexpr int wpb = 2;/; s/#define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 4)/#define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 2)/' ;;
     WPB8)    build $v 's/constexpr int wpb = 4;/constexpr int wpb = 8;/; s/#define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 4)/#define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 8)/' ;;
     PAIRW*)  build $v "s/__global__ __launch_bounds__(256) void k_basis_pair/__global__ __launch_bounds__(256, ${v#PAIRW}) void k_basis_pair/" ;;
     *) echo "unknown probe $v"; exit 2 ;;
