@@ -1600,6 +1600,10 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.frames = regular ? nullptr : h->frame_tab;
     a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
     a.batch = n;
+    // state kept: frames from the two halves of the batch in flight together (see k_basis); the stateless launch is bound by
+    // the SIMDs and does not care.  CVS_BATCH_WAYS=<n> is a tuning aid (1 = frames in order).
+    a.z_ways = (!a.no_state && n >= 4) ? 2 : 1;
+    if (const char* e = std::getenv("CVS_BATCH_WAYS")) a.z_ways = std::max(1, std::min(n, std::atoi(e)));
     a.frame_stride = h->frame_stride;
     if ((rc = tune_block_order(h, a, nullptr, 16 | 1 | 4 | (a.no_state ? 8 : 0)))) return rc;
     if ((rc = batch_block_search(h, a))) return rc;   // opt-in (CVS_OPT_PLACEMENT_SEARCH = 1), once per block size

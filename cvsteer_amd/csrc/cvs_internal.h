@@ -59,6 +59,7 @@ struct BasisArgs {
     // state planes at basis + z*frame_stride (orient likewise)
     const BatchFrame* frames;  // device pointer, or nullptr = single image / regular batch
     int batch;
+    int z_ways;           // frames are dispatched dealt from z_ways equal parts of the batch in turn (1 = in order)
     // regular batch (frames == nullptr, batch_regular = 1): frame z reads in + z*in_frame_stride and writes
     // pipe_out[k].p + z*out_frame_stride -- pointers from kernel arguments only, no table, no upload
     int batch_regular;

@@ -568,7 +568,21 @@ template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int 
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
     __shared__ float lds[WPB][64 + 2 * B::W + 4];
-    basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB>(a, t, lds[threadIdx.x >> 6], blockIdx.z);
+    // Frame batches with state kept: the frames are dispatched dealt from z_ways equal parts of the batch in turn (0, n/2, 1,
+    // n/2 + 1, ... for two), so that the frames in flight together -- about ten of 1080p -- have their state planes, inputs and
+    // outputs in DISTANT parts of the batch's blocks.  Same reason as the placement windows of cvs_state.cpp: planes written
+    // together stream faster when they come from two runs of the VRAM allocator than from one, and a 3 GB batch block spans
+    // more than one run.  tools/zways_probe.py, 32 x 1080p, same handles and buffers: a "slow" block 0.677 -> 0.752 of the HBM
+    // roofline, a "fast" one 0.717 -> 0.725; four / eight / sixteen parts give less (0.72 / 0.71 / 0.70).
+    unsigned z = blockIdx.z;
+    if constexpr (BATCH != 0) {
+        if (a.z_ways > 1) {
+            const unsigned per = ((unsigned)a.batch + a.z_ways - 1) / a.z_ways;
+            z = (z % a.z_ways) * per + z / a.z_ways;
+            if (z >= (unsigned)a.batch) return;
+        }
+    }
+    basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB>(a, t, lds[threadIdx.x >> 6], z);
 }
 
 // G + H half banks in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
@@ -716,6 +730,8 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     if (a.frames || a.batch_regular) {  // batched caller pipeline: one launch, grid.z = frames (G2 only)
         if constexpr (B::KIND == 2 && B::HALF == 0) {
             grid.z = a.batch;
+            if (a.z_ways < 1 || a.z_ways > a.batch) a.z_ways = 1;
+            if (a.z_ways > 1) grid.z = (unsigned)((a.batch + a.z_ways - 1) / a.z_ways * a.z_ways);   // slots past the batch leave at once
             if (a.batch_regular && a.out_one) {
                 // exactly the three feature maps of find*(magnitude, phase) with the compatible arctangent: the specialised instance
                 const bool feat3 = a.no_state && a.out_mask == 0xE0u && !a.find_on_e && a.atan_mode == 0;

@@ -682,6 +682,31 @@ def test_pipeline_batch_equals_per_frame(cv):
         eng.select_frame(1)
 
 
+def test_pipeline_batch_dispatch_order_of_frames_does_not_show(cv, monkeypatch):
+    """State-keeping batches dispatch their frames dealt from two halves of the batch (k_basis, z_ways; CVS_BATCH_WAYS is the
+    tuning aid): any number of parts, batches that do not divide, the frame-table form -- every plane of every frame as in order."""
+    import torch
+    n = 7
+    block = torch.from_numpy(np.stack([smooth_image(61, 150) + 0.1 * rand_image(61, 150, seed=40 + s) for s in range(n)])).cuda()
+    loose = [block[i].clone() for i in range(n)]                       # separately allocated frames: per-frame pointer table
+    monkeypatch.setenv("CVS_BATCH_WAYS", "1")
+    want = cv.SteerableFiltersG2(None).pipeline_batch(block).clone()
+    for ways in ("2", "3", "4", "7", "50"):
+        monkeypatch.setenv("CVS_BATCH_WAYS", ways)
+        eng = cv.SteerableFiltersG2(None)
+        got = eng.pipeline_batch(block)
+        assert torch.equal(got, want), ways
+        for i in (0, 3, 6):                                            # the state of frame i is frame i's
+            eng.select_frame(i)
+            single = cv.SteerableFiltersG2(None)
+            single.setup(block[i])
+            assert torch.equal(eng.basis(5), single.basis(5)) and torch.equal(eng.getDominantOrientationAngle(), single.getDominantOrientationAngle())
+        got_l = cv.SteerableFiltersG2(None).pipeline_batch(loose)
+        assert torch.equal(got_l, want), ways
+    monkeypatch.delenv("CVS_BATCH_WAYS")
+    assert torch.equal(cv.SteerableFiltersG2(None).pipeline_batch(block), want)   # the default (two parts)
+
+
 def test_pipeline_batch_fallback_paths(cv):
     # host planes (staged frame by frame) and frames too small for the fused kernel: same results
     host = np.stack([rand_image(40, 64, seed=s) for s in range(3)])
