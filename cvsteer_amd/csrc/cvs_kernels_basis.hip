@@ -323,6 +323,13 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 
     const int nrows_in = (yend - y0) + 2 * W;
     const int ngroups = (nrows_in + NT - 1) / NT;
+    // G2: the plain basis / orientation / fused-steer variants (FLAGS 0..3) take the strength-reduced scalar bookkeeping and
+    // the per-lane plane offsets as well (late round 3; ISA per nine rows, single-resource form: M1 995 -> 975 vector and
+    // 655 -> 515 scalar instructions, no SGPR spills left; the headline's fused steer 1181 -> 1113 / 734 -> 583, spill moves
+    // 102 -> 28, 97 VGPRs = four waves per SIMD instead of five; headline loop +1 % on a placement window, +2-3 % on a plain
+    // block, `profiles/r03_g2_sred_probe.txt`).  The pipeline variants keep the old bookkeeping: with the new one they spill.
+    constexpr bool SRED = B::SRED || (B::KIND == 2 && FLAGS < 4);
+    constexpr bool VOFF = B::VOFF || (B::KIND == 2 && FLAGS < 4);
     // Scalar bookkeeping of the row loop, strength-reduced for the banks that ask for it (B::SRED; round 3: the scalar unit
     // is shared by the CU's SIMDs and the G4 kernels feel every scalar instruction -- the pair kernel went from 1574 to 1213
     // scalar and from 3461 to 3347 vector instructions per 13 rows, its SGPR spills from 170 to 46 lane moves): the prefetch row offset and the output row offset advance by one pitch per
@@ -340,7 +347,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     [[maybe_unused]] unsigned orow_run = ((unsigned)(y0 - rbase) - (unsigned)(2 * W)) * pitch_b;  // its byte offset in a state plane
     const unsigned nout = (unsigned)(yend - y0);
     [[maybe_unused]] unsigned xbp[NB];
-    if constexpr (ONE && B::VOFF) {
+    if constexpr (ONE && VOFF) {
 #pragma unroll
         for (int p = 0; p < NB; ++p) xbp[p] = xb + (unsigned)(B::PLANE0 + p) * pstride_b;   // kLaneOff + offset stays out of range
     }
@@ -365,7 +372,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             // a full group (2W+1 rows) of loads stays in flight with a single set of registers
             {
                 unsigned ro;
-                if constexpr (B::SRED) {
+                if constexpr (SRED) {
                     ro = ro_lin >= ro_lim ? ro_mir - ro_lin : ro_lin;
                     ro_lin += in_pitch_b;
                 } else {
@@ -424,7 +431,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             unsigned oi = 0, orow_s = 0;
             bool row_ok;
             [[maybe_unused]] int yout = 0;
-            if constexpr (B::SRED) {
+            if constexpr (SRED) {
                 oi = oi_run;
                 orow_s = orow_run;
                 ++oi_run;
@@ -464,7 +471,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
                 // output row relative to the plane pointers, and its byte offset in a state plane
                 unsigned yo, orow;
-                if constexpr (B::SRED) {
+                if constexpr (SRED) {
                     yo = (unsigned)(y0 - rbase) + oi;
                     orow = orow_s;
                 } else {
@@ -474,7 +481,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 if constexpr ((FLAGS & F_NOSTATE) == 0) {
 #pragma unroll
                     for (int p = 0; p < NB; ++p)
-                        if constexpr (ONE && B::VOFF) bst<STREAM>(r_state, xbp[p], orow, b[p]);
+                        if constexpr (ONE && VOFF) bst<STREAM>(r_state, xbp[p], orow, b[p]);
                         else if constexpr (ONE) bst<STREAM>(r_state, xbr, orow + (unsigned)(B::PLANE0 + p) * pstride_b, b[p]);
                         else bst<STREAM>(plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orow, b[p]);
                 }

@@ -4,8 +4,8 @@ allocation-dependent speed modes (tools/alloc_modes.py) cannot masquerade as an 
 usage: ab_same.py "8=0" "8=32" "8=0,7=8" ...   (option=value[,option=value]; options not named are reset to
 order 0, strip rows auto, default weights).  AB_KIND=4 for the G4 bank, AB_HANDLES=n repeats on n handles."""
 import os, sys, statistics
-os.environ["CVS_PLACEMENT_SEARCH"] = "0"
-os.environ["CVS_AUTOTUNE"] = "0"
+os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")
+os.environ.setdefault("CVS_AUTOTUNE", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cvsteer_amd as cv

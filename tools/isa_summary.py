@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
          "-I" + os.path.join(ROOT, "cvsteer_amd", "csrc"), "-S", "--cuda-device-only"]
+FLAGS += os.environ.get("ISA_EXTRA", "").split()   # e.g. -DCVS_G2_SRED_MASK=15 for a what-if table
 UNITS = [("cvs_kernels_basis.hip", ["-fno-slp-vectorize"]), ("cvs_kernels_point.hip", [])]
 
 def demangle(names):
