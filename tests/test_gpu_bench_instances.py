@@ -232,6 +232,37 @@ def test_m5_pipeline_4096_and_g4_streaming_instances(cv, ora):
         assert np.abs(g4[lo:hi].cpu().numpy() - og).max() <= 1e-6 and np.abs(h4[lo:hi].cpu().numpy() - oh).max() <= 1e-6
 
 
+def test_m3_steer_kernels_4096_streaming(cv, ora):
+    """bench.py legs M3_steer_scalar (cvs::k_point<(PointOp)1, 4, true, true>: scalar theta, 7 planes in, g / h out) and
+    M3_steer_map_full (cvs::k_point<(PointOp)2, 4, true, true>: theta_dom per pixel, g / h / e / magnitude / phase out) at
+    4096 x 4096 -- four pixels per lane, streaming stores, nontemporal loads -- against the oracle on top / middle / bottom
+    bands, from the GPU's own state planes of the band (same op order: 1e-6) and stage by stage."""
+    import torch
+    n = 4096
+    img = torch.rand((n, n), generator=torch.Generator(device="cuda").manual_seed(4321), device="cuda")
+    f = cv.SteerableFiltersG2(None)
+    f.setup(img, flags=cv.SETUP_FULL)
+    g, h = torch.zeros_like(img), torch.zeros_like(img)
+    outs5 = [torch.zeros_like(img) for _ in range(5)]
+    for _ in range(2):
+        f.steer(0.3, out=(g, h))
+        f.steer(None, full=True, out=outs5)
+    torch.cuda.synchronize()
+    coeff = f.coefficients()
+    th = f.getDominantOrientationAngle()
+    for lo, hi in ((0, 16), (2048, 2064), (n - 16, n)):
+        sl = slice(lo, hi)
+        b = np.stack([f.basis(p)[sl].cpu().numpy() for p in range(7)])
+        og, oh = ora.g2_steer_scalar(b, 0.3)
+        assert np.abs(g[sl].cpu().numpy() - og).max() <= 1e-6 and np.abs(h[sl].cpu().numpy() - oh).max() <= 1e-6, lo
+        c = tuple(x[sl].cpu().numpy() for x in coeff)
+        mg, mh, me, mm, mp = ora.g2_steer_map(b, th[sl].cpu().numpy(), c)
+        got = [o[sl].cpu().numpy() for o in outs5]
+        for k, want in enumerate((mg, mh, me, mm)):
+            assert np.abs(got[k] - want).max() <= TOL, (lo, k)
+        assert angle_diff(got[4], mp, 2 * np.pi)[mm > 1e-3].max() <= TOL, lo
+
+
 def _small_shapes():
     rng = np.random.default_rng(2025)
     shapes = [(13, 5), (14, 64), (19, 65), (28, 128), (38, 191), (57, 257), (120, 200)]

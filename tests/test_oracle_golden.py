@@ -288,3 +288,28 @@ def test_shared_phase_weight_identities_hold_against_the_oracle(ora):
         for got, want in zip(mine, ora.find(ones.reshape(1, -1), p.reshape(1, -1))):
             tol = 1e-6 if span <= 4 else 2e-5      # |p| ~ 20: one ulp of the reference's own float differences is 2e-6 rad
             assert np.abs(got.astype(np.float64) - want.reshape(-1)).max() <= tol, span
+
+
+def test_every_timed_kernel_instance_has_a_parity_test():
+    """profiles/r03_kernel_stats_all_legs.csv lists every kernel instance `bench.py` launched in its profiled run;
+    tests/golden/timed_instances.json maps each one to the bench legs that time it and to the `-m gpu` tests that hold it
+    against the oracle (round-2 verdict item 1).  This check keeps the three in step: no timed instance without an entry, no
+    entry that names a test which does not exist."""
+    import csv
+    import glob
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mapping = json.load(open(os.path.join(root, "tests", "golden", "timed_instances.json")))
+    timed = [r[0] for r in csv.reader(open(os.path.join(root, "profiles", "r03_kernel_stats_all_legs.csv"))) if r and r[0].startswith("cvs::")]
+    assert len(timed) >= 20
+    for name in timed:
+        key = name.split("(cvs::ProbePlanes")[0].split("(unsigned char")[0]
+        assert key in mapping, "timed kernel instance without a parity test on record: " + name
+        assert mapping[key]["tests"] and mapping[key]["legs"]
+    defined = set()
+    for f in glob.glob(os.path.join(root, "tests", "test_gpu_*.py")):
+        defined |= set(re.findall(r"^def (test_\w+)", open(f).read(), re.M))
+    for key, entry in mapping.items():
+        for t in entry["tests"]:
+            assert t in defined, (key, t)
