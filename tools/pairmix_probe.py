@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pairmix_probe.py -- G4 pair kernel: half banks as grid.z (all G tiles, then all H tiles) against both halves of a tile
+"""tools/pairmix_probe.py (needs tools/patches/g4_pair_halves_on_one_xcd_probe.patch applied) -- G4 pair kernel: half banks as grid.z (all G tiles, then all H tiles) against both halves of a tile
 on one XCD, eight workgroups apart (CVS_PAIR_MIX=1), same handles, interleaved rounds; values compared as well."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

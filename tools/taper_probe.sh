@@ -1,4 +1,4 @@
-# probe: a shorter last round of strips (CVS_TAPER=percent:rows) against the uniform launch, same box, bench legs
+# probe (needs tools/patches/tapered_strips_probe.patch applied): a shorter last round of strips (CVS_TAPER=percent:rows) against the uniform launch, same box, bench legs
 for T in off 75:10 85:10 90:10 off 60:10; do
   echo "== taper $T"
   if [ $T = off ]; then unset CVS_TAPER; else export CVS_TAPER=$T; fi
