@@ -682,6 +682,32 @@ def test_pipeline_batch_equals_per_frame(cv):
         eng.select_frame(1)
 
 
+@pytest.mark.parametrize("kind", [2, 4])
+def test_impulse_response_is_the_outer_product_of_the_reference_taps(cv, golden_dir, kind):
+    """the HIP filter bank against a known answer that comes from the reference, not from the oracle (tests/known_answers.py):
+    the basis planes of an impulse image are f32(ky * kx) of the reference's own tap tables, bit for bit -- in the interior
+    in two corners (REFLECT_101 adds nothing at the first and last index), at strip borders (columns 63 / 64) -- on the strip kernel
+    (96 x 200), and for two impulses at once"""
+    from known_answers import impulse_planes
+    rows, cols = 96, 200
+    f = cv.SteerableFiltersG2(None) if kind == 2 else cv.SteerableFiltersG4(None)
+    n = 7 if kind == 2 else 11
+    for r, c in ((40, 100), (0, 0), (rows - 1, cols - 1), (17, 63), (50, 64), (60, 191)):
+        img = np.zeros((rows, cols), np.float32)
+        img[r, c] = 1.0
+        f.setup(img)
+        got = _basis_stack(f, n)
+        want = impulse_planes(golden_dir, kind, rows, cols, r, c)
+        assert np.array_equal(got, want), (kind, r, c)
+    # linearity, exactly: two impulses far enough apart not to meet are the sum of two responses with no value added twice
+    img = np.zeros((rows, cols), np.float32)
+    img[20, 30] = 1.0
+    img[70, 150] = 1.0
+    f.setup(img)
+    want = impulse_planes(golden_dir, kind, rows, cols, 20, 30) + impulse_planes(golden_dir, kind, rows, cols, 70, 150)
+    assert np.array_equal(_basis_stack(f, n), want)
+
+
 def test_pipeline_batch_dispatch_order_of_frames_does_not_show(cv, monkeypatch):
     """State-keeping batches dispatch their frames dealt from two halves of the batch (k_basis, z_ways; CVS_BATCH_WAYS is the
     tuning aid): any number of parts, batches that do not divide, the frame-table form -- every plane of every frame as in order."""

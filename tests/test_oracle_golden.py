@@ -290,6 +290,26 @@ def test_shared_phase_weight_identities_hold_against_the_oracle(ora):
             assert np.abs(got.astype(np.float64) - want.reshape(-1)).max() <= tol, span
 
 
+@pytest.mark.parametrize("kind", [2, 4])
+@pytest.mark.parametrize("where", ["interior", "corner", "far corner"])
+def test_impulse_response_is_the_outer_product_of_the_reference_taps(ora, golden_dir, kind, where):
+    """a known answer anchored on the reference itself (tests/known_answers.py): every basis plane of an impulse image is
+    f32(ky * kx) of the reference's own taps, to the bit -- for the f32 restatement and, rounded once more, for the f64 truth"""
+    from known_answers import DEFAULTS, impulse_planes
+    w, s = DEFAULTS[kind]
+    rows, cols = 41, 53
+    r, c = {"interior": (20, 26), "corner": (0, 0), "far corner": (rows - 1, cols - 1)}[where]
+    img = np.zeros((rows, cols), np.float32)
+    img[r, c] = 1.0
+    want = impulse_planes(golden_dir, kind, rows, cols, r, c)
+    got = ora.basis(kind, img, w, s)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ora.basis(kind, img, w, s, f64=True).astype(np.float32), want)
+    # an impulse of another height scales every value exactly (one product more would round twice: compare with tolerance)
+    img[r, c] = 3.0
+    assert np.abs(ora.basis(kind, img, w, s) - 3.0 * want).max() <= 1e-6
+
+
 def test_every_timed_kernel_instance_has_a_parity_test():
     """profiles/r03_kernel_stats_all_legs.csv lists every kernel instance `bench.py` launched in its profiled run;
     tests/golden/timed_instances.json maps each one to the bench legs that time it and to the `-m gpu` tests that hold it
