@@ -605,8 +605,8 @@ __global__ __launch_bounds__(256) void k_basis_pair(const BasisArgs a, const Fol
 
 // ---------------------------------------------------------------------------------------
 // generic-width fallback (any width <= kMaxWidth, any taps): two plain passes through a
-// scratch plane, one basis plane at a time.  Same summation order as the CPU reference's
-// generic RowFilter / ColumnFilter.  Not tuned: the reference's defaults (G2 w=4, G4 w=6)
+// scratch plane, one basis plane at a time.  Same structure as the CPU reference's generic RowFilter and its column
+// filters (folded for mirror / anti-mirror kernels, plain otherwise).  Not tuned: the reference's defaults (G2 w=4, G4 w=6)
 // never take this path.
 // ---------------------------------------------------------------------------------------
 struct TapVec {
@@ -625,14 +625,26 @@ __global__ __launch_bounds__(256) void k_rowpass_generic(const float* in, size_t
     out[(size_t)y * out_pitch + x] = acc;
 }
 
+// sym = +1 / -1: the column kernel is a mirror / anti-mirror image of itself and the CPU reference takes its folded column
+// filter (SymmColumnFilter: k0 c + sum k_i (S[+i] +/- S[-i]); the anti-mirror form never touches the centre row -- which is
+// what decides where a non-finite pixel shows up); 0: the plain sum over all taps
 __global__ __launch_bounds__(256) void k_colpass_generic(const float* in, size_t in_pitch, int rows, int cols,
-                                                          float* out, size_t out_pitch, TapVec ky, int w)
+                                                          float* out, size_t out_pitch, TapVec ky, int w, int sym)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= cols || y >= rows) return;
-    float acc = ky.k[0] * in[(size_t)reflect101(y - w, rows) * in_pitch + x];
-    for (int j = 1; j <= 2 * w; ++j) acc = fmaf(ky.k[j], in[(size_t)reflect101(y - w + j, rows) * in_pitch + x], acc);
+    float acc;
+    if (sym != 0) {
+        acc = sym > 0 ? ky.k[w] * in[(size_t)y * in_pitch + x] : 0.0f;
+        for (int j = 1; j <= w; ++j) {
+            const float hi = in[(size_t)reflect101(y + j, rows) * in_pitch + x], lo = in[(size_t)reflect101(y - j, rows) * in_pitch + x];
+            acc = fmaf(ky.k[w + j], sym > 0 ? hi + lo : hi - lo, acc);
+        }
+    } else {
+        acc = ky.k[0] * in[(size_t)reflect101(y - w, rows) * in_pitch + x];
+        for (int j = 1; j <= 2 * w; ++j) acc = fmaf(ky.k[j], in[(size_t)reflect101(y - w + j, rows) * in_pitch + x], acc);
+    }
     out[(size_t)y * out_pitch + x] = acc;
 }
 
@@ -832,8 +844,13 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
         TapVec kx, ky;
         for (int i = 0; i < 2 * width + 1; ++i) { kx.k[i] = taps[ix][i]; ky.k[i] = taps[iy][i]; }
         hipLaunchKernelGGL(k_rowpass_generic, grid, block, 0, s, a.in, a.in_pitch, a.rows, a.cols, scratch, a.pitch, kx, width);
+        int sym = 1, asym = ky.k[width] == 0.0f ? 1 : 0;
+        for (int i = 1; i <= width; ++i) {
+            if (ky.k[width + i] != ky.k[width - i]) sym = 0;
+            if (ky.k[width + i] != -ky.k[width - i]) asym = 0;
+        }
         hipLaunchKernelGGL(k_colpass_generic, grid, block, 0, s, (const float*)scratch, a.pitch, a.rows, a.cols,
-                           a.basis + (size_t)p * a.plane_stride, a.pitch, ky, width);
+                           a.basis + (size_t)p * a.plane_stride, a.pitch, ky, width, sym ? 1 : asym ? -1 : 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -796,6 +796,24 @@ def test_non_finite_inputs_propagate_like_the_reference(cv, ora):
     g2, h2, e, m, p = f.steer(0.3, full=True)
     assert np.isfinite(p).all()          # patchNaNs (G2.cpp:111)
     assert not np.isfinite(m[20, 30])
+    # every plane of both banks, on the strip kernels and on the two-pass fallback (images too small for the strips, and a
+    # non-default width): NaN and Inf sit exactly where the reference's filters put them -- the row filter multiplies the
+    # zero centre tap of an odd kernel in (0 * Inf = NaN), its folded column filter never touches the centre row.
+    # (tools/fuzz_campaign.py found the fallback's column pass summing all taps: a wider footprint for odd column kernels.)
+    rng = np.random.default_rng(99)
+    for kind, w, s_, rows, cols in ((2, 4, 0.67, 48, 64), (4, 6, 0.5, 48, 64), (2, 4, 0.67, 12, 40), (2, 4, 0.67, 30, 4), (4, 6, 0.5, 14, 127),
+                                    (4, 6, 0.5, 5, 90), (2, 4, 0.67, 6, 21), (2, 6, 0.5, 40, 50), (4, 8, 0.4, 60, 70), (2, 4, 0.67, 1, 1)):
+        img = rng.random((rows, cols), dtype=np.float32)
+        for v in (np.nan, np.inf, -np.inf):
+            img[rng.integers(0, rows), rng.integers(0, cols)] = v
+        f = cv.SteerableFiltersG2(img, w, s_) if kind == 2 else cv.SteerableFiltersG4(img, w, s_)
+        n = 7 if kind == 2 else 11
+        got = _basis_stack(f, n)
+        want = ora.basis(kind, img, w, s_)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (kind, w, rows, cols)
+        assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want)), (kind, w, rows, cols)
+        ok = np.isfinite(want)
+        assert np.abs(got[ok] - want[ok]).max(initial=0.0) <= TOL, (kind, w, rows, cols)
 
 
 def test_stateless_pipeline_outputs_only(cv):
