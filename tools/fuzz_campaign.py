@@ -26,6 +26,8 @@ def angle_diff(a, b, period):
 
 def pick_shape():
     mode = rng.integers(0, 5)
+    if rng.integers(0, 25) == 0:      # now and then an image large enough for streaming stores and many strips per wave slot
+        return int(rng.integers(1200, 2600)), int(rng.integers(1500, 3300))
     if mode == 0:
         return int(rng.integers(1, 24)), int(rng.integers(1, 24))
     if mode == 1:
@@ -92,17 +94,26 @@ for it in range(iters):
         opts[L.OPT_STORE_POLICY] = int(rng.choice([0, 1, 2]))
     if kind == 4 and rng.integers(0, 2):
         opts[L.OPT_G4_SPLIT] = int(rng.integers(0, 3))
-    entry = str(rng.choice(["setup", "setup_steer", "pipeline", "batch", "rows"]))
+    entry = str(rng.choice(["setup", "setup_steer", "pipeline", "batch", "rows", "pyr"]))
+    custom = bool(rng.integers(0, 6) == 0)   # a non-default (width, spacing): the two-pass fallback at every size
+    cw, cs = int(rng.integers(1, 9)), float(np.float32(rng.uniform(0.3, 1.0)))
+    if custom and entry in ("pipeline", "batch", "pyr"):
+        entry = "setup"
     theta = float(rng.uniform(-4, 4))
     desc = dict(it=it, seed=seed, nonfinite=nonfinite, kind=kind, rows=rows, cols=cols, device=device, strided=strided, opts=opts, entry=entry, theta=round(theta, 4))
     try:
         w, s = (4, 0.67) if kind == 2 else (6, 0.5)
+        if custom:
+            w, s = cw, cs
+            desc["width"], desc["spacing"] = w, s
         nb = 7 if kind == 2 else 11
-        f = cv.SteerableFiltersG2(None) if kind == 2 else cv.SteerableFiltersG4(None)
+        f = cv.SteerableFiltersG2(None, w, s) if kind == 2 else cv.SteerableFiltersG4(None, w, s)
         for o, v in opts.items():
             f.set_option(o, v)
         x = as_plane(img, device, strided)
         truth = ora.basis(kind, img, w, s, f64=True)
+        fin_t = truth[np.isfinite(truth)]
+        scale = max(scale, float(np.abs(fin_t).max()) if fin_t.size else 1.0)   # wide / dense tap sets have gains of 30 and more
         if nonfinite:
             entry = "setup"
             f.setup(x, flags=cv.SETUP_BASIS)
@@ -175,6 +186,22 @@ for it in range(iters):
                 for j, k in enumerate(range(8) if sel is None else sel):
                     assert np.array_equal(to_np(out[i][j]), to_np(single[k]), equal_nan=True), "batch frame %d output %d" % (i, k)
             desc["n"], desc["ways"], desc["persist"] = n, ways, persist
+        elif entry == "pyr":
+            if kind == 4:
+                kind = 2
+                f = cv.SteerableFiltersG2(None)
+                for o, v in opts.items():
+                    if o != L.OPT_G4_SPLIT:
+                        f.set_option(o, v)
+                nb, truth = 7, ora.basis(2, img, 4, 0.67, f64=True)
+            want = ora.pyr_down(img)
+            down = f.pyrDown(x)
+            assert np.array_equal(to_np(down), want), "pyrDown"
+            flags = cv.SETUP_FULL if rng.integers(0, 2) else cv.SETUP_BASIS
+            nxt = f.setup_pyr(x, flags=flags)
+            assert np.array_equal(to_np(nxt), want), "next level written by the filter launch"
+            got = np.stack([to_np(f.basis(p)) for p in range(nb)])
+            assert np.abs(got - truth).max() <= TOL * scale, "basis of the fused pyramid launch"
         else:  # rows: a row range of the image (cvs_setup_rows); needs a device image
             if rows < 2:
                 continue
