@@ -122,6 +122,54 @@ int check_plane(cvs_handle h, const cvs_plane* p, const char* name, bool allow_u
         if (p->step < (size_t)p->cols) return fail(h, CVS_E_SIZE, "bad step");
     } else if (p->step < (size_t)p->cols * sizeof(float) || p->step % sizeof(float)) {
         return fail(h, CVS_E_SIZE, "bad step");
+    } else if (reinterpret_cast<uintptr_t>(p->data) % alignof(float)) {
+        return fail(h, CVS_E_BADARG, "f32 plane not aligned to 4 bytes");   // a float* the C language itself does not allow
+    }
+    return CVS_OK;
+}
+
+// Do two planes share a byte?  Same kind of memory only (a host plane and a device plane never do).  Planes with the same row
+// step are compared exactly -- two column ranges of one buffer side by side (ROI views) interleave in address space without
+// sharing anything --, planes with different steps by their address ranges (conservative).
+bool planes_overlap(const cvs_plane* a, const cvs_plane* b)
+{
+    if (!a || !b || !a->data || !b->data || mem_of(a) != mem_of(b)) return false;
+    auto width = [](const cvs_plane* p) { return (size_t)p->cols * (is_u8(p) ? 1 : sizeof(float)); };
+    auto extent = [&](const cvs_plane* p) { return (size_t)(p->rows - 1) * p->step + width(p); };
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(a->data), pb = reinterpret_cast<uintptr_t>(b->data);
+    if (pa + extent(a) <= pb || pb + extent(b) <= pa) return false;
+    if (a->step != b->step || a->step == 0) return true;
+    const cvs_plane* lo = pa <= pb ? a : b;
+    const cvs_plane* hi = pa <= pb ? b : a;
+    const size_t d = (size_t)(reinterpret_cast<uintptr_t>(hi->data) - reinterpret_cast<uintptr_t>(lo->data));
+    const size_t r = d / lo->step, c = d % lo->step;   // hi's first pixel sits at (row r, byte column c) of lo's frame
+    return (r < (size_t)lo->rows && c < width(lo)) || (r + 1 < (size_t)lo->rows && c + width(hi) > lo->step);
+}
+
+// outputs of one call: none may share memory with the input it is computed from (the kernels read rows ahead of the rows
+// they write, and the overlapped host path downloads results while later rows are still being uploaded), nor with another output
+int check_no_overlap(cvs_handle h, const cvs_plane* input, const cvs_plane* const* outs, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        if (!outs[i] || !outs[i]->data) continue;
+        if (input && planes_overlap(outs[i], input)) return fail(h, CVS_E_BADARG, "an output plane overlaps the input image");
+        for (int j = i + 1; j < n; ++j)
+            if (outs[j] && planes_overlap(outs[i], outs[j])) return fail(h, CVS_E_BADARG, "two output planes overlap each other");
+    }
+    return CVS_OK;
+}
+
+// per-pixel stages read a pixel and write the same pixel: an output may BE an input (same first pixel, same step -- the
+// reference itself calls wrap(m_theta, m_theta)), but it may not overlap one in any other way, nor another output
+int check_point_overlaps(cvs_handle h, std::initializer_list<const cvs_plane*> ins, std::initializer_list<const cvs_plane*> outs)
+{
+    for (auto o = outs.begin(); o != outs.end(); ++o) {
+        if (!*o || !(*o)->data) continue;
+        for (const cvs_plane* i : ins)
+            if (i && planes_overlap(*o, i) && !((*o)->data == i->data && (*o)->step == i->step))
+                return fail(h, CVS_E_BADARG, "an output plane overlaps an input plane without being it");
+        for (auto q = o + 1; q != outs.end(); ++q)
+            if (*q && planes_overlap(*o, *q)) return fail(h, CVS_E_BADARG, "two output planes overlap each other");
     }
     return CVS_OK;
 }
@@ -736,8 +784,8 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     if (rc) return rc;
     if (pyr) {  // the next pyramid level, written by the same pass (cvs_setup_pyr)
         if ((rc = check_plane(h, pyr, "next_level")) || (rc = check_same(h, pyr, (image->rows + 1) / 2, (image->cols + 1) / 2))) return rc;
-        if (pyr->data == image->data) return fail(h, CVS_E_BADARG, "an output plane aliases the input image");
     }
+    if (flags & ~(unsigned)CVS_SETUP_FULL) return fail(h, CVS_E_BADARG, "unknown setup flags");
     if (!(flags & CVS_SETUP_BASIS)) flags |= CVS_SETUP_BASIS;
     if ((flags & CVS_SETUP_ORIENT) && h->kind != CVS_KIND_G2 && !h->g4_ext)
         return fail(h, CVS_E_UNSUPPORTED, "the reference computes no orientation for G4 (G4.cpp:67-81); see CVS_OPT_G4_EXTENSIONS");
@@ -745,13 +793,13 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         if ((rc = check_plane(h, g, "g")) || (rc = check_plane(h, hq, "hq"))) return rc;
         if ((rc = check_same(h, g, image->rows, image->cols)) || (rc = check_same(h, hq, image->rows, image->cols))) return rc;
     }
-    // the kernel reads rows ahead of the rows it writes: an output that aliases the input would be
+    // the kernel reads rows ahead of the rows it writes: an output that shares memory with the input would be
     // clobbered mid-flight (the reference's sepFilter2D copies in that case; here it is an error)
     {
-        const cvs_plane* outs_chk[10] = {steer ? g : nullptr, steer ? hq : nullptr};
+        const cvs_plane* outs_chk[11] = {steer ? g : nullptr, steer ? hq : nullptr};
         for (int k = 0; k < 8; ++k) outs_chk[2 + k] = pipe_outs ? pipe_outs[k] : nullptr;
-        for (const cvs_plane* o : outs_chk)
-            if (o && o->data == image->data) return fail(h, CVS_E_BADARG, "an output plane aliases the input image");
+        outs_chk[10] = pyr;
+        if ((rc = check_no_overlap(h, image, outs_chk, 11))) return rc;
     }
     const size_t pitch = round_up((size_t)image->cols, 64);
     size_t max_pitch = std::max(pitch, is_u8(image) ? pitch : image->step / sizeof(float));
@@ -958,6 +1006,7 @@ int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map
         return fail(h, CVS_E_UNSUPPORTED, "G4 has no energy / magnitude / phase in the reference (G4.cpp:88-90); see CVS_OPT_G4_EXTENSIONS");
     if (e && (rc = need_state(h, true))) return rc;
     if (map && !theta_map && (rc = need_state(h, true))) return rc;
+    if ((rc = check_point_overlaps(h, {theta_map}, {g, hq, e, mag, phase}))) return rc;
 
     Call c;
     if ((rc = begin(h, c, {g, hq, e, mag, phase, theta_map}))) return rc;
@@ -1345,6 +1394,7 @@ int cvs_mag_phase(cvs_handle h, const cvs_plane* g, const cvs_plane* hq, const c
         if (!p) continue;
         if ((rc = check_plane(h, p, "plane")) || (rc = check_same(h, p, g->rows, g->cols))) return rc;
     }
+    if ((rc = check_point_overlaps(h, {g, hq}, {mag, phase}))) return rc;
     Call c;
     if ((rc = begin(h, c, {g, hq, mag, phase}))) return rc;
     PointArgs a{};
@@ -1365,6 +1415,7 @@ int cvs_phase_weights(cvs_handle h, const cvs_plane* phase, const cvs_plane* lam
     int rc;
     if ((rc = check_plane(h, phase, "phase")) || (rc = check_plane(h, lambda, "lambda"))) return rc;
     if ((rc = check_same(h, lambda, phase->rows, phase->cols))) return rc;
+    if ((rc = check_point_overlaps(h, {phase}, {lambda}))) return rc;
     Call c;
     if ((rc = begin(h, c, {phase, lambda}))) return rc;
     PointArgs a{};
@@ -1384,6 +1435,7 @@ int cvs_wrap(cvs_handle h, const cvs_plane* angle, const cvs_plane* out)
     int rc;
     if ((rc = check_plane(h, angle, "angle")) || (rc = check_plane(h, out, "out"))) return rc;
     if ((rc = check_same(h, out, angle->rows, angle->cols))) return rc;
+    if ((rc = check_point_overlaps(h, {angle}, {out}))) return rc;
     Call c;
     if ((rc = begin(h, c, {angle, out}))) return rc;
     PointArgs a{};
@@ -1406,6 +1458,7 @@ int cvs_find(cvs_handle h, const cvs_plane* e, const cvs_plane* phase, const cvs
         if (!p) continue;
         if ((rc = check_plane(h, p, "plane")) || (rc = check_same(h, p, e->rows, e->cols))) return rc;
     }
+    if ((rc = check_point_overlaps(h, {e, phase}, {edges, dark, bright}))) return rc;
     Call c;
     if ((rc = begin(h, c, {e, phase, edges, dark, bright}))) return rc;
     PointArgs a{};
@@ -1448,7 +1501,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
             const cvs_plane* o = &outs[(size_t)i * 8 + k];
             if (!o->data) continue;
             if ((rc = check_plane(h, o, "out")) || (rc = check_same(h, o, rows, cols))) return rc;
-            if (o->data == images[i].data) return fail(h, CVS_E_BADARG, "an output plane aliases the input image");
+            if (planes_overlap(o, &images[i])) return fail(h, CVS_E_BADARG, "an output plane overlaps the input image");
             all_dev = all_dev && o->mem == CVS_MEM_DEVICE;
             max_bytes = std::max(max_bytes, (size_t)rows * o->step);
         }
@@ -1645,6 +1698,7 @@ int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst)
     int rc;
     if ((rc = check_plane(h, src, "src")) || (rc = check_plane(h, dst, "dst"))) return rc;
     if ((rc = check_same(h, dst, (src->rows + 1) / 2, (src->cols + 1) / 2))) return rc;
+    if (planes_overlap(src, dst)) return fail(h, CVS_E_BADARG, "the level overlaps the image it is made from");
     Call c;
     if ((rc = begin(h, c, {src, dst}))) return rc;
     PlaneRef in, out;

@@ -46,6 +46,15 @@ enum {
     CVS_E_UNSUPPORTED = -6  /* operation the reference does not define for this kind */
 };
 
+/* Planes that share memory.  The reference never checks (an output that overlaps its input gives whatever OpenCV's loops
+ * happen to produce).  Here it is CVS_E_BADARG, for host planes and device planes alike:
+ *   - filter-bank entries (cvs_setup*, cvs_pipeline*, cvs_pyr_down): no output may share a byte with the input image (the
+ *     kernels read rows ahead of the rows they write) or with another output;
+ *   - per-pixel entries (cvs_steer_*, cvs_mag_phase, cvs_phase_weights, cvs_find, cvs_wrap): an output may BE an input -- same
+ *     first pixel, same step; the reference itself calls wrap(m_theta, m_theta) -- but may not overlap one in any other way,
+ *     nor another output.
+ * Two views with the same step are compared exactly (column ranges of one buffer side by side share nothing and are fine);
+ * views with different steps by their address ranges.  f32 planes must be 4-byte aligned. */
 enum { CVS_KIND_G2 = 2, CVS_KIND_G4 = 4 };
 enum { CVS_MEM_HOST = 0, CVS_MEM_DEVICE = 1 };
 /* OR-ed into cvs_plane.mem of an INPUT IMAGE (cvs_setup / cvs_setup_steer / cvs_pipeline[_batch]): `data` points

@@ -782,6 +782,69 @@ def test_point_steer_follows_selected_frame_and_alias_is_rejected(cv):
     assert ei.value.status == -1
 
 
+def test_planes_that_share_memory(cv):
+    """include/cvsteer_hip.h, "Planes that share memory": filter-bank entries refuse an output that shares a byte with the input
+    image or with another output; per-pixel entries allow an output that IS an input and nothing else; two column ranges of one
+    buffer side by side (ROI views: interleaved addresses, nothing shared) are fine and give the contiguous case's values;
+    host planes follow the same rules; unknown setup flags and misaligned f32 planes are refused; the handle survives it all."""
+    import ctypes as C
+    import torch
+    from cvsteer_amd.api import _plane
+    lib = cv.lib()
+    f = cv.SteerableFiltersG2(None)
+    h = f._h
+
+    def steer(img, g, hq):
+        return lib.cvs_setup_steer(h, C.byref(_plane(img)), cv.SETUP_BASIS, C.c_float(0.3), C.byref(_plane(g)), C.byref(_plane(hq)))
+
+    big = torch.rand((80, 120), device="cuda")
+    left, right = big[:40, 0:50], big[:40, 60:110]
+    h2 = torch.empty((40, 50), device="cuda")
+    assert steer(left, right, h2) == 0
+    torch.cuda.synchronize()
+    ref_g, ref_h = cv.SteerableFiltersG2(None).setup_steer(left.contiguous(), 0.3)
+    assert torch.equal(right, ref_g) and torch.equal(h2, ref_h)
+    assert steer(big[:40, 0:50], big[:40, 45:95], h2) == -1          # columns overlap by five
+    assert b"overlaps the input" in lib.cvs_last_error(h)
+    assert steer(big[0:40, 0:50], big[20:60, 0:50], h2) == -1        # rows overlap
+    assert steer(big[0:40, 0:50], big[40:80, 0:50], h2) == 0         # rows disjoint
+    g2 = torch.empty((40, 50), device="cuda")
+    assert steer(left, g2, g2) == -1 and b"two output planes" in lib.cvs_last_error(h)
+    assert steer(left, left, h2) == -1
+    from cvsteer_amd.api import Plane
+    p5, p6 = _plane(g2), _plane(g2[:, :])                            # two of the eight pipeline outputs on one plane
+    outs = (C.POINTER(Plane) * 8)(*([None] * 5 + [C.pointer(p5), C.pointer(p6), None]))
+    assert lib.cvs_pipeline(h, C.byref(_plane(left)), outs) == -1
+    assert lib.cvs_setup(h, C.byref(_plane(left)), 0xffff) == -1 and b"unknown setup flags" in lib.cvs_last_error(h)
+    crooked = _plane(g2)
+    crooked.data += 2
+    assert lib.cvs_setup(h, C.byref(crooked), cv.SETUP_FULL) == -1
+    lvl = torch.empty((20, 25), device="cuda")
+    assert lib.cvs_pyr_down(h, C.byref(_plane(g2)), C.byref(_plane(lvl))) == 0
+    assert lib.cvs_pyr_down(h, C.byref(_plane(g2)), C.byref(_plane(g2[:20, :25]))) == -1
+    # per-pixel entries: in place yes, shifted no -- device and host
+    ang = torch.rand((40, 50), device="cuda") * 9
+    want = f.wrap(ang.clone())
+    assert lib.cvs_wrap(h, C.byref(_plane(ang)), C.byref(_plane(ang))) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ang, want)
+    buf = torch.rand((41, 50), device="cuda")
+    assert lib.cvs_wrap(h, C.byref(_plane(buf[0:40])), C.byref(_plane(buf[1:41]))) == -1
+    hb = np.random.default_rng(3).random((41, 50), dtype=np.float32) * 9
+    hwant = f.wrap(hb[0:40].copy())
+    assert lib.cvs_wrap(h, C.byref(_plane(hb[0:40])), C.byref(_plane(hb[1:41]))) == -1
+    assert lib.cvs_wrap(h, C.byref(_plane(hb[0:40])), C.byref(_plane(hb[0:40]))) == 0
+    assert np.array_equal(hb[0:40], hwant)
+    e, ph = torch.rand((40, 50), device="cuda"), torch.rand((40, 50), device="cuda")
+    o = torch.empty((40, 50), device="cuda")
+    assert lib.cvs_find(h, C.byref(_plane(e)), C.byref(_plane(ph)), C.byref(_plane(e)), C.byref(_plane(o)), None) == 0     # edges onto e
+    assert lib.cvs_find(h, C.byref(_plane(e)), C.byref(_plane(ph)), C.byref(_plane(o)), C.byref(_plane(o)), None) == -1   # two outputs, one plane
+    assert lib.cvs_mag_phase(h, C.byref(_plane(e)), C.byref(_plane(ph)), C.byref(_plane(e)), C.byref(_plane(ph))) == 0    # both in place
+    # after all that the handle still works
+    g, hq = f.setup_steer(left.contiguous(), 0.3)
+    assert torch.equal(g, ref_g)
+
+
 def test_non_finite_inputs_propagate_like_the_reference(cv, ora):
     """NaN / Inf pixels: basis planes carry them exactly where the 9x9 support touches them; phase is patched to 0"""
     img = rand_image(48, 64, seed=5)
