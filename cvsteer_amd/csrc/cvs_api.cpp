@@ -1501,9 +1501,13 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
             const cvs_plane* o = &outs[(size_t)i * 8 + k];
             if (!o->data) continue;
             if ((rc = check_plane(h, o, "out")) || (rc = check_same(h, o, rows, cols))) return rc;
-            if (planes_overlap(o, &images[i])) return fail(h, CVS_E_BADARG, "an output plane overlaps the input image");
             all_dev = all_dev && o->mem == CVS_MEM_DEVICE;
             max_bytes = std::max(max_bytes, (size_t)rows * o->step);
+        }
+        if (outs) {
+            const cvs_plane* po[8];
+            for (int k = 0; k < 8; ++k) po[k] = outs[(size_t)i * 8 + k].data ? &outs[(size_t)i * 8 + k] : nullptr;
+            if ((rc = check_no_overlap(h, &images[i], po, 8))) return rc;
         }
     }
     // 8-bit frames that lie back to back on the device (a driver's upload of a block of byte images): widened by ONE
