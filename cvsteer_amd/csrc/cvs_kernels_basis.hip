@@ -49,9 +49,11 @@ struct BankG2 {  // SteerableFiltersG2.cpp:62-68
     static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3, 5}; return t[r]; }
     static constexpr int dup_a = 1, dup_b = 4;  // m_g2 == m_h2 bit for bit
     static constexpr int PLANE0 = 0, HALF = 0;  // first basis plane written; 0 = whole bank
-    static constexpr bool VOFF = false;         // plane offsets of the single-resource form in per-lane registers (see BankG4G)
-    static constexpr bool SRED = false;         // strength-reduced scalar bookkeeping of the row loop (see basis_body): the G2
-                                                // kernels are memory-bound and short of SGPRs -- the extra live scalars spill
+    // plane offsets in per-lane registers (VOFF, see BankG4G) and the strength-reduced scalar bookkeeping of the row loop (SRED,
+    // see basis_body): off for the bank as a whole -- the pipeline variants are short of SGPRs and spill with it --, switched
+    // on per variant in basis_body for the basis / orientation / fused-steer launches (FLAGS 0..3)
+    static constexpr bool VOFF = false;
+    static constexpr bool SRED = false;
 };
 
 struct BankG4 {  // SteerableFiltersG4.cpp:69-80
