@@ -131,7 +131,13 @@ for it in range(iters):
             got = np.stack([to_np(f.basis(p)) for p in range(nb)])
             assert np.abs(got - truth).max() <= TOL * scale, "basis"
             if flags == cv.SETUP_FULL:
-                o1, o2, o3, oth, ost = ora.g2_orientation(got)
+                exact = bool(rng.integers(0, 3) == 0)   # CVS_OPT_ATAN_MODE = 1: atan2f instead of OpenCV's polynomial
+                desc["atan_exact"] = exact
+                if exact:
+                    f.set_atan_mode(True)
+                    f.setup(x, flags=flags)
+                    got = np.stack([to_np(f.basis(p)) for p in range(nb)])
+                o1, o2, o3, oth, ost = ora.g2_orientation(got, mode=ora.ATAN_EXACT if exact else ora.ATAN_CV)
                 c = [to_np(v) for v in f.coefficients()]
                 for a, b in zip(c + [to_np(f.getDominantOrientationStrength())], (o1, o2, o3, ost)):
                     assert np.abs(a - b).max() <= 1e-6 * scale * scale * 30, "orientation planes"
