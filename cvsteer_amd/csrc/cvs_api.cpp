@@ -547,8 +547,11 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     // what the caller pinned is part of the key, in a field of its own (the raw block order can be as large as 1e6)
     const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->g4_split >= 0 ? 1 : 0);
     // the batch size is part of the shape: the order tuned for an 8-frame chunk is not the one a 32-frame batch wants
-    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->kind << 12) | (pins << 16), a.rows, a.cols, xw_pinned,
-                                     h->block_order, a.batch);
+    // ... and so is the kind of state block: on a placement window the 19-row strips win, on a plain block of one run the
+    // 10-row ones (same handle, plain block: fused steer 74.6 -> 79.5 %, basis 77.4 -> 79.2 %) -- what was tuned on one must
+    // not be handed to the other
+    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->sb.vmm ? 1024 : 0) | (h->kind << 12) | (pins << 16), a.rows, a.cols,
+                                     xw_pinned, h->block_order, a.batch);
     {
         std::lock_guard<std::mutex> lock(g_tune_mutex);
         TuneEntry& e = g_tune[key];
