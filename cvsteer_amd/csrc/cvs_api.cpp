@@ -464,7 +464,13 @@ int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input = fals
     // (tools/ab_rot.py, 8 rotating 4096x4096 inputs: 10-row strips 66 %, 19-row strips 57 %)
     // G4 half banks: 40-row strips (k = 4) filter 30 % more rows than they write, 27-row strips 44 %; the kernel is
     // SIMD-bound, so the taller strip wins by 1-3 points (tools/ab_same.py AB_KIND=4 "2=27" "2=40" "2=53", round 2)
-    const long kmax = h->kind == CVS_KIND_G4 ? 4 : (fresh_input || (size_t)rows * cols >= ((size_t)32 << 20)) ? 2 : 3;
+    // ... and so do plain state blocks (the library default; late round 3, tools/ab_same.py on one handle each, two boxes): where
+    // the planes lie in one run of the allocator -- most plain blocks -- the 10-row strips with the tiles dealt 5:4 win every
+    // variant (basis 77 -> 80 %, fused steer 74.6 -> 79.3 %, full setup 70.7 -> 72.9 %, pipeline 67.5 -> 69.6 %); on a placement
+    // window the 19-row strips at 4:3 stay ahead by 1-2 %.  The launch tuner times the other combination on the second call.
+    const bool plain_block = !h->sb.vmm && h->sb.base != nullptr && h->num_frames == 1 &&
+                             (size_t)rows * cols * sizeof(float) * (size_t)(h->nb + 5) >= ((size_t)256 << 20);   // states the Infinity Cache cannot hold
+    const long kmax = h->kind == CVS_KIND_G4 ? 4 : (fresh_input || plain_block || (size_t)rows * cols >= ((size_t)32 << 20)) ? 2 : 3;
     if (k < 2) k = 2;
     if (k > kmax) k = kmax;
     return (int)(k * nt - halo);
@@ -513,8 +519,10 @@ int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool f
 int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input)
 {
     const int xw_pinned = h->xcd_weights;
-    a.xcd_even = xw_pinned ? xw_pinned / 100 : 4;
-    a.xcd_odd = xw_pinned ? xw_pinned % 100 : 3;
+    const bool short_default = h->kind == CVS_KIND_G2 && !h->sb.vmm && h->strip_rows <= 0 && a.batch == 0 &&   // see default_strip_rows
+                               (size_t)a.rows * a.cols * sizeof(float) * (size_t)(h->nb + 5) >= ((size_t)256 << 20);
+    a.xcd_even = xw_pinned ? xw_pinned / 100 : short_default ? 5 : 4;
+    a.xcd_odd = xw_pinned ? xw_pinned % 100 : short_default ? 4 : 3;
     a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
     const bool fast = basis_fast_path(h->kind, h->width, h->taps);
     const bool big = (size_t)a.rows * a.cols >= ((size_t)1 << 20);
@@ -573,17 +581,21 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     }
     struct Cand { int order, xw, strip, split; };
     const int xw0 = a.xcd_even * 100 + a.xcd_odd, sr0 = a.strip_rows, sp0 = a.g4_split, o0 = a.block_order;
-    const int sr_short = 2 * (2 * h->width + 1) - 2 * h->width;
+    const int sr_short = 2 * (2 * h->width + 1) - 2 * h->width, sr_tall = 3 * (2 * h->width + 1) - 2 * h->width;
     // candidate 0 is the default; the others change one thing each (measured alternatives, see above)
     Cand list[6];
     int ncand = 0;
     list[ncand++] = {o0, xw0, sr0, sp0};
     if (h->kind == CVS_KIND_G2) {
+        // the two families that win somewhere: 19-row strips dealt 4:3 (placement windows, plain blocks across a boundary) and
+        // 10-row strips dealt 5:4 (plain blocks inside one run); whichever is not the default is a candidate
+        const int xw_alt = xw0 == 504 ? 403 : 504;
+        const int sr_alt = sr0 == sr_short ? sr_tall : sr_short;
+        const bool strip_alt_ok = free_strip && (size_t)a.rows * a.cols < ((size_t)32 << 20);
         if (free_order) list[ncand++] = {o0 ? 0 : 1, xw0, sr0, sp0};  // the other order
-        if (free_order && !xw_pinned) list[ncand++] = {1, 504, sr0, sp0};
-        // with the weighted order 10-row strips win the 7/9-plane passes, and 5:4 suits them a little better than 4:3
-        if (free_strip && sr_short != sr0) list[ncand++] = {o0, xw0, sr_short, sp0};
-        if (free_strip && sr_short != sr0 && free_order && !xw_pinned) list[ncand++] = {1, 504, sr_short, sp0};
+        if (free_order && !xw_pinned) list[ncand++] = {1, xw_alt, sr0, sp0};
+        if (strip_alt_ok) list[ncand++] = {o0, xw0, sr_alt, sp0};
+        if (strip_alt_ok && free_order && !xw_pinned) list[ncand++] = {1, xw_alt, sr_alt, sp0};
     } else {
         if (free_order) list[ncand++] = {1, xw0, sr0, sp0};
         if (free_split) list[ncand++] = {o0, xw0, sr0, 0};  // one 11-plane kernel instead of the two half banks
