@@ -589,6 +589,7 @@ def main():
         fp = nfr * 1080 * 1920
         extra["C4_32x1080p_pipeline_batch"] = dict(rate(ms, 84, ws * fp), ms_per_frame=round(ms / nfr, 5), launches_per_batch=1,
                                                    frames_per_gpu=nfr, timed_steps=csteps, frame_sets=2, ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR,
+                                                   launch={k: ff.launch_info()[k] for k in ("block_order", "xcd_weights", "strip_rows")},
                                                    placement={"mode": args.placement, "better_block_found": bool(ff.launch_info()["window_found"]),
                                                               "search_ms": round(ff.launch_info()["probe_ms"], 2)})
         ff.set_persist(False)

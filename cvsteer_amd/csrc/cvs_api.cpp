@@ -549,7 +549,10 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     // image, i.e. it would measure the cache-resident case and pick for the wrong regime
     if (fresh_input) return CVS_OK;
     const bool free_order = h->block_order < 0;
-    const bool free_strip = h->strip_rows <= 0 && !fresh_input && a.batch == 0;
+    // (frame batches with state kept have their strip height timed as well since late round 3: 32 x 1080p, one handle, 10-row
+    // strips dealt 5:4 in the weighted order 0.652 against 0.627 for the default; the stateless launch is bound by the SIMDs
+    // and loses 7 % on short strips, so it keeps its default)
+    const bool free_strip = h->strip_rows <= 0 && !fresh_input && (a.batch == 0 || !a.no_state);
     const bool free_split = h->kind == CVS_KIND_G4 && h->g4_split < 0;
     if (!h->autotune || (!free_order && !free_strip && !free_split)) return CVS_OK;
     // what the caller pinned is part of the key, in a field of its own (the raw block order can be as large as 1e6)
@@ -1675,6 +1678,11 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     // state kept: frames from the two halves of the batch in flight together (see k_basis); the stateless launch is bound by
     // the SIMDs and does not care.  CVS_BATCH_WAYS=<n> is a tuning aid (1 = frames in order).
     a.z_ways = (!a.no_state && n >= 4) ? 2 : 1;
+    // ... and on 10-row strips: tools/c4_config_sweep.py, 32 x 1080p, five state blocks of the allocation lottery, one handle
+    // each: against 19 rows in the plain order 0.634 / 0.70 / 0.70 / 0.796 / 0.795 for 0.644 / 0.70 / 0.70 / 0.762 / 0.764 --
+    // level on the slow and middle blocks, +4.5 % on the fast ones; the launch tuner then times the 19-row family and the
+    // weighted order (which wins another 3 % on the slow blocks)
+    if (!a.no_state && n >= 4 && h->strip_rows <= 0) a.strip_rows = 2 * (2 * h->width + 1) - 2 * h->width;
     if (const char* e = std::getenv("CVS_BATCH_WAYS")) a.z_ways = std::max(1, std::min(n, std::atoi(e)));
     a.frame_stride = h->frame_stride;
     if ((rc = tune_block_order(h, a, nullptr, 16 | 1 | 4 | (a.no_state ? 8 : 0)))) return rc;

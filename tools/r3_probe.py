@@ -41,7 +41,7 @@ def c4strips():
     fo8 = torch.empty((nfr, 8, 1080, 1920), device="cuda")
     alt = {"i": 0}
     for persist, out, sel, bpp in ((False, fo3, (5, 6, 7), 16), (True, fo8, None, 84)):
-        cands = [0, 19, 28, 37, 46, 64, 91]
+        cands = [0, 10, 19, 28, 37, 46, 64, 91]
         hs = {}
         for sr in cands:
             f = cv.SteerableFiltersG2(None)
