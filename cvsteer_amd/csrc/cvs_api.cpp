@@ -599,6 +599,9 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
         if (free_order && !xw_pinned) list[ncand++] = {1, xw_alt, sr0, sp0};
         if (strip_alt_ok) list[ncand++] = {o0, xw0, sr_alt, sp0};
         if (strip_alt_ok && free_order && !xw_pinned) list[ncand++] = {1, xw_alt, sr_alt, sp0};
+        // ... and the other strip height in the PLAIN order: on placement windows it wins the 12- and 20-plane launches (full
+        // setup 84.7 -> 87.0 %, pipeline 79.1 -> 85.1 % against the weighted order on 19 rows; profiles/r03_launch_config_sweeps.txt)
+        if (strip_alt_ok && free_order && o0 != 0) list[ncand++] = {0, xw0, sr_alt, sp0};
     } else {
         if (free_order) list[ncand++] = {1, xw0, sr0, sp0};
         if (free_split) list[ncand++] = {o0, xw0, sr0, 0};  // one 11-plane kernel instead of the two half banks
