@@ -41,6 +41,7 @@ struct BasisArgs {
     size_t steer_h_pitch;
     float steer_w[kMaxBasis];  // scalar steering weights (host-computed)
     int strip_rows;       // output rows per wave strip
+    int xcd_steal;        // XCD-column order: tiles every odd XCD leaves (the last of its range) to its even neighbour; 0 = equal shares
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch

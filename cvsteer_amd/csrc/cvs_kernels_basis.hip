@@ -215,9 +215,22 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
         // tiles share an L2 and the line at a tile's left / right edge is not fetched from HBM by two XCDs: on a stream of
         // fresh images the L2 fetch drops from 1.24 x to 1.11 x the image (rocprofv3 FETCH_SIZE) at the same launch time --
         // the default order for fresh images whose column blocks divide evenly among the 8 XCDs.
-        const int cpx = (a.grid_x + 7) >> 3, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        // The odd XCDs need longer per strip (see the weighted order above): with xcd_steal > 0 each of them leaves the last
+        // xcd_steal tiles of its range to its even neighbour, which takes them up when its own range is done.
+        const int cpx = (a.grid_x + 7) >> 3, xcd = blockIdx.x & 7;
+        int k = blockIdx.x >> 3, owner = xcd;
+        if (a.xcd_steal > 0) {
+            const int n_own = cpx * a.grid_y;
+            if (xcd & 1) {
+                if (k >= n_own - a.xcd_steal) return;
+            } else if (k >= n_own) {
+                if (k - n_own >= a.xcd_steal) return;
+                owner = xcd + 1;
+                k = (n_own - a.xcd_steal) + (k - n_own);
+            }
+        }
         by = k / cpx;
-        bx = xcd * cpx + (k - by * cpx);
+        bx = owner * cpx + (k - by * cpx);
         if (bx >= a.grid_x || by >= a.grid_y) return;
     } else if (a.block_order >= 2) {
         const int T = min(a.block_order, a.grid_y);
@@ -719,8 +732,13 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     dim3 grid((strips_x + wpb - 1) / wpb, (a.row_hi - a.row_lo + a.strip_rows - 1) / a.strip_rows);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
+    a.xcd_steal = 0;
     if (a.block_order == kOrderXcdColumns) {
-        grid = dim3(8u * (unsigned)((a.grid_x + 7) / 8) * (unsigned)a.grid_y, 1);
+        const int n_own = ((a.grid_x + 7) / 8) * a.grid_y;
+        // shares e : o for even : odd XCDs (the same pair of numbers as the weighted order's tiles per period); needs the
+        // column blocks to divide evenly (the API layer only picks this order then)
+        if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
+        grid = dim3(8u * (unsigned)(n_own + a.xcd_steal), 1);
     } else if (a.block_order >= 2) {
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1);
