@@ -671,7 +671,7 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     // Second stage: the short bursts above are biased against configurations whose launches feed on what the previous launch
     // of the SAME configuration left in the L2s (the XCD-column order: 8 % slower in interleaved bursts of three, 1.7 % FASTER
     // than the weighted order in a queue of its own launches).  The three best of the first stage -- and the default -- are
-    // timed again in bursts of twenty; a challenger displaces the default only if it wins there by 2 %.
+    // timed again after ten settling launches each, in bursts of twelve; a challenger displaces the default only if it wins there by 2 %.
     {
         int order_by_time[10];
         for (int i = 0; i < ncand; ++i) order_by_time[i] = i;
@@ -688,13 +688,15 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
         if (nfin > 1) {
             // twenty launches per burst: the uneven XCD-column deal needs a queue of about ten of its own launches to show what
             // it does in a loop (bursts of 8: 0.1020 ms, of 24: 0.0963 ms per launch; the equal deal 0.0974 either way)
-            constexpr int kLong = 20;
+            constexpr int kLong = 12, kSettle = 10;
             float t2[6];
             for (float& t : t2) t = std::numeric_limits<float>::max();
             for (int round = 0; round < 3; ++round)
                 for (int fi = 0; fi < nfin; ++fi) {
                     apply(list[fin[fi]]);
-                    HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));   // settles the L2s on this configuration
+                    // ten launches to settle on this configuration (about a millisecond: the uneven XCD-column deal runs its first
+                    // ten launches after a change of configuration at 0.102 ms and the following ones at 0.093), then the timed ones
+                    for (int k = 0; k < kSettle; ++k) HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
                     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
                     for (int k = 0; k < kLong; ++k) HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
                     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
