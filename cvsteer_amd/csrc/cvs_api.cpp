@@ -655,7 +655,7 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
     // an isolated launch by 4 % and lose the queue by 9 %; round 2).
     constexpr int kBurst = 3;
     HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
-    for (int round = 0; round < 4; ++round) {
+    for (int round = 0; round < 3; ++round) {
         for (int ci = 0; ci < ncand; ++ci) {
             apply(list[ci]);
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -691,7 +691,7 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
             constexpr int kLong = 12, kSettle = 10;
             float t2[6];
             for (float& t : t2) t = std::numeric_limits<float>::max();
-            for (int round = 0; round < 3; ++round)
+            for (int round = 0; round < 2; ++round)
                 for (int fi = 0; fi < nfin; ++fi) {
                     apply(list[fin[fi]]);
                     // ten launches to settle on this configuration (about a millisecond: the uneven XCD-column deal runs its first
@@ -703,7 +703,7 @@ int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_
                     HIP_TRY(h, hipEventSynchronize(h->ev1));
                     float ms = 0.f;
                     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-                    if (round > 0) t2[fi] = std::min(t2[fi], ms / kLong);
+                    t2[fi] = std::min(t2[fi], ms / kLong);   // both rounds count: every burst starts settled
                 }
             for (int fi = 0; fi < nfin; ++fi) tmin[fin[fi]] = t2[fi];
             for (int i = 0; i < ncand; ++i) {
