@@ -831,7 +831,13 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
     dim3 grid((strips_x + 3) / 4, (a.row_hi - a.row_lo + a.strip_rows - 1) / a.strip_rows, 2), block(256);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
-    if (a.block_order >= 2) {  // same 1-D band-interleaved walk as launch_fast; z still picks the half bank
+    a.xcd_steal = 0;
+    if (a.block_order == kOrderXcdColumns) {  // as in launch_fast (found by tools/fuzz_campaign.py: this order, pinned by the caller, used to
+                                              // fall into the band-interleaved grid below and leave tiles of a G4 image unwritten)
+        const int n_own = ((a.grid_x + 7) / 8) * a.grid_y;
+        if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
+        grid = dim3(8u * (unsigned)(n_own + a.xcd_steal), 1, 2);
+    } else if (a.block_order >= 2) {  // same 1-D band-interleaved walk as launch_fast; z still picks the half bank
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1, 2);
     } else if (a.block_order == 1) {

@@ -1079,6 +1079,34 @@ def test_xcd_weighted_order_never_changes_results(cv):
         cv.SteerableFiltersG2(None).set_option(L.OPT_XCD_WEIGHTS, 1700)
 
 
+def test_xcd_column_order_with_uneven_shares_and_g4(cv):
+    """block order 1000000 (every XCD on its own range of column blocks) with CVS_OPT_XCD_WEIGHTS e : o -- the odd XCDs leave the
+    end of their range to their even neighbours (BasisArgs::xcd_steal) -- on widths whose 256-column blocks divide among the 8
+    XCDs and on widths where they do not (equal shares then), short and tall images, G2 and G4: identical outputs.  (G4 with
+    this order pinned used to take the band-interleaved grid and leave tiles unwritten: tools/fuzz_campaign.py, seed 43.)"""
+    import torch
+    from cvsteer_amd import _lib as L
+    for shape in ((300, 2048), (61, 4096), (1200, 2048 - 70), (95, 449), (220, 309), (29, 255)):
+        img = torch.rand(shape, device="cuda")
+        for cls, n in ((cv.SteerableFiltersG2, 7), (cv.SteerableFiltersG4, 11)):
+            ref = None
+            for order, xw in ((0, 0), (1000000, 0), (1000000, 101), (1000000, 706), (1000000, 403), (1000000, 1601), (1000000, 116)):
+                f = cls(None)
+                f.set_option(L.OPT_BLOCK_ORDER, order)
+                f.set_option(L.OPT_XCD_WEIGHTS, xw)
+                for sr in (0, 10):
+                    if sr:
+                        f.set_strip_rows(sr)
+                    g, h = f.setup_steer(img, 0.3)
+                    cur = [g.clone(), h.clone()] + [f.basis(p).clone() for p in range(n)]
+                    if cls is cv.SteerableFiltersG2:
+                        cur += [o.clone() for o in f.pipeline(img)]
+                    if ref is None:
+                        ref = cur
+                    for a_, b_ in zip(cur, ref):
+                        assert torch.equal(a_, b_), (shape, cls.__name__, order, xw, sr)
+
+
 def test_planes_beyond_2gib_row_banded(cv):
     """Planes of 2 GiB and more (here 30000 x 40000 f32 = 4.8 GB, far end beyond 4 GiB) run through the same
     kernel in row bands.  Size-independent check: any window of rows, cropped out with enough halo and filtered on

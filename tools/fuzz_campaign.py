@@ -28,6 +28,8 @@ def pick_shape():
     mode = rng.integers(0, 5)
     if rng.integers(0, 25) == 0:      # now and then an image large enough for streaming stores and many strips per wave slot
         return int(rng.integers(1200, 2600)), int(rng.integers(1500, 3300))
+    if rng.integers(0, 12) == 0:      # column counts whose 256-column blocks divide evenly among the 8 XCDs (the XCD-column order with uneven shares)
+        return int(rng.integers(13, 700)), int(2048 * rng.integers(1, 3) - rng.integers(0, 200))
     if mode == 0:
         return int(rng.integers(1, 24)), int(rng.integers(1, 24))
     if mode == 1:
@@ -87,9 +89,9 @@ for it in range(iters):
     if rng.integers(0, 2):
         opts[L.OPT_STRIP_ROWS] = int(rng.choice([1, 5, 10, 19, 28, 37, 64, 131]))
     if rng.integers(0, 2):
-        opts[L.OPT_BLOCK_ORDER] = int(rng.choice([0, 1, 2, 3, 8, 1000]))
+        opts[L.OPT_BLOCK_ORDER] = int(rng.choice([0, 1, 2, 3, 8, 1000, 1000000, 1000000]))   # 1000000 = every XCD on its own column blocks
     if rng.integers(0, 3) == 0:
-        opts[L.OPT_XCD_WEIGHTS] = int(rng.choice([403, 504, 101, 302]))
+        opts[L.OPT_XCD_WEIGHTS] = int(rng.choice([403, 504, 101, 302, 706, 1601, 116]))
     if rng.integers(0, 2):
         opts[L.OPT_STORE_POLICY] = int(rng.choice([0, 1, 2]))
     if kind == 4 and rng.integers(0, 2):
