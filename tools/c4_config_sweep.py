@@ -28,7 +28,7 @@ for hnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     for rnd in range(3):
         for sr, xw in ((19, 403), (10, 403), (10, 504), (19, 504)):
             f.set_strip_rows(sr); f.set_option(L.OPT_XCD_WEIGHTS, xw)
-            for order in (0, 1):
+            for order in (0, 1, 1000000):
                 f.set_option(L.OPT_BLOCK_ORDER, order)
                 res.setdefault((sr, xw, order), []).append(84 * pix / timeit(run) / 1e6 / 8000)
     print("handle", hnd, " ".join("%s:%.3f" % (k, sorted(v)[1]) for k, v in res.items()), flush=True)
