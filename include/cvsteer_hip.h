@@ -81,12 +81,16 @@ enum {
     CVS_OPT_G4_EXTENSIONS = 6, /* 0 (default) = G4 exactly as the reference leaves it (no orientation, no e/mag/phase);
                                   1 = EXTENSION beyond the reference: cvs_setup(G4, CVS_SETUP_FULL) fills C1..C3 / theta /
                                   strength from the G4/H4 steering polynomials, and cvs_steer_* accept e/mag/phase */
-    CVS_OPT_BLOCK_ORDER = 8, /* order in which the basis kernel walks its strips: -1 (default) = the engine's choice (G2: 1,
-                                G4: 0), checked by timing once per (kernel variant, image shape) and cached; 0 = row-major;
-                                1 = row-major with more tiles for the faster XCDs (CVS_OPT_XCD_WEIGHTS); T >= 2 = groups of T row bands walked column by
-                                column (T >= number of bands: column-major).  Results do not depend on it. */
-    CVS_OPT_XCD_WEIGHTS = 10, /* block order 1: 100 * e + o = tiles per period for the even / odd XCDs (1..16 each);
-                                 0 (default) = 4:3, or what the autotuner found (tuning) */
+    CVS_OPT_BLOCK_ORDER = 8, /* order in which the basis kernel walks its strips: -1 (default) = the engine's choice (by kind,
+                                entry point, kind of state block and whether the image is a new one), checked by timing once
+                                per (kernel variant, image shape) and cached; 0 = row-major; 1 = row-major with more tiles for
+                                the faster XCDs (CVS_OPT_XCD_WEIGHTS); 2 <= T < 1000000 = groups of T row bands walked column
+                                by column (T >= number of bands: column-major); 1000000 = every XCD walks its own range of
+                                column blocks (needs the 256-column blocks to divide among the 8 XCDs, else as 0), with
+                                CVS_OPT_XCD_WEIGHTS e : o the odd XCDs leave the end of their range to their even neighbours.
+                                Results do not depend on it. */
+    CVS_OPT_XCD_WEIGHTS = 10, /* block orders 1 and 1000000: 100 * e + o = shares of the even / odd XCDs (1..16 each; 101 =
+                                 equal); 0 (default) = the engine's choice, or what the autotuner found (tuning) */
     CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the second launch of a shape times a few launch configurations and caches the
                                 winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
     CVS_OPT_PLACEMENT_SEARCH = 11, /* where the state planes of a large image (state >= 256 MiB) live.  0 (DEFAULT since round 3):
