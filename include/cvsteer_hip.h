@@ -86,8 +86,8 @@ enum {
                                 per (kernel variant, image shape) and cached; 0 = row-major; 1 = row-major with more tiles for
                                 the faster XCDs (CVS_OPT_XCD_WEIGHTS); 2 <= T < 1000000 = groups of T row bands walked column
                                 by column (T >= number of bands: column-major); 1000000 = every XCD walks its own range of
-                                column blocks (needs the 256-column blocks to divide among the 8 XCDs, else as 0), with
-                                CVS_OPT_XCD_WEIGHTS e : o the odd XCDs leave the end of their range to their even neighbours.
+                                column blocks; with CVS_OPT_XCD_WEIGHTS e : o the odd XCDs leave the end of their range to
+                                their even neighbours (only when the 256-column blocks divide evenly among the 8 XCDs).
                                 Results do not depend on it. */
     CVS_OPT_XCD_WEIGHTS = 10, /* block orders 1 and 1000000: 100 * e + o = shares of the even / odd XCDs (1..16 each; 101 =
                                  equal); 0 (default) = the engine's choice, or what the autotuner found (tuning) */
