@@ -372,7 +372,7 @@ class SteerableFiltersG2(SteerableFilters):
         produce (default all 8); returns / fills out [n, len(outputs), H, W].  select_frame(i) then
         picks whose state the getters and steer() use (unless set_persist(False))."""
         sel = list(range(8)) if outputs is None else [int(k) for k in outputs]
-        block = _is_torch(frames) and frames.dim() == 3 and frames.dtype == torch.float32 and frames.is_cuda
+        block = _is_torch(frames) and frames.dim() == 3 and frames.dtype in (torch.float32, torch.uint8) and frames.is_cuda
         if block and out is None:
             out = torch.empty((frames.shape[0], len(sel)) + tuple(frames.shape[1:]), dtype=torch.float32, device=frames.device)
         if block and _is_torch(out) and out.dim() == 4 and out.is_cuda and out.dtype == torch.float32 \
@@ -383,8 +383,10 @@ class SteerableFiltersG2(SteerableFilters):
             self._like = frames[0]
             self._bind_stream(frames, out)
             imgs = np.zeros(n, _PLANE_DTYPE)
-            imgs["data"] = frames.data_ptr() + np.arange(n, dtype=np.uint64) * np.uint64(frames.stride(0) * 4)
-            imgs["rows"], imgs["cols"], imgs["step"], imgs["mem"] = rows, cols, frames.stride(1) * 4, L.MEM_DEVICE
+            esz = 1 if frames.dtype == torch.uint8 else 4   # 8-bit frames are read as bytes by the kernel (CVS_DEPTH_U8)
+            imgs["data"] = frames.data_ptr() + np.arange(n, dtype=np.uint64) * np.uint64(frames.stride(0) * esz)
+            imgs["rows"], imgs["cols"], imgs["step"] = rows, cols, frames.stride(1) * esz
+            imgs["mem"] = L.MEM_DEVICE | (L.DEPTH_U8 if esz == 1 else 0)
             outs = np.zeros((n, 8), _PLANE_DTYPE)  # data == NULL means "not requested"
             frame_off = np.arange(n, dtype=np.uint64) * np.uint64(out.stride(0) * 4)
             for j, k in enumerate(sel):

@@ -37,7 +37,12 @@ struct cvs_context {
     float taps[kMaxBasis][kMaxTaps];
     // state planes: nb basis, then c1,c2,c3,theta,strength
     int rows = 0, cols = 0;
-    size_t pitch = 0, plane_stride = 0;
+    // geometry of the state: two groups of planes (nb basis planes; c1,c2,c3,theta,strength), each with its own row pitch
+    // and plane stride (elements) -- planar or row-interleaved, see ensure_state
+    size_t pitch = 0, plane_stride = 0;      // basis group
+    size_t opitch = 0, ostride = 0;          // orientation group
+    size_t orient_off = 0;                   // first orientation plane, elements from the frame's first basis plane
+    size_t dense_pitch = 0;                  // round_up(cols, 64): the length of one row of one plane
     float* state = nullptr;      // = sb.base
     size_t state_elems = 0;      // = sb.elems
     StateBlock sb;               // owner of the state memory (cvs_state.cpp)
@@ -53,14 +58,12 @@ struct cvs_context {
     // staging arena for host planes and scratch (bump allocated per call)
     float* arena = nullptr;
     size_t arena_elems = 0, arena_used = 0;
-    float* minmax = nullptr;
-    float* widen = nullptr;       // f32 copy of a block of 8-bit frames (cvs_pipeline_batch)
-    size_t widen_elems = 0;
     float* point_out = nullptr;
     unsigned long long* diag = nullptr;  // diagnostic builds only
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
     // placement = 0: the allocation-time placement search (cvs_state.cpp) is OPT-IN since round 3 -- on the judge's box of
     // round 2 it cost 8 ms on first use and bought nothing, and it reserves address space for the life of the process
+    int layout = 1;   // CVS_OPT_STATE_LAYOUT: 0 = planar, 1 = row-interleaved (default)
     int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 0, autotune = 1;
     // what the last state allocation / the last basis launch of this handle did (cvs_get_launch_info)
     int window_found = 0;
@@ -197,6 +200,8 @@ struct Call {
     const cvs_plane* deferred_image = nullptr;
     uint8_t* deferred_u8 = nullptr;   // device staging of an 8-bit host image
     size_t deferred_u8_pitch = 0;
+    // 8-bit image read by the strip kernel itself (buffer_load_ubyte, widened in registers): no f32 copy of the image is made
+    bool u8_direct = false;
 };
 
 int arena_reserve(cvs_handle h, size_t elems)
@@ -220,12 +225,15 @@ float* arena_take(cvs_handle h, size_t elems)
     return p;
 }
 
+// bytes-as-floats of the device staging of an 8-bit HOST image (rows padded to 256 bytes)
+size_t u8_stage_elems(const cvs_plane* p) { return round_up(round_up((size_t)p->cols, 256) * p->rows / 4 + 64, 64); }
+
 size_t staged_elems(const cvs_plane* p)
 {
     if (!p) return 0;
     const size_t plane = round_up(round_up((size_t)p->cols, 64) * p->rows, 64);
-    if (is_u8(p))  // f32 plane on the device, plus the byte image itself when it comes from the host
-        return plane + (mem_of(p) == CVS_MEM_HOST ? round_up(round_up((size_t)p->cols, 256) * p->rows / 4 + 64, 64) : 0);
+    if (is_u8(p))  // widened copy: f32 plane on the device, plus the byte image itself when it comes from the host
+        return plane + (mem_of(p) == CVS_MEM_HOST ? u8_stage_elems(p) : 0);
     return mem_of(p) == CVS_MEM_HOST ? plane : 0;
 }
 
@@ -233,7 +241,20 @@ size_t staged_elems(const cvs_plane* p)
 int in_ref(Call& c, const cvs_plane* p, PlaneRef& r)
 {
     cvs_handle h = c.h;
-    if (is_u8(p)) {  // 8-bit image: bytes cross PCIe, widening happens on the device
+    if (is_u8(p) && c.u8_direct) {  // the strip kernel reads the bytes itself; r.pitch is then in BYTES (BasisArgs::in_u8)
+        if (mem_of(p) == CVS_MEM_DEVICE) {
+            r = {p->data, p->step};
+            return CVS_OK;
+        }
+        const size_t bpitch = round_up((size_t)p->cols, 256);
+        uint8_t* b = reinterpret_cast<uint8_t*>(arena_take(h, u8_stage_elems(p)));
+        HIP_TRY(h, copy_rows(b, bpitch, p->data, p->step, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, h->stream));
+        c.touched_host = true;
+        r = {reinterpret_cast<float*>(b), bpitch};
+        return CVS_OK;
+    }
+    if (is_u8(p)) {  // 8-bit image on a path the strip kernels do not cover (generic widths, tiny images, pyramid emission):
+                     // bytes cross PCIe, a widening pass makes the f32 plane on the device
         const size_t pitch = round_up((size_t)p->cols, 64);
         float* d = arena_take(h, pitch * p->rows);
         const uint8_t* src = reinterpret_cast<const uint8_t*>(p->data);
@@ -323,8 +344,12 @@ int begin(cvs_handle h, Call& c, std::initializer_list<const cvs_plane*> planes,
 
 float* state_plane(cvs_handle h, int idx)
 {
-    return h->state + (size_t)h->cur_frame * h->frame_stride + (size_t)idx * h->plane_stride;
+    float* frame = h->state + (size_t)h->cur_frame * h->frame_stride;
+    return idx < h->nb ? frame + (size_t)idx * h->plane_stride : frame + h->orient_off + (size_t)(idx - h->nb) * h->ostride;
 }
+
+// a state plane with the row pitch of its group
+PlaneRef state_ref(cvs_handle h, int idx) { return {state_plane(h, idx), idx < h->nb ? h->pitch : h->opitch}; }
 
 // Process-wide cache of released state blocks.  The reference's usage model is one short-lived object per image
 // (example/steer.cpp:86 inside the parallel_for_ body; test/test.cpp:85): a hipMalloc + hipFree of the 0.8 GiB state
@@ -364,7 +389,7 @@ bool pool_take(int device, size_t elems, bool vmm, size_t piece_bytes_min, int n
     return true;
 }
 
-// the caller has synchronised the stream that last used the block
+// blk.ready (if any) marks the end of the work that last used the block
 void pool_give(StateBlock& blk)
 {
     const size_t lim = pool_limit_bytes(), bytes = blk.elems * sizeof(float);
@@ -385,6 +410,38 @@ void pool_give(StateBlock& blk)
     }
     blk = StateBlock();
     for (StateBlock& d : drop) state_block_free(d);
+}
+
+// The handle lets go of its state block WITHOUT draining the device: an event recorded on its stream travels with the
+// parked block, and the next taker's stream waits for it (ensure_state).  The reference's callers build one object per
+// image (example/steer.cpp:86): object k+1's launch is queued while object k's is still running.
+void release_state(cvs_handle h)
+{
+    if (!h->state) return;
+    h->sb.ready = nullptr;
+    if (h->used) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(h->stream, &cap);
+        hipEvent_t ev = nullptr;
+        if (cap == hipStreamCaptureStatusNone && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess &&
+            hipEventRecord(ev, h->stream) == hipSuccess) {
+            h->sb.ready = ev;
+        } else {
+            if (ev) (void)hipEventDestroy(ev);
+            (void)hipGetLastError();
+            if (cap == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(h->stream);
+        }
+    }
+    pool_give(h->sb);
+    h->state = nullptr;
+    h->state_elems = 0;
+}
+
+// row-interleaved state planes (CVS_OPT_STATE_LAYOUT = 1, the default) while a whole group of planes stays below 2 GiB, i.e.
+// within the 32-bit buffer offsets of one launch (larger states -- 8192^2 G4, 16384^2 G2 -- stay planar and are banded)
+bool state_interleaved(cvs_handle h, int rows, size_t dense_pitch)
+{
+    return h->layout == 1 && (size_t)rows * dense_pitch * sizeof(float) * (size_t)std::max(h->nb, 5) <= (size_t)0x7ffffff0;
 }
 
 int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
@@ -411,14 +468,17 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
         else reuse = !h->sb.vmm && stride * nplanes * (size_t)nframes <= h->state_elems;
     }
     if (!reuse) {
-        if (h->state) {
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            state_block_free(h->sb);
-            h->state = nullptr;
-            h->state_elems = 0;
-        }
+        release_state(h);   // parked, not freed: a handle that alternates between two geometries gets its blocks back
         const size_t elems = stride * nplanes * (size_t)nframes;
         const bool from_pool = pool_take(h->device, elems, want_planes, stride * sizeof(float), nplanes, h->sb);
+        if (from_pool && h->sb.ready) {   // the previous owner's work on this block comes first
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(h->stream, &cap);
+            const hipError_t we = cap == hipStreamCaptureStatusNone ? hipStreamWaitEvent(h->stream, h->sb.ready, 0) : hipEventSynchronize(h->sb.ready);
+            (void)hipEventDestroy(h->sb.ready);
+            h->sb.ready = nullptr;
+            if (we != hipSuccess) return fail_hip(h, we, "waiting for a parked state block");
+        }
         if (!from_pool) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(h->stream, &cap);
@@ -438,9 +498,31 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
     if (h->sb.vmm) stride = h->sb.piece_bytes / sizeof(float);  // planes start at piece boundaries
     h->rows = rows;
     h->cols = cols;
-    h->pitch = pitch;
-    h->plane_stride = stride;
-    h->frame_stride = stride * (h->nb + 5);
+    h->dense_pitch = pitch;
+    // Layout of the planes inside the block.  Round 4 (tools/layout_probe.py, profiles/r04_layout_probe.txt): where the rows
+    // of the planes lie relative to each other decides how fast a launch that writes 7..20 planes at once streams.  PLANAR
+    // (plane after plane, rounds 1-3): a wave's stores of one output row go to addresses 64 MiB apart, one stream per plane.
+    // ROW-INTERLEAVED (default): row r of all planes of a group lies side by side -- [row][plane][column] -- so the launch's
+    // write frontier is ONE linear sweep through the block (per group), and every plane is still an ordinary strided view
+    // (step = planes x row length), which is all the per-pixel kernels, cvs_state_plane and the facade ever ask for.  Two
+    // groups, basis and orientation, so that a basis-only setup writes a dense stream too.  On plain blocks, same handles
+    // side by side: basis 0.76 -> 0.80, fused steer 0.70 -> 0.80, full setup 0.65 -> 0.82, pipeline 0.66 -> 0.73 of the HBM
+    // roofline, fresh images +4-5 points.  Per-plane windows (the opt-in placement search) keep the planar form.
+    const bool inter = state_interleaved(h, rows, pitch) && !h->sb.vmm;
+    if (inter) {
+        h->pitch = pitch * h->nb;
+        h->plane_stride = pitch;
+        h->opitch = pitch * 5;
+        h->ostride = pitch;
+        h->orient_off = round_up(pitch * rows * h->nb, 64);
+        h->frame_stride = h->orient_off + round_up(pitch * rows * 5, 64);   // <= stride * (nb + 5): the block holds it
+    } else {
+        h->pitch = h->opitch = pitch;
+        h->plane_stride = h->ostride = stride;
+        h->orient_off = stride * h->nb;
+        h->frame_stride = stride * (h->nb + 5);
+    }
+    h->last.state_layout = inter ? 1 : 0;
     h->num_frames = nframes;
     if (h->cur_frame >= nframes) h->cur_frame = 0;
     return CVS_OK;
@@ -907,13 +989,19 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     if (pipe_outs)
         for (int k = 0; k < 8; ++k)
             if (pipe_outs[k]) max_pitch = std::max(max_pitch, pipe_outs[k]->step / sizeof(float));
+    if (state_interleaved(h, image->rows, pitch)) max_pitch = std::max(max_pitch, pitch * (size_t)std::max(h->nb, 5));
     const bool may_generic = basis_may_need_scratch(h->kind, h->width, h->taps, image->rows, image->cols, max_pitch);
     const size_t scratch = may_generic ? round_up(basis_scratch_elems(h->kind, h->width, image->rows, pitch), 64) : 0;
     Call c;
     const cvs_plane* po[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (pipe_outs)
         for (int k = 0; k < 8; ++k) po[k] = pipe_outs[k];
-    rc = begin(h, c, {image, steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7], pyr}, scratch);
+    // 8-bit images (what the reference's callers hold: test/test.cpp:73,85, example/steer.cpp:73-86) are read by the strip kernel
+    // as bytes: 1 B/pix of input traffic instead of 1 B read + 4 B written by a widening pass + 4 B read
+    c.u8_direct = is_u8(image) && !may_generic && !pyr;
+    const size_t u8_stage = (c.u8_direct && mem_of(image) == CVS_MEM_HOST) ? u8_stage_elems(image) : 0;
+    rc = begin(h, c, {c.u8_direct ? nullptr : image, steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7], pyr},
+               scratch + u8_stage);
     if (rc) return rc;
     // host planes on the fast path of a large enough image: upload, filtering and download overlap band by band
     // (it pays when a sizeable upload can hide behind the downloads: an f32 host image with host outputs -- measured
@@ -938,12 +1026,16 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     if ((rc = in_ref(c, image, in))) return rc;
     a.in = in.p;
     a.in_pitch = in.pitch;
+    a.in_u8 = c.u8_direct ? 1 : 0;
     a.rows = image->rows;
     a.cols = image->cols;
     a.basis = state_plane(h, 0);
     a.pitch = h->pitch;
     a.plane_stride = h->plane_stride;
     a.orient = ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G2) ? state_plane(h, h->nb) : nullptr;
+    a.orient_pitch = h->opitch;
+    a.orient_stride = h->ostride;
+    a.state_bytes = h->frame_stride * sizeof(float);
     a.atan_mode = h->atan_mode;
     // a different input pointer than last time = a stream of fresh images (not resident in the Infinity Cache);
     // the pipeline variants keep the taller strips (tools/shape_sweep.py)
@@ -999,8 +1091,8 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         pa.cols = a.cols;
         pa.atan_mode = h->atan_mode;
         pa.nt_stores = a.nt_stores;
-        for (int p = 0; p < 11; ++p) pa.in[p] = {state_plane(h, p), h->pitch};
-        for (int i = 0; i < 5; ++i) pa.out[i] = {state_plane(h, h->nb + i), h->pitch};
+        for (int p = 0; p < 11; ++p) pa.in[p] = state_ref(h, p);
+        for (int i = 0; i < 5; ++i) pa.out[i] = state_ref(h, h->nb + i);
         HIP_TRY(h, launch_point(OP_G4_ORIENT, pa, h->stream));
     }
     // a pipeline run with CVS_OPT_PERSIST_STATE = 0 wrote its outputs only: no state to address afterwards
@@ -1011,7 +1103,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
 
 void basis_inputs(cvs_handle h, PointArgs& a)
 {
-    for (int p = 0; p < h->nb; ++p) a.in[p] = {state_plane(h, p), h->pitch};
+    for (int p = 0; p < h->nb; ++p) a.in[p] = state_ref(h, p);
 }
 
 int need_state(cvs_handle h, bool orient)
@@ -1117,14 +1209,14 @@ int steer_common(cvs_handle h, bool map, float theta, const cvs_plane* theta_map
     basis_inputs(h, a);
     const int nb = h->nb;
     if (e) {  // C1..C3 follow the basis planes: in[7..9] (G2) / in[11..13] (G4 extension)
-        for (int i = 0; i < 3; ++i) a.in[nb + i] = {state_plane(h, nb + i), h->pitch};
+        for (int i = 0; i < 3; ++i) a.in[nb + i] = state_ref(h, nb + i);
     }
     if (map) {
         PlaneRef th;
         if (theta_map) {
             if ((rc = in_ref(c, theta_map, th))) return rc;
         } else {
-            th = {state_plane(h, nb + 3), h->pitch};
+            th = state_ref(h, nb + 3);
         }
         a.in[h->kind == CVS_KIND_G2 ? 10 : 14] = th;
     } else {
@@ -1198,6 +1290,7 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
     // example/steer.cpp:86, and a hipMalloc + hipFree pair per object costs ~20 us of the ~150 us such an object lives;
     // the 8 bytes of min / max scratch are allocated by the first 8-bit conversion that needs them)
     if (const char* e = std::getenv("CVS_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CVS_STATE_LAYOUT")) h->layout = std::atoi(e) != 0;
     if (const char* e = std::getenv("CVS_PYR_STRIP")) h->pyr_strip = std::atoi(e) != 0;
     if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::max(0, std::min(2, std::atoi(e)));  // opt-in for new handles
     *out = h;
@@ -1208,11 +1301,10 @@ int cvs_destroy(cvs_handle h)
 {
     if (!h) return CVS_E_BADARG;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
-    if (h->state) pool_give(h->sb);  // the stream has drained: the block may be reused
+    release_state(h);   // no drain: the block is parked with an event
+    // staging memory exists only on handles that were given host planes, 8-bit conversions or irregular batches: those wait
+    if (h->arena || h->frame_tab || h->point_out) (void)hipStreamSynchronize(h->stream);
     if (h->arena) (void)hipFree(h->arena);
-    if (h->minmax) (void)hipFree(h->minmax);
-    if (h->widen) (void)hipFree(h->widen);
     if (h->frame_tab) (void)hipFree(h->frame_tab);
     if (h->point_out) (void)hipFree(h->point_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1320,6 +1412,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "host overlap");
             h->host_overlap = value;
             return CVS_OK;
+        case CVS_OPT_STATE_LAYOUT:
+            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "state layout");
+            h->layout = value;
+            return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -1340,6 +1436,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_AUTOTUNE: *value = h->autotune; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;
+        case CVS_OPT_STATE_LAYOUT: *value = h->layout; return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -1430,7 +1527,7 @@ int cvs_state_plane(cvs_handle h, int which, cvs_plane* view)
     view->data = state_plane(h, idx);
     view->rows = h->rows;
     view->cols = h->cols;
-    view->step = h->pitch * sizeof(float);
+    view->step = (idx < h->nb ? h->pitch : h->opitch) * sizeof(float);
     view->mem = CVS_MEM_DEVICE;
     return CVS_OK;
 }
@@ -1477,8 +1574,8 @@ int cvs_steer_point(cvs_handle h, int x, int y, float theta, float out[5])
     a.c2t = (float)std::cos((double)theta * 2.0);  // G2.cpp:132: std::cos(theta * 2.0), double argument
     a.s2t = (float)std::sin((double)theta * 2.0);
     if (!h->point_out) HIP_TRY(h, hipMalloc(&h->point_out, 8 * sizeof(float)));
-    HIP_TRY(h, launch_steer_point(state_plane(h, 0), h->plane_stride, (size_t)y * h->pitch + x, h->have_orient ? 1 : 0, a,
-                                  h->point_out, h->stream));
+    HIP_TRY(h, launch_steer_point(state_plane(h, 0), h->plane_stride, (size_t)y * h->pitch + x, h->have_orient ? state_plane(h, h->nb) : nullptr,
+                                  h->ostride, (size_t)y * h->opitch + x, a, h->point_out, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out, h->point_out, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CVS_OK;
@@ -1610,37 +1707,20 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
             if ((rc = check_no_overlap(h, &images[i], po, 8))) return rc;
         }
     }
-    // 8-bit frames that lie back to back on the device (a driver's upload of a block of byte images): widened by ONE
-    // launch into an f32 block of the handle, which then takes the one-launch path below like any f32 batch
-    std::vector<cvs_plane> widened;
+    // 8-bit frames that lie back to back on the device (a driver's upload of a block of byte images): the one-launch path
+    // below reads the bytes itself (BasisArgs::in_u8), like any regular f32 batch -- no widened copy
+    bool u8_batch = n >= 1 && images[0].mem == (CVS_MEM_DEVICE | CVS_DEPTH_U8);
     {
-        bool u8_block = n >= 1 && images[0].mem == (CVS_MEM_DEVICE | CVS_DEPTH_U8);
         const uint8_t* b0 = reinterpret_cast<const uint8_t*>(images[0].data);
-        for (int i = 0; i < n && u8_block; ++i)
-            u8_block = images[i].mem == images[0].mem && images[i].step == images[0].step &&
+        for (int i = 0; i < n && u8_batch; ++i)
+            u8_batch = images[i].mem == images[0].mem && images[i].step == images[0].step &&
                        reinterpret_cast<const uint8_t*>(images[i].data) == b0 + (size_t)i * rows * images[0].step;
-        if (u8_block && (size_t)n * rows < ((size_t)1 << 31)) {
-            HIP_TRY(h, hipSetDevice(h->device));
-            const size_t wp = round_up((size_t)cols, 64), elems = wp * rows * n;
-            if (elems > h->widen_elems) {
-                if (h->widen) {
-                    HIP_TRY(h, hipStreamSynchronize(h->stream));
-                    HIP_TRY(h, hipFree(h->widen));
-                    h->widen = nullptr;
-                    h->widen_elems = 0;
-                }
-                HIP_TRY(h, hipMalloc(&h->widen, elems * sizeof(float)));
-                h->widen_elems = elems;
-            }
-            HIP_TRY(h, launch_u8_to_f32(b0, images[0].step, rows * n, cols, h->widen, wp, h->stream));
-            widened.resize(n);
-            for (int i = 0; i < n; ++i) widened[i] = cvs_plane{h->widen + (size_t)i * rows * wp, rows, cols, wp * sizeof(float), CVS_MEM_DEVICE};
-            images = widened.data();
+        u8_batch = u8_batch && (size_t)rows * images[0].step <= (size_t)0x7ffffff0;
+        if (u8_batch) {
             all_dev = true;
             for (int i = 0; i < n && all_dev; ++i)
                 for (int k = 0; outs && k < 8 && all_dev; ++k)
                     if (outs[(size_t)i * 8 + k].data) all_dev = outs[(size_t)i * 8 + k].mem == CVS_MEM_DEVICE;
-            max_bytes = std::max(max_bytes, (size_t)rows * wp * sizeof(float));
         }
     }
     const size_t pitch = round_up((size_t)cols, 64);
@@ -1666,7 +1746,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     std::vector<BatchFrame> tab(n);
     for (int i = 0; i < n; ++i) {
         tab[i].in = images[i].data;
-        tab[i].in_pitch = images[i].step / sizeof(float);
+        tab[i].in_pitch = u8_batch ? images[i].step : images[i].step / sizeof(float);   // elements of the image's own type
         for (int k = 0; k < 8; ++k) {
             const cvs_plane* o = outs ? &outs[(size_t)i * 8 + k] : nullptr;
             tab[i].out[k] = (o && o->data) ? PlaneRef{o->data, o->step / sizeof(float)} : PlaneRef{nullptr, 0};
@@ -1679,7 +1759,8 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     ptrdiff_t d_in = 0, d_out = 0;
     bool have_out_stride = false;
     for (int i = 1; i < n && regular; ++i) {
-        const ptrdiff_t di = tab[i].in - tab[0].in;
+        // (8-bit frames: byte addresses, and u8_batch has already established that they lie back to back)
+        const ptrdiff_t di = u8_batch ? (ptrdiff_t)((size_t)i * rows * images[0].step) : tab[i].in - tab[0].in;
         if (i == 1) d_in = di;
         regular = di == d_in * i && d_in >= 0 && tab[i].in_pitch == tab[0].in_pitch;
         for (int k = 0; k < 8 && regular; ++k) {
@@ -1709,6 +1790,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.rows = rows;
     a.cols = cols;
     a.in_pitch = pitch;
+    a.in_u8 = u8_batch ? 1 : 0;
     if (regular) {
         a.batch_regular = 1;
         a.in = tab[0].in;
@@ -1747,7 +1829,10 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.basis = h->state;
     a.pitch = h->pitch;
     a.plane_stride = h->plane_stride;
-    a.orient = h->state + (size_t)h->nb * h->plane_stride;
+    a.orient = h->state + h->orient_off;
+    a.orient_pitch = h->opitch;
+    a.orient_stride = h->ostride;
+    a.state_bytes = h->frame_stride * sizeof(float);
     a.atan_mode = h->atan_mode;
     a.strip_rows = default_strip_rows(h, rows, cols);
     a.nt_stores = use_nt_stores(h, (size_t)rows * cols * n);
@@ -1828,9 +1913,10 @@ static int to_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_st
     const size_t dpitch = round_up((size_t)src->cols, 256);
     const size_t u8_elems = dst_mem == CVS_MEM_HOST ? round_up(dpitch * src->rows / 4 + 64, 64) : 0;
     Call c;
-    if ((rc = begin(h, c, {src}, u8_elems))) return rc;
+    if ((rc = begin(h, c, {src}, u8_elems + (minmax ? 64 : 0)))) return rc;
     PlaneRef in;
     if ((rc = in_ref(c, src, in))) return rc;
+    float* mm = minmax ? arena_take(h, 64) : nullptr;   // min / max scratch from the arena (no allocation of its own, cf. to_u8_batch)
     uint8_t* d = dst;
     size_t dstep = dst_step;
     if (dst_mem == CVS_MEM_HOST) {
@@ -1838,9 +1924,8 @@ static int to_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_st
         dstep = dpitch;
     }
     if (minmax) {
-        if (!h->minmax) HIP_TRY(h, hipMalloc(&h->minmax, 2 * sizeof(float)));
-        HIP_TRY(h, launch_minmax(in.p, in.pitch, src->rows, src->cols, h->minmax, h->stream));
-        HIP_TRY(h, launch_quantize_u8(in.p, in.pitch, src->rows, src->cols, h->minmax, d, dstep, h->stream));
+        HIP_TRY(h, launch_minmax(in.p, in.pitch, src->rows, src->cols, mm, h->stream));
+        HIP_TRY(h, launch_quantize_u8(in.p, in.pitch, src->rows, src->cols, mm, d, dstep, h->stream));
     } else {
         HIP_TRY(h, launch_convert_u8(in.p, in.pitch, src->rows, src->cols, alpha, beta, d, dstep, h->stream));
     }

@@ -994,6 +994,9 @@ int cvs_batch_pyramid_setup(cvs_batch b, const cvs_plane* image, int rows, int c
                 rc = cvs_create(b->kind, b->width, b->spacing, s.device, &h);
                 if (rc != CVS_OK) return fail(b, rc, "cvs_create (level handle)");
                 B_CVS(b, h, cvs_set_stream(h, s.stream));
+                // planar state: the bands of a plane are gathered as ONE contiguous message per plane and rank (below); in the
+                // row-interleaved layout a band of one plane is not contiguous
+                B_CVS(b, h, cvs_set_option(h, CVS_OPT_STATE_LAYOUT, 0));
                 s.level.push_back(h);
                 s.level_img.push_back(DevBuf());
             }
@@ -1067,6 +1070,7 @@ int cvs_batch_pyramid_setup(cvs_batch b, const cvs_plane* image, int rows, int c
                     if (s) B_CVS(b, s->level[l], cvs_state_plane(s->level[l], which, &sv));
                     if (rs) B_CVS(b, rs->level[l], cvs_state_plane(rs->level[l], which, &dv));
                     const size_t pitch = (s ? sv.step : dv.step) / sizeof(float);
+                    if (pitch != ((size_t)lc[l] + 63) / 64 * 64) return fail(b, CVS_E_STATE, "band gather needs planar state planes (CVS_OPT_STATE_LAYOUT = 0)");
                     mv.push_back({r, root, s ? sv.data + (size_t)lo * pitch : nullptr, rs ? dv.data + (size_t)lo * pitch : nullptr,
                                   (size_t)(hi - lo) * pitch});
                 }

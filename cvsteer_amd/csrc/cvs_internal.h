@@ -28,13 +28,19 @@ struct BatchFrame {
 
 // One launch of the fused basis kernel ("K1").  All pitches/strides are in ELEMENTS.
 struct BasisArgs {
-    const float* in;      // image, device
-    size_t in_pitch;
+    const float* in;      // image, device (in_u8: the pointer really is a const uint8_t*)
+    size_t in_pitch;      // elements of the image's own type (floats, or bytes with in_u8)
+    int in_u8;            // 1 = the image is 8-bit: the strip kernels read bytes and widen them in registers (buffer_load_ubyte +
+                          // v_cvt_f32_ubyte0), exactly cv::Mat1f(const Mat&) of test/test.cpp:85 -- no f32 copy of the image exists
     int rows, cols;
     float* basis;         // nb planes, plane p at basis + p*plane_stride
     size_t pitch;         // row pitch of every state plane
     size_t plane_stride;
-    float* orient;        // c1,c2,c3,theta,strength at orient + i*plane_stride, or nullptr
+    float* orient;        // c1,c2,c3,theta,strength at orient + i*orient_stride (row pitch orient_pitch), or nullptr
+    size_t orient_pitch;  // the state is laid out as two groups of planes, basis and orientation, each either planar
+    size_t orient_stride; // (pitch = row length, stride = plane size) or ROW-INTERLEAVED (stride = row length, pitch = planes x row
+                          // length: row r of all planes of the group lies side by side) -- see cvs_api.cpp ensure_state
+    size_t state_bytes;   // bytes of one frame's state block from `basis` on (basis group, then orientation group)
     float* steer_g;       // fused scalar-steer outputs, or nullptr
     size_t steer_g_pitch;
     float* steer_h;
@@ -132,8 +138,8 @@ struct PointArgs {
 
 hipError_t launch_point(PointOp op, const PointArgs& a, hipStream_t s);
 // single-pixel steer (G2.cpp:115-134): uses a.w, a.c2t, a.s2t; writes {g2,h2,e,mag,phase} to out5 (device)
-hipError_t launch_steer_point(const float* state, size_t plane_stride, size_t offset, int have_orient, const PointArgs& a,
-                              float* out5, hipStream_t s);
+hipError_t launch_steer_point(const float* basis, size_t plane_stride, size_t offset, const float* orient, size_t orient_stride,
+                              size_t orient_offset, const PointArgs& a, float* out5, hipStream_t s);   // orient may be nullptr
 
 // per-image min/max + 8-bit quantise (cv::normalize NORM_MINMAX -> CV_8UC1)
 hipError_t launch_minmax(const float* src, size_t pitch, int rows, int cols, float* minmax2, hipStream_t s);
@@ -164,6 +170,9 @@ struct StateBlock {
     std::vector<hipMemGenericAllocationHandle_t> pieces;
     void* va_base = nullptr;   // the reserved virtual range the planes are a window of (freed with the block)
     size_t va_bytes = 0;
+    // a PARKED block (cvs_destroy / a handle that changed geometry): recorded on the stream that last used the block; whoever
+    // takes the block over makes its own stream wait for it -- the device is never drained for a destroy.  nullptr = idle.
+    hipEvent_t ready = nullptr;
 };
 hipError_t state_block_alloc_plain(int device, size_t elems, StateBlock& b);
 hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b);

@@ -157,6 +157,13 @@ __device__ __forceinline__ float bld(rsrc_t r, unsigned lane_off, unsigned row_o
 {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));
 }
+// one 8-bit sample per lane, widened unscaled (0..255) like cv::Mat1f(const Mat&); out-of-range lanes read 0
+template <bool U8>
+__device__ __forceinline__ float bld_in(rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+    if constexpr (U8) return (float)__builtin_amdgcn_raw_buffer_load_b8(r, lane_off, row_off, 0);
+    else return bld(r, lane_off, row_off);
+}
 template <bool STREAM>
 __device__ __forceinline__ void bst(rsrc_t r, unsigned lane_off, unsigned row_off, float v)
 {
@@ -179,9 +186,10 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 // and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones; one- and
 // two-wave workgroups fill the wave slots better (no slot waits for the slowest of four) but lose 3-12 % on the G2 legs and
 // 7 % on fresh images (profiles/r03_wpb_probe.txt): the four strips of a workgroup write 1 KiB of every plane row from one CU.
-template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB>
+template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB, bool U8 = false>
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe)
 {
+    constexpr unsigned EB = U8 ? 1u : 4u;   // bytes per input sample
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
     constexpr int LW = 64 + 2 * W;
 
@@ -269,8 +277,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     const int xh = min(reflect1(lane < W ? x0 - W + lane : x0 + 64 + (lane - W), a.cols), a.cols - 1);
     // per-lane byte offsets; kLaneOff = "this lane does not take part" (hardware range check)
     const unsigned xb = xin ? (unsigned)x * 4u : kLaneOff;
-    const unsigned xmb = (unsigned)xm * 4u;
-    const unsigned xhb = is_halo ? (unsigned)xh * 4u : kLaneOff;
+    const unsigned xmb = (unsigned)xm * EB;      // input column offsets (bytes of the image's own type)
+    const unsigned xhb = is_halo ? (unsigned)xh * EB : kLaneOff;
     // left halo -> [0,W), right -> [64+W, 64+2W); lanes that carry no halo value write into the
     // 4 pad words behind the line, so the staging code has no exec-mask branch
     const int hslot = lane < W ? lane : (is_halo ? 64 + lane : LW + (lane & 3));
@@ -284,7 +292,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     if constexpr (BATCH == 2) {  // regular frames, one output resource per frame: nothing but three 64-bit bases depends on the frame
         basis_p += (size_t)zframe * a.frame_stride;
         orient_p += (size_t)zframe * a.frame_stride;
-        in_p += (size_t)zframe * a.in_frame_stride;
+        in_p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(in_p) + (size_t)zframe * a.in_frame_stride * EB);
         r_out = plane_rsrc(a.out_base + (size_t)zframe * a.out_frame_stride, a.out_bytes);
     } else if constexpr (BATCH == 1) {
         basis_p += (size_t)zframe * a.frame_stride;
@@ -299,7 +307,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 pipe_out[k].pitch = uniform64(fr->out[k].pitch);
             }
         } else {  // regularly strided frames (one [n, H, W] block in, one [n, K, H, W] block out): scalar arithmetic only
-            in_p += (size_t)zframe * a.in_frame_stride;
+            in_p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(in_p) + (size_t)zframe * a.in_frame_stride * EB);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 pipe_out[k].p = a.pipe_out[k].p ? a.pipe_out[k].p + (size_t)zframe * a.out_frame_stride : nullptr;
@@ -313,15 +321,19 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // buffer resources (wave-uniform): input plane, state planes
     const size_t plane_bytes = (size_t)(a.rows - rbase) * a.pitch * sizeof(float);
     const unsigned pitch_b = (unsigned)(a.pitch * sizeof(float));
-    const rsrc_t r_in = plane_rsrc(in_p, (size_t)(a.rows - rbase) * in_pitch * sizeof(float));
+    const rsrc_t r_in = plane_rsrc(in_p, (size_t)(a.rows - rbase) * in_pitch * EB);
     // ONE: the frame's whole state block (basis + orientation planes, one allocation) is a single
     // resource and the plane is part of the scalar offset -- 4 SGPRs instead of 4 per plane, which is
     // what keeps the 20-plane pipeline variant from spilling SGPRs.  Needs the block to be < 2 GiB;
     // larger images use one resource per plane.
-    constexpr int NBTOT = B::KIND == 2 ? 7 : 11;
-    const rsrc_t r_state = plane_rsrc(basis_p, ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float));
+    const rsrc_t r_state = plane_rsrc(basis_p, a.state_bytes);
     const unsigned pstride_b = (unsigned)(a.plane_stride * sizeof(float));
-    const unsigned in_pitch_b = (unsigned)(in_pitch * sizeof(float));
+    // the orientation planes are a group of their own (own row pitch, own plane stride: ensure_state in cvs_api.cpp)
+    [[maybe_unused]] const unsigned opitch_b = (unsigned)(a.orient_pitch * sizeof(float));
+    [[maybe_unused]] const unsigned ostride_b = (unsigned)(a.orient_stride * sizeof(float));
+    [[maybe_unused]] const unsigned ooff_b = (unsigned)((size_t)(orient_p - basis_p) * sizeof(float));   // single-resource form only (block < 2 GiB)
+    [[maybe_unused]] const size_t oplane_bytes = (size_t)(a.rows - rbase) * a.orient_pitch * sizeof(float);
+    const unsigned in_pitch_b = (unsigned)(in_pitch * EB);
 
     float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
     float pre[NT], preh[NT];  // prefetched input rows (main lane value, halo-lane value)
@@ -360,6 +372,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     [[maybe_unused]] const unsigned ro_mir = (unsigned)(2 * a.rows - 2 - 2 * rbase) * in_pitch_b;
     [[maybe_unused]] unsigned oi_run = 0u - (unsigned)(2 * W);                   // output row relative to y0 (wraps below 0)
     [[maybe_unused]] unsigned orow_run = ((unsigned)(y0 - rbase) - (unsigned)(2 * W)) * pitch_b;  // its byte offset in a state plane
+    [[maybe_unused]] unsigned orow_o_run = ((unsigned)(y0 - rbase) - (unsigned)(2 * W)) * opitch_b;  // ... and in an orientation plane
     const unsigned nout = (unsigned)(yend - y0);
     [[maybe_unused]] unsigned xbp[NB];
     if constexpr (ONE && VOFF) {
@@ -370,8 +383,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const unsigned ro = (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b;
-        pre[j] = bld(r_in, xmb, ro);
-        preh[j] = bld(r_in, xhb, ro);
+        pre[j] = bld_in<U8>(r_in, xmb, ro);
+        preh[j] = bld_in<U8>(r_in, xhb, ro);
     }
 
     for (int g = 0; g < ngroups; ++g) {
@@ -393,8 +406,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 } else {
                     ro = (unsigned)(reflect1(y0 - W + (g + 1) * NT + j, a.rows) - rbase) * in_pitch_b;
                 }
-                pre[j] = bld(r_in, nxmb, ro);
-                preh[j] = bld(r_in, nxhb, ro);
+                pre[j] = bld_in<U8>(r_in, nxmb, ro);
+                preh[j] = bld_in<U8>(r_in, nxhb, ro);
             }
             // ---- row pass: stage the line, read the 2W+1 neighbours ----
             line[W + lane] = v;
@@ -444,6 +457,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----
             // which output row this is, and whether the strip owns it (wave-uniform)
             unsigned oi = 0, orow_s = 0;
+            [[maybe_unused]] unsigned orow_o_s = 0;
             bool row_ok;
             [[maybe_unused]] int yout = 0;
             if constexpr (SRED) {
@@ -451,6 +465,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 orow_s = orow_run;
                 ++oi_run;
                 orow_run += pitch_b;
+                if constexpr ((FLAGS & F_ORIENT) != 0 && (FLAGS & F_NOSTATE) == 0) {
+                    orow_o_s = orow_o_run;
+                    orow_o_run += opitch_b;
+                }
                 row_ok = oi < nout;  // y0 <= y0 + oi < yend
             } else {
                 yout = y0 + g * NT + j - 2 * W;
@@ -486,12 +504,15 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
                 // output row relative to the plane pointers, and its byte offset in a state plane
                 unsigned yo, orow;
+                [[maybe_unused]] unsigned orow_o = 0;
                 if constexpr (SRED) {
                     yo = (unsigned)(y0 - rbase) + oi;
                     orow = orow_s;
+                    orow_o = orow_o_s;
                 } else {
                     yo = row_ok ? (unsigned)(yout - rbase) : 0u;
                     orow = yo * pitch_b;
+                    if constexpr ((FLAGS & F_ORIENT) != 0 && (FLAGS & F_NOSTATE) == 0) orow_o = yo * opitch_b;
                 }
                 if constexpr ((FLAGS & F_NOSTATE) == 0) {
 #pragma unroll
@@ -512,8 +533,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         const float ov[5] = {c1, c2, c3, th, st};
 #pragma unroll
                         for (int k = 0; k < 5; ++k)
-                            if constexpr (ONE) bst<STREAM>(r_state, xbr, orow + (unsigned)(NBTOT + k) * pstride_b, ov[k]);
-                            else bst<STREAM>(plane_rsrc(orient_p + (size_t)k * a.plane_stride, plane_bytes), xbr, orow, ov[k]);
+                            if constexpr (ONE) bst<STREAM>(r_state, xbr, orow_o + ooff_b + (unsigned)k * ostride_b, ov[k]);
+                            else bst<STREAM>(plane_rsrc(orient_p + (size_t)k * a.orient_stride, oplane_bytes), xbr, orow_o, ov[k]);
                     }
                     if constexpr ((FLAGS & F_PIPE) != 0) {
                         // the callers' sequence (test/test.cpp:86-90) on values still in registers:
@@ -586,7 +607,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #endif
 }
 
-template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int WPB = 4>
+template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int WPB = 4, bool U8 = false>
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
     __shared__ float lds[WPB][64 + 2 * B::W + 4];
@@ -604,18 +625,18 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
             if (z >= (unsigned)a.batch) return;
         }
     }
-    basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB>(a, t, lds[threadIdx.x >> 6], z);
+    basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB, U8>(a, t, lds[threadIdx.x >> 6], z);
 }
 
 // G + H half banks in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
 // one launch start-up / tail and read the same image rows at about the same time (L2 hits), while each
 // keeps its half-size register window.
-template <class BG, class BH, int FLAGS, bool STREAM, bool ONE>
+template <class BG, class BH, int FLAGS, bool STREAM, bool ONE, bool U8 = false>
 __global__ __launch_bounds__(256) void k_basis_pair(const BasisArgs a, const Folded<BG> tg, const Folded<BH> th)
 {
     __shared__ float lds[4][64 + 2 * BG::W + 4];
-    if (blockIdx.z == 0) basis_body<BG, FLAGS, STREAM, false, ONE, 4>(a, tg, lds[threadIdx.x >> 6], 0);
-    else basis_body<BH, FLAGS, STREAM, false, ONE, 4>(a, th, lds[threadIdx.x >> 6], 0);
+    if (blockIdx.z == 0) basis_body<BG, FLAGS, STREAM, false, ONE, 4, U8>(a, tg, lds[threadIdx.x >> 6], 0);
+    else basis_body<BH, FLAGS, STREAM, false, ONE, 4, U8>(a, th, lds[threadIdx.x >> 6], 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -748,21 +769,25 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     dim3 block(64 * wpb);
     const bool orient = orient_v;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
-    constexpr int NBTOT = B::KIND == 2 ? 7 : 11;
     // the single-resource form addresses the whole image from row 0: a banded launch (a caller plane of 2 GiB or
     // more beside a small state block, e.g. a narrow column view of a huge image) must use the per-plane form,
     // which honours row_lo / row_hi / row_base
     const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;
-    const bool one = !banded && ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float) <= kMaxPlaneBytes;
-#define CVS_LAUNCH_W(FL, BATCHED, WP)                                                                              \
+    const bool one = !banded && a.state_bytes > 0 && a.state_bytes <= kMaxPlaneBytes;
+#define CVS_LAUNCH_U(FL, BATCHED, WP, U)                                                                           \
     do {                                                                                                           \
         if (one) {                                                                                                 \
-            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, true, WP>), grid, block, 0, s, a, f);   \
-            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, true, WP>), grid, block, 0, s, a, f);              \
+            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, true, WP, U>), grid, block, 0, s, a, f);   \
+            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, true, WP, U>), grid, block, 0, s, a, f);              \
         } else {                                                                                                   \
-            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, false, WP>), grid, block, 0, s, a, f);  \
-            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, false, WP>), grid, block, 0, s, a, f);             \
+            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, false, WP, U>), grid, block, 0, s, a, f);  \
+            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, false, WP, U>), grid, block, 0, s, a, f);             \
         }                                                                                                          \
+    } while (0)
+#define CVS_LAUNCH_W(FL, BATCHED, WP)                       \
+    do {                                                    \
+        if (a.in_u8) CVS_LAUNCH_U(FL, BATCHED, WP, true);   \
+        else CVS_LAUNCH_U(FL, BATCHED, WP, false);          \
     } while (0)
 #define CVS_LAUNCH_B(FL, BATCHED) CVS_LAUNCH_W(FL, BATCHED, 4)
 #define CVS_LAUNCH(FL) CVS_LAUNCH_B(FL, 0)
@@ -819,6 +844,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     }
 #undef CVS_LAUNCH_B
 #undef CVS_LAUNCH_W
+#undef CVS_LAUNCH_U
 #undef CVS_LAUNCH
     return hipGetLastError();
 }
@@ -844,10 +870,13 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
         grid = dim3(weighted_grid(a), 1, 2);
     }
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
-    constexpr int NBTOT = BG::KIND == 2 ? 7 : 11;
     const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;  // see launch_fast
-    const bool one = !banded && ((size_t)(NBTOT + 4) * a.plane_stride + (size_t)a.rows * a.pitch) * sizeof(float) <= kMaxPlaneBytes;
-#define CVS_PAIR(FL, ST, ON) hipLaunchKernelGGL((k_basis_pair<BG, BH, FL, ST, ON>), grid, block, 0, s, a, fg, fh)
+    const bool one = !banded && a.state_bytes > 0 && a.state_bytes <= kMaxPlaneBytes;
+#define CVS_PAIR(FL, ST, ON)                                                                                             \
+    do {                                                                                                                 \
+        if (a.in_u8) hipLaunchKernelGGL((k_basis_pair<BG, BH, FL, ST, ON, true>), grid, block, 0, s, a, fg, fh);         \
+        else hipLaunchKernelGGL((k_basis_pair<BG, BH, FL, ST, ON, false>), grid, block, 0, s, a, fg, fh);                \
+    } while (0)
     if (steer) {
         if (a.nt_stores) { if (one) CVS_PAIR(F_STEER, true, true); else CVS_PAIR(F_STEER, true, false); }
         else { if (one) CVS_PAIR(F_STEER, false, true); else CVS_PAIR(F_STEER, false, false); }
@@ -864,18 +893,19 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
 {
     const int nb = host_num_basis(kind);
     dim3 block(256), grid((a.cols + 255) / 256, a.rows);
+    const size_t spitch = ((size_t)a.cols + 63) / 64 * 64;   // the scratch plane is dense whatever the layout of the state planes
     for (int p = 0; p < nb; ++p) {
         int ix, iy;
         host_basis_taps(kind, p, &ix, &iy);
         TapVec kx, ky;
         for (int i = 0; i < 2 * width + 1; ++i) { kx.k[i] = taps[ix][i]; ky.k[i] = taps[iy][i]; }
-        hipLaunchKernelGGL(k_rowpass_generic, grid, block, 0, s, a.in, a.in_pitch, a.rows, a.cols, scratch, a.pitch, kx, width);
+        hipLaunchKernelGGL(k_rowpass_generic, grid, block, 0, s, a.in, a.in_pitch, a.rows, a.cols, scratch, spitch, kx, width);
         int sym = 1, asym = ky.k[width] == 0.0f ? 1 : 0;
         for (int i = 1; i <= width; ++i) {
             if (ky.k[width + i] != ky.k[width - i]) sym = 0;
             if (ky.k[width + i] != -ky.k[width - i]) asym = 0;
         }
-        hipLaunchKernelGGL(k_colpass_generic, grid, block, 0, s, (const float*)scratch, a.pitch, a.rows, a.cols,
+        hipLaunchKernelGGL(k_colpass_generic, grid, block, 0, s, (const float*)scratch, spitch, a.rows, a.cols,
                            a.basis + (size_t)p * a.plane_stride, a.pitch, ky, width, sym ? 1 : asym ? -1 : 0);
     }
     hipError_t e = hipGetLastError();
@@ -885,7 +915,7 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
         PointArgs pa{};
         pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
         for (int p = 0; p < 7; ++p) pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch};
-        for (int i = 0; i < 5; ++i) pa.out[i] = {a.orient + (size_t)i * a.plane_stride, a.pitch};
+        for (int i = 0; i < 5; ++i) pa.out[i] = {a.orient + (size_t)i * a.orient_stride, a.orient_pitch};
         e = launch_point(OP_G2_ORIENT, pa, s);
         if (e != hipSuccess) return e;
     }
@@ -894,8 +924,8 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
         pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
         pa.find_on_e = a.find_on_e;
         for (int p = 0; p < 7; ++p) pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch};
-        for (int i = 0; i < 3; ++i) pa.in[7 + i] = {a.orient + (size_t)i * a.plane_stride, a.pitch};
-        pa.in[10] = {a.orient + (size_t)3 * a.plane_stride, a.pitch};
+        for (int i = 0; i < 3; ++i) pa.in[7 + i] = {a.orient + (size_t)i * a.orient_stride, a.orient_pitch};
+        pa.in[10] = {a.orient + (size_t)3 * a.orient_stride, a.orient_pitch};
         for (int k = 0; k < 8; ++k) pa.out[k] = a.pipe_out[k];
         e = launch_point(OP_G2_PIPELINE, pa, s);
         if (e != hipSuccess) return e;
@@ -915,6 +945,7 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
 static size_t max_pitch_bytes(const BasisArgs& a)
 {
     size_t mx = a.in_pitch > a.pitch ? a.in_pitch : a.pitch;
+    if (a.orient) mx = max(mx, a.orient_pitch);
     if (a.steer_g) { mx = max(mx, a.steer_g_pitch); mx = max(mx, a.steer_h_pitch); }
     for (int k = 0; k < 8; ++k)
         if (a.pipe && a.pipe_out[k].p) mx = max(mx, a.pipe_out[k].pitch);
@@ -999,9 +1030,9 @@ static hipError_t for_each_band(const BasisArgs& a_in, int width, F&& fn)
         a.row_base = lo > width ? lo - width : 0;
         if (per >= a.rows) a.row_base = 0;
         const size_t rb = (size_t)a.row_base;
-        a.in += rb * a.in_pitch;
+        a.in = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + rb * a.in_pitch * (a.in_u8 ? 1 : sizeof(float)));
         a.basis += rb * a.pitch;
-        if (a.orient) a.orient += rb * a.pitch;
+        if (a.orient) a.orient += rb * a.orient_pitch;
         if (a.steer_g) a.steer_g += rb * a.steer_g_pitch;
         if (a.steer_h) a.steer_h += rb * a.steer_h_pitch;
         for (int k = 0; k < 8; ++k)
@@ -1029,6 +1060,9 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
         const hipError_t e = launch_basis(kind, width, taps, b, scratch, s);
         return e != hipSuccess ? e : launch_pyr_down(a.in, a.in_pitch, a.rows, a.cols, a.pyr_out, a.pyr_pitch, s);
     }
+    // 8-bit images are read by the strip kernels only; the API layer widens the image first wherever this function may take
+    // another path (basis_may_need_scratch), so these are defensive
+    if (a.in_u8 && (a.pyr_out || !fast_geometry_ok(a, width) || band_rows(a, width) == 0 || !basis_fast_path(kind, width, taps))) return hipErrorInvalidValue;
     if (!fast_geometry_ok(a, width) || band_rows(a, width) == 0) return launch_generic(kind, width, taps, a, scratch, s);
     if (kind == 2 && width == BankG2::W) {
         Folded<BankG2> f;

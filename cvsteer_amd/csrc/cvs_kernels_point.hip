@@ -296,12 +296,14 @@ __global__ __launch_bounds__(256) void k_quantize_u8(const float* src, size_t pi
 // One lane gathers the 7 (+3) state values at (y, x) and evaluates the reference's scalar
 // expression: float sums left to right, libm-style atan2 (no wrap, no NaN patch) and sqrt.
 // ---------------------------------------------------------------------------------------
-__global__ void k_steer_point(const float* state, size_t plane_stride, size_t offset, int have_orient,
-                              PointArgs a, float* out5)
+__global__ void k_steer_point(const float* basis, size_t plane_stride, size_t offset, const float* orient, size_t orient_stride,
+                              size_t orient_offset, PointArgs a, float* out5)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool have_orient = orient != nullptr;
     float v[10];
-    for (int i = 0; i < 10; ++i) v[i] = (i < 7 || have_orient) ? state[(size_t)i * plane_stride + offset] : 0.f;
+    for (int i = 0; i < 7; ++i) v[i] = basis[(size_t)i * plane_stride + offset];
+    for (int i = 0; i < 3; ++i) v[7 + i] = have_orient ? orient[(size_t)i * orient_stride + orient_offset] : 0.f;
     const float g2 = __fadd_rn(__fadd_rn(__fmul_rn(a.w[0], v[0]), __fmul_rn(a.w[1], v[1])), __fmul_rn(a.w[2], v[2]));
     float h2 = __fadd_rn(__fmul_rn(a.w[3], v[3]), __fmul_rn(a.w[4], v[4]));
     h2 = __fadd_rn(h2, __fmul_rn(a.w[5], v[5]));
@@ -313,10 +315,10 @@ __global__ void k_steer_point(const float* state, size_t plane_stride, size_t of
     out5[4] = atan2f(h2, g2);
 }
 
-hipError_t launch_steer_point(const float* state, size_t plane_stride, size_t offset, int have_orient, const PointArgs& a,
-                              float* out5, hipStream_t s)
+hipError_t launch_steer_point(const float* basis, size_t plane_stride, size_t offset, const float* orient, size_t orient_stride,
+                              size_t orient_offset, const PointArgs& a, float* out5, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_steer_point, dim3(1), dim3(64), 0, s, state, plane_stride, offset, have_orient, a, out5);
+    hipLaunchKernelGGL(k_steer_point, dim3(1), dim3(64), 0, s, basis, plane_stride, offset, orient, orient_stride, orient_offset, a, out5);
     return hipGetLastError();
 }
 

@@ -98,6 +98,11 @@ int state_probes_run() { return g_probes_run.load(); }
 void state_block_free(StateBlock& b)
 {
     if (!b.base) return;
+    if (b.ready) {   // work of the handle that parked the block may still be running
+        (void)hipEventSynchronize(b.ready);
+        (void)hipEventDestroy(b.ready);
+        b.ready = nullptr;
+    }
     if (b.vmm) {
         for (size_t p = 0; p < b.pieces.size(); ++p) {
             (void)hipMemUnmap(reinterpret_cast<char*>(b.base) + p * b.piece_bytes, b.piece_bytes);

@@ -115,6 +115,14 @@ enum {
     CVS_OPT_HOST_OVERLAP = 13, /* cvs_setup / cvs_setup_steer / cvs_pipeline with HOST planes on images of 1 Mpix and more:
                                   1 (default) = the image goes up, is filtered and comes down in row bands, all three at once
                                   (full-duplex host link, a second host thread for the downloads); 0 = one after the other */
+    CVS_OPT_STATE_LAYOUT = 14, /* how the handle's state planes lie in its block.  1 (default) = ROW-INTERLEAVED: row r of all basis
+                                  planes side by side ([row][plane][column]; the five orientation planes likewise, in a group of
+                                  their own) -- a launch that writes 7..12 planes then streams ONE linear sweep per group instead of
+                                  one stream per plane 64 MiB apart, and runs 5-25 % faster on a plain block; every
+                                  plane is still an ordinary strided image (cvs_state_plane: step = planes x row length).  0 =
+                                  planar, plane after plane (rounds 1-3; also what per-plane placement windows and groups of
+                                  2 GiB and more use).  Takes effect at the next cvs_setup*; results do not depend on it.  Also
+                                  CVS_STATE_LAYOUT in the environment (new handles). */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
                                 launch (blockIdx.z picks the half); -1 (default) = 2, or 0 where the autotuner finds it faster */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
@@ -187,6 +195,9 @@ typedef struct cvs_launch_info {
     int32_t strip_rows;       /* ... output rows per wave strip */
     int32_t nt_stores;        /* ... 1 = streaming (nontemporal) stores */
     int32_t g4_split;         /* ... CVS_OPT_G4_SPLIT value in effect */
+    int32_t state_layout;     /* layout of the current state block: 0 = planar, 1 = row-interleaved (CVS_OPT_STATE_LAYOUT) */
+    int32_t tuning_launches;  /* launches the engine has issued on this handle's stream beyond the caller's own calls
+                                 (always 0 since round 4: configurations are compared on the caller's launches) */
 } cvs_launch_info;
 int cvs_get_launch_info(cvs_handle h, cvs_launch_info* out);
 /* the handle's idx-th tap vector (m_g1.. members), 2*width+1 floats */

@@ -923,6 +923,59 @@ def test_8bit_input_images(cv, ora, fish, golden_dir):
         f.computeMagnitudeAndPhase(u8, u8)
 
 
+@pytest.mark.parametrize("shape", [(185, 256), (1080, 1920), (131, 1021), (64, 67)])
+def test_8bit_images_read_in_kernel_equal_widened(cv, shape):
+    """8-bit images are read by the strip kernels themselves (buffer_load_ubyte + cvt, BasisArgs::in_u8; test/test.cpp:73,85 hands
+    an 8-bit Mat to the constructor): every entry point gives bit-identical results to the same image widened to f32 first --
+    dense planes, odd widths, ROI views (step > cols, odd byte offsets), device and host, G2 and G4, single image and batch"""
+    import torch
+    rows, cols = shape
+    gen = torch.Generator(device="cuda").manual_seed(rows * 31 + cols)
+    big = (torch.rand((rows + 6, cols + 13), device="cuda", generator=gen) * 256).to(torch.uint8)
+    views = [big[:rows, :cols].contiguous(), big[3:3 + rows, 5:5 + cols], big[1:1 + rows, :cols]]
+    for u8 in views:
+        f32 = u8.to(torch.float32).contiguous()
+        a, b = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
+        a.setup(u8, flags=cv.SETUP_FULL)
+        b.setup(f32, flags=cv.SETUP_FULL)
+        for p in range(7):
+            assert torch.equal(a._state(p), b._state(p)), ("basis", p)
+        assert torch.equal(a.getDominantOrientationAngle(), b.getDominantOrientationAngle())
+        ga, ha = a.setup_steer(u8, 0.3)
+        gb, hb = b.setup_steer(f32, 0.3)
+        assert torch.equal(ga, gb) and torch.equal(ha, hb)
+        for x, y in zip(a.pipeline(u8), b.pipeline(f32)):
+            assert torch.equal(x, y)
+        a4, b4 = cv.SteerableFiltersG4(None), cv.SteerableFiltersG4(None)
+        g4a, h4a = a4.setup_steer(u8, -0.7)
+        g4b, h4b = b4.setup_steer(f32, -0.7)
+        assert torch.equal(g4a, g4b) and torch.equal(h4a, h4b)
+        for p in range(11):
+            assert torch.equal(a4._state(p), b4._state(p)), ("g4 basis", p)
+    # host bytes (pageable numpy, padded rows): the bytes are uploaded and read as bytes
+    hu8 = views[1].cpu().numpy()
+    assert hu8.strides[0] > cols
+    hw = cv.SteerableFiltersG2(None).pipeline(hu8)
+    hr = cv.SteerableFiltersG2(None).pipeline(np.ascontiguousarray(hu8).astype(np.float32))
+    for x, y in zip(hw, hr):
+        assert np.array_equal(x, y)
+    # a block of frames: one launch over grid.z reading bytes; state kept and outputs only
+    n = 5
+    blk = (torch.rand((n, rows, cols), device="cuda", generator=gen) * 256).to(torch.uint8)
+    for persist in (True, False):
+        e8, e32 = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
+        e8.set_persist(persist)
+        e32.set_persist(persist)
+        assert torch.equal(e8.pipeline_batch(blk), e32.pipeline_batch(blk.to(torch.float32)))
+        assert torch.equal(e8.pipeline_batch(blk, outputs=(5, 6, 7)), e32.pipeline_batch(blk.to(torch.float32), outputs=(5, 6, 7)))
+    if True:
+        e8.set_persist(True)
+        e8.pipeline_batch(blk)
+        e8.select_frame(3)
+        single = cv.SteerableFiltersG2(blk[3].to(torch.float32))
+        assert torch.equal(e8._state(2), single._state(2))
+
+
 def test_random_shapes_fuzz(cv, ora):
     """seeded shape fuzz across the fast / generic path boundaries (rows around 3W+1, cols around W+1 and
     around multiples of 64, strip boundaries): basis planes and the fused pipeline vs the oracle"""
