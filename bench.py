@@ -33,14 +33,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ROWS = COLS = 4096
 THETA = 0.3
-BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56}
-# calls on a new handle before a timed region: the engine times a few launch orders on the SECOND repeat of a shape
-# (bounded: ~50 launches, cached process-wide).  The allocation-time placement search is OPT-IN in
-# the library since round 3; bench.py switches it ON for the headline handle (--placement 1, the default here) and
-# records what it found and cost in `config.placement`; `extra.M2_plain_block` is the same loop on the library's default
-# (a plain hipMalloc block), so that one line shows what a window is worth on the box it ran on.  `M2_untuned` /
-# `M2_first_call` = the library's defaults without the tuner.
-INIT_CALLS = 4
+BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56, "M2_u8": 37, "C4_u8_feat3": 13}
+# Everything here runs on the library's DEFAULTS (round 4): plain hipMalloc state block, row-interleaved state planes, the
+# online launch tuner.  The tuner compares a handful of launch configurations on the caller's own calls (no extra launches):
+# a new (handle kind, entry point, shape) needs about 40 calls to settle, which every leg makes before its timed region
+# (SETTLE_CALLS).  The allocation-time placement search stays an opt-in knob of the library; `extra.M2_placement_window`
+# shows what it is worth on the box the run landed on.  `M2_untuned` = CVS_OPT_AUTOTUNE 0.
+SETTLE_CALLS = 44
+INIT_CALLS = SETTLE_CALLS
 EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
 EXIT_LEGS_FAILED = 5  # a secondary leg raised: headline + the legs finished so far are printed first
 EXIT_TERMINATED = 4   # SIGTERM (another rank failed / the launcher gave up): whatever was measured is printed first
@@ -128,9 +128,55 @@ def _median(v):
     return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _opencv_baseline(theta, threads_all):
+    """BASELINE.md 3.3a / SURVEY 8(d): when OpenCV exists on the box, the literal reference sequence -- 7 x cv::sepFilter2D
+    (SteerableFiltersG2.cpp:62-68) + the scalar steer (G2.cpp:137-145) -- on the same synthetic image, one thread and all."""
+    try:
+        import cv2
+    except Exception:
+        return "absent"
+    import numpy as np
+    import cvsteer_amd as cv
+    taps = [cv.make_taps(cv.KIND_G2, i, 4, 0.67) for i in range(7)]
+    pairs = [cv.basis_taps(cv.KIND_G2, p) for p in range(7)]
+    w = cv.steer_weights(cv.KIND_G2, theta)
+    img = np.random.default_rng(1234).random((ROWS, COLS), dtype=np.float32)
+
+    def once():
+        b = [cv2.sepFilter2D(img, cv2.CV_32F, taps[kx].reshape(1, -1), taps[ky].reshape(-1, 1)) for kx, ky in pairs]
+        g = w[0] * b[0] + w[1] * b[1] + w[2] * b[2]
+        hq = w[3] * b[3] + w[4] * b[4] + w[5] * b[5] + w[6] * b[6]
+        return g, hq
+
+    out = {"version": cv2.__version__}
+    for label, nthr in (("1_thread", 1), ("all_threads", threads_all)):
+        cv2.setNumThreads(nthr)
+        once()
+        reps, total = 0, 0.0
+        while total < 4.0 and reps < 8:
+            t0 = time.perf_counter()
+            once()
+            total += time.perf_counter() - t0
+            reps += 1
+        out[label] = {"value": round(reps * ROWS * COLS / total / 1e6, 3), "unit": "Mpix/s", "cores": nthr, "sample": "%d x 4096x4096" % reps}
+    return out
+
+
 def _cpu_baseline(theta):
-    """The CPU restatement of the reference call sequence (oracle/, kind 'port'), one thread,
-    on a bounded sample of the same workload: full 4096x4096 images, ~10-20 s of CPU work."""
+    """The CPU restatement of the reference call sequence (oracle/, kind 'port'), one thread, on a bounded sample of the same
+    workload (full 4096x4096 images, ~10-20 s of CPU work); then the example's own model of parallelism (one image per thread,
+    example/steer.cpp:169) and one image row-parallel -- on ALL host cores the process may use, with the
+    64-thread figures of earlier rounds beside them."""
     import numpy as np
     import oracle  # test infrastructure used as the timed CPU baseline leg only
     img = np.random.default_rng(1234).random((ROWS, COLS), dtype=np.float32)
@@ -139,29 +185,39 @@ def _cpu_baseline(theta):
     while total < 10.0 and reps < 16:
         total += oracle.time_g2_filter_steer(img, theta, 1)
         reps += 1
-    # the example's own model of parallelism (example/steer.cpp:169): one image per thread, all cores.
-    # Bounded: at most 64 threads, one 1920x1080 frame each, repeated for ~2-5 s of wall time.
     from concurrent.futures import ThreadPoolExecutor
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     frame = np.random.default_rng(99).random((1080, 1920), dtype=np.float32)
-    per_thread = 12
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as pool:  # ctypes releases the GIL inside the C call
-        list(pool.map(lambda _: oracle.time_g2_filter_steer(frame, theta, per_thread), range(threads)))
-    wall = time.perf_counter() - t0
-    many = {"value": round(threads * per_thread * 1080 * 1920 / wall / 1e6, 3), "unit": "Mpix/s", "cores": threads,
-            "sample": "%d threads x %d x (1080x1920 f32, 7 sepFilter2D + scalar steer), one frame per thread" % (threads, per_thread)}
-    # ... and one image with its rows split over the same number of threads (bands with halo rows)
-    t_mt = min(oracle.time_g2_filter_steer_mt(img, theta, 1, threads) for _ in range(3))
-    banded = {"value": round(ROWS * COLS / t_mt / 1e6, 3), "unit": "Mpix/s", "cores": threads,
-              "sample": "best of 3 x (4096x4096 f32, 7 sepFilter2D + scalar steer), rows split over %d threads" % threads}
-    return {
+
+    def per_thread(threads, per=12):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as pool:  # ctypes releases the GIL inside the C call
+            list(pool.map(lambda _: oracle.time_g2_filter_steer(frame, theta, per), range(threads)))
+        wall = time.perf_counter() - t0
+        return {"value": round(threads * per * 1080 * 1920 / wall / 1e6, 3), "unit": "Mpix/s", "cores": threads,
+                "sample": "%d threads x %d x (1080x1920 f32, 7 sepFilter2D + scalar steer), one frame per thread" % (threads, per)}
+
+    def banded(threads):
+        t_mt = min(oracle.time_g2_filter_steer_mt(img, theta, 1, threads) for _ in range(3))
+        return {"value": round(ROWS * COLS / t_mt / 1e6, 3), "unit": "Mpix/s", "cores": threads,
+                "sample": "best of 3 x (4096x4096 f32, 7 sepFilter2D + scalar steer), rows split over %d threads" % threads}
+
+    t64 = max(1, min(avail, 64))
+    res = {
         "value": round(reps * ROWS * COLS / total / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
-        "one_image_per_thread": many, "one_image_row_parallel": banded,
         "sample": "%d x (4096x4096 f32, 7 sepFilter2D + scalar steer), single thread, oracle/ C restatement "
-                  "(-O3 -march=native); OpenCV itself is not installed on this image" % reps,
-        "host_cpus": os.cpu_count(),
+                  "(-O3 -march=native)" % reps,
+        "one_image_per_thread": per_thread(avail), "one_image_row_parallel": banded(avail),
+        "host_cpus": os.cpu_count(), "usable_cpus": avail, "cpu_model": _cpu_model(),
     }
+    if t64 != avail:
+        res["one_image_per_thread_64"] = per_thread(t64)
+        res["one_image_row_parallel_64"] = banded(t64)
+    res["opencv"] = _opencv_baseline(theta, avail)
+    return res
 
 
 def main():
@@ -173,10 +229,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--extra-timeout", type=int, default=300, help="seconds the secondary legs may take before every rank gives up on them (0 = no watchdog)")
-    ap.add_argument("--placement", type=int, default=1, choices=(0, 1),
-                    help="CVS_OPT_PLACEMENT_SEARCH of the headline handle: 1 = the library's opt-in allocation-time placement search "
-                         "switched on (what it found and cost is recorded in config.placement; extra.M2_plain_block is the same loop with 0), "
-                         "0 = the library default, a plain hipMalloc block")
+    ap.add_argument("--placement", type=int, default=0, choices=(0, 1),
+                    help="CVS_OPT_PLACEMENT_SEARCH of the headline handle: 0 (default) = the library default, a plain hipMalloc block; "
+                         "1 = the library's opt-in allocation-time placement search (A/B aid: extra.M2_placement_window reports it in any case)")
     ap.add_argument("--repeats", type=int, default=11, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
     ap.add_argument("--leg-repeats", type=int, default=5, help="repeats of every secondary leg's timed region (median reported)")
     args = ap.parse_args()
@@ -244,12 +299,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return tuple(float(v) for v in t)
 
+    # which physical device every rank sits on: a run with N ranks on fewer than N distinct GPUs is a rehearsal and must
+    # never be scored as a scaling result
+    try:
+        my_uuid = str(torch.cuda.get_device_properties(local_rank).uuid)
+    except Exception:
+        my_uuid = "device-%d" % local_rank
+    uuids = [my_uuid]
+    if dist is not None:
+        uuids = [None] * ws
+        dist.all_gather_object(uuids, my_uuid)
+    distinct = len(set(uuids)) == len(uuids)
+    if ws > 1 and not test_backend and not distinct:
+        raise SystemExit("bench.py: %d ranks on %d distinct GPUs -- one rank per GPU is required for a real run "
+                         "(CVS_BENCH_TEST_BACKEND=gloo is the rehearsal mode)" % (ws, len(set(uuids))))
+
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)  # i.i.d. uniform [0,1)
     f = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-    # the headline handle runs with the library's OPT-IN placement search on (a documented tuning knob, off by default in the
-    # library): config.placement records what it found and what it cost, extra.M2_plain_block is the same loop without it
-    f.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
+    # the headline handle is a handle as the library hands it out: no option is touched (--placement 1 is an A/B aid)
+    if args.placement:
+        f.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
     if args.strip_rows:
         f.set_strip_rows(args.strip_rows)
     g = torch.empty_like(img)
@@ -298,9 +368,17 @@ def main():
 
     threading.Thread(target=sigterm_watcher, daemon=True).start()
 
-    for _ in range(INIT_CALLS):
-        step()
-    torch.cuda.synchronize()
+    def launch_of(handle):
+        li = handle.launch_info()
+        return {k: li[k] for k in ("block_order", "xcd_weights", "strip_rows", "nt_stores", "state_layout", "tuning_launches")}
+
+    def settle(fn, n=SETTLE_CALLS):
+        """calls before a timed region on a new (handle, entry point, shape): the online tuner compares its candidates on them"""
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+
+    settle(step, INIT_CALLS)
     R = max(1, args.repeats)
     walls, evs = _time_steps(torch, step, args.steps, args.warmup, barrier, repeats=R)
     # per repeat: the slowest rank; then the median over the repeats
@@ -335,11 +413,12 @@ def main():
                                "per GPU per step, image resident in HBM, bases persisted (BASELINE configs[1])",
                    "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective",
                    "init_calls": INIT_CALLS, "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process"),
+                   "library_defaults": not args.placement and not args.strip_rows,
                    "placement": {"mode": info["placement_mode"], "window_found": bool(info["window_found"]), "probe_ms": round(info["probe_ms"], 3),
-                                 "note": "CVS_OPT_PLACEMENT_SEARCH of the headline handle: 1 = the library's opt-in allocation-time search, switched on "
-                                         "by bench.py (--placement); 0 = plain hipMalloc block, the library default -- see extra.M2_plain_block"},
-                   "launch": {"block_order": info["block_order"], "xcd_weights": info["xcd_weights"], "strip_rows": info["strip_rows"],
-                              "nt_stores": info["nt_stores"], "note": "configuration of the timed launches: engine defaults or what the launch-order tuner kept"}},
+                                 "note": "CVS_OPT_PLACEMENT_SEARCH of the headline handle; 0 = plain hipMalloc block, the library default "
+                                         "(the opt-in search is reported as extra.M2_placement_window)"},
+                   "launch": dict(launch_of(f), note="configuration of the timed launches: the engine's default or what its online tuner kept; "
+                                                     "tuning_launches = launches issued beyond the caller's own calls")},
         "clocks": {"value": "host wall clock around the timed region, median of the repeats",
                    "roofline": "HIP events on the launch stream around the same region, median of the repeats; roofline.frac_wall = the same from the wall clock"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -347,7 +426,26 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "cvs::k_basis<BankG2, F_STEER>", "algorithmic_bytes_per_launch": BYTES_PER_PIX["M2"] * npix,
                      "avg_launch_ms": round(k_ms, 5)},
+        "multi_gpu": {"rccl_ranks": ws if (ws > 1 and not test_backend) else 0, "ranks": ws, "device_uuids": uuids, "distinct_devices": distinct,
+                      "transport": None, "note": "filled in by the C4_e2e / C3 band-split legs when ranks > 1"},
     })
+
+    # ---- north_star's own target, at the top level: the G2+H2 7-basis separable pass ALONE (M1, 32 B/pix), same handle,
+    # same image, library defaults, timed like the headline (median of the repeats, slowest rank) ----
+    def step_m1():
+        f.setup(img, flags=cv.SETUP_BASIS)
+
+    settle(step_m1)
+    R1 = max(3, R // 2)
+    _w1, e1 = _time_steps(torch, step_m1, args.steps, args.warmup, barrier, repeats=R1)
+    e1 = sorted(v / args.steps for v in max_over_ranks(*e1))
+    m1_ms = _median(e1)
+    out["roofline_m1"] = {"bound": "hbm", "kernel": "cvs::k_basis<BankG2, 0>", "frac": round(BYTES_PER_PIX["M1"] * npix / (m1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "achieved": round(BYTES_PER_PIX["M1"] * npix / (m1_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "avg_launch_ms": round(m1_ms, 5), "ms_min": round(e1[0], 5), "ms_max": round(e1[-1], 5), "repeats": R1,
+                          "Mpix/s": round(npix / (m1_ms * 1e-3) / 1e6, 1), "algorithmic_bytes_per_launch": BYTES_PER_PIX["M1"] * npix,
+                          "target": "north_star: >= 0.70 of the HBM roofline on this pass", "launch": launch_of(f)}
+    settle(step, 4)   # back to the headline entry point
 
     # ---- secondary legs (reported, not the headline) ----
     # Insurance for runs with several ranks: the secondary legs contain collectives (barriers, the RCCL scatter / gather
@@ -365,11 +463,11 @@ def main():
         timer = threading.Timer(args.extra_timeout, watchdog)
         timer.daemon = True
         timer.start()
+
     def run_extras():
         if os.environ.get("CVS_BENCH_TEST_CRASH_RANK") == str(rank):   # tests only: a rank that dies inside the secondary legs
             os._exit(17)
-        ksteps, kwarm = args.steps, max(10, args.warmup // 2)
-        WARM_NEW = 6   # a new handle / new shape: first call + the one tuning call happen in here
+        ksteps, kwarm = args.steps, max(5, args.warmup)
 
         def rate(ms, bpp, pix):
             return {"Mpix/s": round(pix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5), "GB/s": round(bpp * pix / (ms * 1e-3) / 1e9, 1),
@@ -383,9 +481,13 @@ def main():
             per = sorted(v / steps for v in max_over_ranks(*e_))
             return _median(per), per[0], per[-1]
 
-        def leg(name, fn, bpp, pix=npix, steps=None, warm=None):
+        def leg(name, fn, bpp, pix=npix, steps=None, warm=None, handle=None, settle_calls=SETTLE_CALLS):
+            if settle_calls:
+                settle(fn, settle_calls)
             ms, lo, hi = timed(fn, steps or ksteps, kwarm if warm is None else warm)
             extra[name] = dict(rate(ms, bpp, pix), ms_min=round(lo, 5), ms_max=round(hi, 5), repeats=LR)
+            if handle is not None:
+                extra[name]["launch"] = launch_of(handle)
 
         # the headline loop re-filters ONE 64 MiB image, which can stay resident in the 256 MiB Infinity Cache
         # between steps; this leg rotates 8 distinct images (512 MiB) so every input read comes from HBM
@@ -396,33 +498,56 @@ def main():
             rot["i"] = (rot["i"] + 1) & 7
             f.setup_steer(imgs8[rot["i"]], THETA, flags=cv.SETUP_BASIS, out=(g, h))
 
-        leg("M2_rotating_8_inputs", step_rot, BYTES_PER_PIX["M2"])
+        leg("M2_rotating_8_inputs", step_rot, BYTES_PER_PIX["M2"], handle=f)
 
-        # the bare kernel: a fresh handle with the launch-order tuning and the placement search both off
-        # (the engine's default order from the first call), same image, same outputs
+        # 8-bit images, what the reference's callers hold (test/test.cpp:73,85; example/steer.cpp:73-86): read as bytes by the
+        # kernel itself, 1 B/pix of input -> 1 + 36 = 37 algorithmic bytes per pixel; 8 images take turns
+        imgs8_u8 = [(im * 255.0).to(torch.uint8) for im in imgs8]
+
+        def step_rot_u8():
+            rot["i"] = (rot["i"] + 1) & 7
+            f.setup_steer(imgs8_u8[rot["i"]], THETA, flags=cv.SETUP_BASIS, out=(g, h))
+
+        leg("M2_u8_input_rotating", step_rot_u8, BYTES_PER_PIX["M2_u8"], handle=f)
+        extra["M2_u8_input_rotating"]["note"] = "8 rotating 8-bit images, bytes read inside the filter kernel (no widening pass): 1 B in + 36 B out per pixel"
+        del imgs8_u8
+
+        # the engine's defaults without the online tuner, same image, same outputs
         fu = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
         fu.set_option(L.OPT_AUTOTUNE, 0)
-        fu.set_option(L.OPT_PLACEMENT_SEARCH, 0)
-        leg("M2_untuned", lambda: fu.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], warm=max(2, args.warmup))
-        extra["M2_untuned"]["note"] = "fresh handle, CVS_OPT_AUTOTUNE=0, CVS_OPT_PLACEMENT_SEARCH=0 (engine defaults from the first call)"
-        rotu = {"i": 0}
-
-        def step_rot_u():
-            rotu["i"] = (rotu["i"] + 1) & 7
-            fu.setup_steer(imgs8[rotu["i"]], THETA, flags=cv.SETUP_BASIS, out=(g, h))
-
-        leg("M2_untuned_rotating_8_inputs", step_rot_u, BYTES_PER_PIX["M2"], warm=max(2, args.warmup))
+        leg("M2_untuned", lambda: fu.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], handle=fu, settle_calls=4)
+        extra["M2_untuned"]["note"] = "fresh handle, CVS_OPT_AUTOTUNE=0 (the engine's default configuration from the first call)"
         del fu
 
-        # the reference's usage pattern: ONE object per image (example/steer.cpp:86, test/test.cpp:85) -- create,
-        # one fused call, wait, destroy.  `ms_call` = HIP events around the single call; `ms_object` = wall time of
-        # create + call + sync + destroy.  Cold = the process-wide state-block cache emptied first (hipMalloc of
-        # 0.8 GB inside the call); warm = the block of the previous object is taken over.
+        # the reference's usage pattern: ONE object per image (example/steer.cpp:86, test/test.cpp:85).
+        # (a) `M2_one_object_per_image`: a loop of 64 objects -- create, one fused call, destroy -- on a stream of different
+        #     images WITHOUT any host synchronisation between them (cvs_destroy parks the state block with an event, the next
+        #     object's launch is queued behind it): HIP events around the whole loop / 64.
+        # (b) `M2_first_call`: the same object by object with a synchronisation after each (latency view): `ms` = events
+        #     around the single call, `ms_object` = wall time of create + call + sync + destroy; cold = the process-wide
+        #     state-block cache emptied first (hipMalloc of 0.8 GB inside the call).
+        def object_loop(nobj):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(nobj):
+                fo = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+                fo.setup_steer(imgs8[i & 7], THETA, flags=cv.SETUP_BASIS, out=(g, h))
+                del fo
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / nobj
+
+        object_loop(SETTLE_CALLS)
+        per_obj = sorted(max_over_ranks(*[object_loop(64) for _ in range(LR)]))
+        extra["M2_one_object_per_image"] = dict(rate(_median(per_obj), BYTES_PER_PIX["M2"], npix), ms_min=round(per_obj[0], 5), ms_max=round(per_obj[-1], 5),
+                                                repeats=LR, objects_per_repeat=64,
+                                                note="64 x (create, one fused filter+steer call on a different image, destroy), no host synchronisation "
+                                                     "inside the loop; events around the loop / 64")
+
         def one_object(image):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             fo = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-            fo.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)   # like the headline handle; the first (cold) object pays for the probe
             e0.record()
             fo.setup_steer(image, THETA, flags=cv.SETUP_BASIS, out=(g, h))
             e1.record()
@@ -438,47 +563,39 @@ def main():
         ms_obj = sorted(r[0] for r in runs)[len(runs) // 2]
         extra["M2_first_call"] = dict(rate(ms_call, BYTES_PER_PIX["M2"], npix), ms_object=round(ms_obj, 4),
                                       ms_call_cold=round(cold[1], 4), ms_object_cold=round(cold[0], 4),
-                                      placement_mode=args.placement,
-                                      note="one new handle per image, a different image each time; median of 10; "
-                                           "ms = events around the single call, ms_object = create+call+sync+destroy wall; "
-                                           "cold = block cache emptied first (with placement 1 the cold object runs the probe, the others take the parked window)")
+                                      note="one new handle per image with a host synchronisation after each; median of 10; "
+                                           "ms = events around the single call (includes the host's launch latency on an idle GPU), "
+                                           "ms_object = create+call+sync+destroy wall; cold = block cache emptied first")
         del imgs8
 
-        # the headline loop on the library's DEFAULT allocation -- a plain hipMalloc state block, no placement search -- with the
-        # launch-order tuner on: next to `value` it shows what the placement search is worth on THIS box (or that it is
-        # worth nothing here: config.placement.window_found)
+        # the library's OPT-IN placement search (CVS_OPT_PLACEMENT_SEARCH = 1, planar per-plane windows): the headline loop on a
+        # handle with the knob on -- what it finds and costs on THIS box
         try:
             fp_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-            fp_.set_option(L.OPT_PLACEMENT_SEARCH, 0)
-            for _ in range(INIT_CALLS):
-                fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
-            leg("M2_plain_block", lambda: fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], warm=max(2, args.warmup))
+            fp_.set_option(L.OPT_PLACEMENT_SEARCH, 1)
+            leg("M2_placement_window", lambda: fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], handle=fp_)
             pi_ = fp_.launch_info()
-            extra["M2_plain_block"].update({"block_order": pi_["block_order"], "xcd_weights": pi_["xcd_weights"], "strip_rows": pi_["strip_rows"],
-                                            "note": "CVS_OPT_PLACEMENT_SEARCH = 0 (the library default), otherwise the headline loop"})
+            extra["M2_placement_window"].update({"window_found": bool(pi_["window_found"]), "probe_ms": round(pi_["probe_ms"], 3),
+                                                 "note": "CVS_OPT_PLACEMENT_SEARCH = 1 (opt-in tuning knob, off by default), otherwise the headline loop"})
             del fp_
         except Exception as ex:
-            extra["M2_plain_block"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            extra["M2_placement_window"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
         if ws == 1:
-            # (for a second or two after gigabytes of device memory have been released -- the spare pieces of a placement
-            # search, any large hipFree -- host-link copies of the process run at about half rate, 56 -> 30 GB/s both
-            # ways, tools/d2h_probe.hip with plain HIP calls; the handles below are created, searched and warmed first,
-            # then the leg waits that out)
             # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in and out -- a
             # stream of 8 different host images, 64 MiB up and 2 x 64 MiB down per image, pageable host memory.  The call
-            # overlaps upload, filtering and download band by band (cvs_api.cpp host_pipeline); `sequential` is the same
+            # overlaps upload, filtering and download band by band (cvs_host.cpp); `sequential` is the same
             # with CVS_OPT_HOST_OVERLAP = 0.  Floor of the link: 128 MiB down at ~56 GB/s = 2.4 ms per image.
+            # (for a second or two after gigabytes of device memory have been released host-link copies of the process run
+            # at about half rate, tools/d2h_probe.hip; the handles below are created and warmed first, then the leg waits)
             import numpy as np
             himgs = [np.random.default_rng(500 + i).random((ROWS, COLS), dtype=np.float32) for i in range(8)]
             hg, hh = np.empty_like(himgs[0]), np.empty_like(himgs[0])
-
             fhs = {}
             for overlap in (0, 1):
                 fhs[overlap] = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
                 fhs[overlap].set_option(L.OPT_HOST_OVERLAP, overlap)
                 fhs[overlap].setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
-
             torch.cuda.synchronize()
             time.sleep(2.5)
 
@@ -497,7 +614,6 @@ def main():
                                                       "note": "stream of 8 host f32 images in, g2/h2 out to host, bases stay on device; "
                                                               "link floor = 128 MiB down per image"}
             del himgs
-
 
         if ws == 1:
             # throughput mode: consecutive images go to two handles on two HIP streams, so the tail of one launch
@@ -529,34 +645,37 @@ def main():
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / k
 
-            timed_two(2 * WARM_NEW)
+            timed_two(2 * SETTLE_CALLS)
             ms2 = timed_two(ksteps)
             extra["M2_two_streams_two_images"] = dict(rate(ms2, 40, npix), note="alternating images on two handles / two streams; not the headline configuration")
             torch.cuda.current_stream().synchronize()
             f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))  # back on the main stream
             del f2, img2, g2_, h2_
-            leg("M1_basis_only", lambda: f.setup(img, flags=cv.SETUP_BASIS), BYTES_PER_PIX["M1"])
-            leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"])
-            outs8 = [torch.empty_like(img) for _ in range(8)]
-            leg("M5_pipeline", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"])
+            leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"], handle=f)
+            # the eight outputs of the pipeline as rows of ONE block ([row][plane][column]; cv.alloc_planes), the layout the
+            # engine gives its own state planes: strided views like any cv::Mat ROI.  `M5_pipeline_separate_outputs` = eight
+            # separate allocations (rounds 1-3).
+            outs8 = cv.alloc_planes(8, ROWS, COLS, device=dev)
+            leg("M5_pipeline", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"], handle=f)
+            outs8s = [torch.empty_like(img) for _ in range(8)]
+            leg("M5_pipeline_separate_outputs", lambda: f.pipeline(img, out=outs8s), BYTES_PER_PIX["M5"], handle=f, settle_calls=8)
+            del outs8s
             f.setup(img, flags=cv.SETUP_FULL)
-            leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36)
-            leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), 64)
+            leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36, settle_calls=4)
+            leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), 64, settle_calls=4)
             del outs8
-            f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)   # (library default allocation: the placement probe is built on the
-            # G2 kernels' write pattern and does not help the G4 pair kernel -- same box, 0.65 with a window against 0.69 without)
-            leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"])
-            leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"])
+            f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)
+            leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"], handle=f4)
+            leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"], handle=f4)
             del f4
             # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed
             # start-up cost of a launch (every wave primes its 8-row window before its first store) amortises
             big2 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
             fb = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-            fb.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
             gb, hb = torch.empty_like(big2), torch.empty_like(big2)
             bsteps = max(5, args.steps // 4)
-            leg("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
-            leg("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
+            leg("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32, pix=4 * npix, steps=bsteps, warm=2, handle=fb)
+            leg("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40, pix=4 * npix, steps=bsteps, warm=2, handle=fb)
             # ... and with two images taking turns: the two legs above re-filter ONE 256 MiB image, most of which is still in
             # the 256 MiB Infinity Cache when the next step starts (the streaming stores do not displace it); any launch in
             # between that touches 64 MiB ends that (tools/c3_between.py), and so does a second image
@@ -567,7 +686,7 @@ def main():
                 flipb["i"] ^= 1
                 fb.setup_steer(big3 if flipb["i"] else big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb))
 
-            leg("M2_filter_steer_8192_rotating_2_inputs", step_big_rot, 40, pix=4 * npix, steps=bsteps, warm=WARM_NEW)
+            leg("M2_filter_steer_8192_rotating_2_inputs", step_big_rot, 40, pix=4 * npix, steps=bsteps, warm=2, handle=fb)
             del big2, big3, fb, gb, hb
 
         # ---- BASELINE config 4: 1080 x 1920 frames, the callers' whole pipeline per frame, 32 frames per GPU ----
@@ -577,7 +696,6 @@ def main():
         fsets = [torch.rand((nfr, 1080, 1920), generator=gen, device=dev, dtype=torch.float32) for _ in range(2)]
         fout = torch.empty((nfr, 8, 1080, 1920), device=dev)
         ff = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-        ff.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)   # batches: the real launch is timed on up to six candidate state blocks, once
         csteps = max(10, args.steps // 10)
         alt = {"i": 0}
 
@@ -585,13 +703,12 @@ def main():
             alt["i"] ^= 1
             ff.pipeline_batch(fsets[alt["i"]], out=fout)
 
-        ms, ms_lo, ms_hi = timed(step_c4, csteps, WARM_NEW)
+        settle(step_c4)
+        ms, ms_lo, ms_hi = timed(step_c4, csteps, 2)
         fp = nfr * 1080 * 1920
         extra["C4_32x1080p_pipeline_batch"] = dict(rate(ms, 84, ws * fp), ms_per_frame=round(ms / nfr, 5), launches_per_batch=1,
                                                    frames_per_gpu=nfr, timed_steps=csteps, frame_sets=2, ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR,
-                                                   launch={k: ff.launch_info()[k] for k in ("block_order", "xcd_weights", "strip_rows")},
-                                                   placement={"mode": args.placement, "better_block_found": bool(ff.launch_info()["window_found"]),
-                                                              "search_ms": round(ff.launch_info()["probe_ms"], 2)})
+                                                   launch=launch_of(ff))
         ff.set_persist(False)
         fo3 = torch.empty((nfr, 3, 1080, 1920), device=dev)
 
@@ -599,11 +716,24 @@ def main():
             alt["i"] ^= 1
             ff.pipeline_batch(fsets[alt["i"]], out=fo3, outputs=(5, 6, 7))
 
-        ms, ms_lo, ms_hi = timed(step_c4f, csteps, WARM_NEW)
+        settle(step_c4f)
+        ms, ms_lo, ms_hi = timed(step_c4f, csteps, 2)
         extra["C4_32x1080p_feature_maps_only"] = dict(rate(ms, 16, ws * fp), ms_per_frame=round(ms / nfr, 5), timed_steps=csteps,
-                                                      ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR,
+                                                      ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR, launch=launch_of(ff),
                                                       note="edges + dark + bright only, no state persisted (what example/steer.cpp keeps)")
-        del fout, fo3
+        # ... and from 8-bit frames, the example's sources (steer.cpp:73-80): bytes read inside the kernel, 1 + 12 = 13 B/pix
+        fsets_u8 = [(fs * 255.0).to(torch.uint8) for fs in fsets]
+
+        def step_c4f_u8():
+            alt["i"] ^= 1
+            ff.pipeline_batch(fsets_u8[alt["i"]], out=fo3, outputs=(5, 6, 7))
+
+        settle(step_c4f_u8)
+        ms, ms_lo, ms_hi = timed(step_c4f_u8, csteps, 2)
+        extra["C4_32x1080p_u8_feature_maps"] = dict(rate(ms, BYTES_PER_PIX["C4_u8_feat3"], ws * fp), ms_per_frame=round(ms / nfr, 5), timed_steps=csteps,
+                                                    ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR, launch=launch_of(ff),
+                                                    note="8-bit frames in (read as bytes by the kernel), edges + dark + bright out, no state persisted")
+        del fout, fo3, fsets_u8
 
         # ---- config 4 end to end through the NATIVE batch entry (cvs_batch_run, cvs_batch.cpp): frames on rank 0 ->
         # scatter (grouped ncclSend/ncclRecv) -> one fused launch per rank -> gather of the three feature maps on rank 0.
@@ -616,6 +746,10 @@ def main():
         if not test_backend:   # the rehearsal backend has no RCCL communicator to build on
             try:
                 nbat = batch.NativeBatch.local((local_rank,)) if ws == 1 else batch.NativeBatch.from_torch_distributed(local_rank)
+                if ws > 1 and distinct and nbat.transport != "rccl":
+                    raise RuntimeError("%d ranks on distinct GPUs but the batch layer chose transport %r -- a rehearsal transport must "
+                                       "never carry a real multi-GPU run" % (ws, nbat.transport))
+                out["multi_gpu"]["transport"] = nbat.transport
                 nbat.set_persist(False)
                 e2e_out = torch.empty((n_all, 3) + shape, device=dev) if rank == 0 else None
                 reps, acc, wall_e2e = 5, {"scatter": 0.0, "compute": 0.0, "gather": 0.0}, 0.0
@@ -634,10 +768,13 @@ def main():
                                    "end_to_end_Mpix/s": round(n_all * 1080 * 1920 / wall_e2e / 1e6, 1),
                                    "gathered": "3 feature maps per frame on rank 0", "entry": "cvs_batch_run", "transport": nbat.transport,
                                    "world": "one process" if ws == 1 else "one process per GPU (ncclCommInitRank, id carried by torch.distributed)"}
+                out["multi_gpu"]["C4_e2e"] = {"frames": n_all, "phase_ms": extra["C4_e2e"]["ms"], "ms_wall": extra["C4_e2e"]["ms_wall"],
+                                              "end_to_end_Mpix/s": extra["C4_e2e"]["end_to_end_Mpix/s"], "transport": nbat.transport}
                 nbat.close()
                 del e2e_out
             except Exception as ex:   # a failing end-to-end leg must not take the headline down with it
                 extra["C4_e2e"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                out["multi_gpu"]["C4_e2e"] = extra["C4_e2e"]
             # ---- the same from HOST planes (what example/steer.cpp holds): each rank uploads its own frames from host memory,
             # launches, downloads its three maps -- chunked and overlapped inside the rank (cvs_batch_run, host planes).
             # PCIe-inclusive; never `value`.
@@ -647,7 +784,7 @@ def main():
                 hb.set_persist(False)
                 host_in = fsets[0].cpu().numpy()
                 host_out = _np.empty((nfr, 3) + shape, _np.float32)
-                time.sleep(2.0)   # host-link copies run at half rate for a moment after large device frees (DESIGN.md section 3)
+                time.sleep(2.0)   # host-link copies run at half rate for a moment after large device frees
                 best, tm_best = None, None
                 for rep in range(4):
                     t0 = time.perf_counter()
@@ -693,8 +830,6 @@ def main():
             lv = fp3.pyramid(bigs[0], 5)
             ppix = sum(l.shape[0] * l.shape[1] for l in lv)
             hp = [cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank) for _ in lv]
-            for hnd in hp:
-                hnd.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
             flip3 = {"i": 0}
 
             def pyr_filter():
@@ -712,9 +847,11 @@ def main():
                         hnd.setup(cur, flags=cv.SETUP_BASIS)
 
             c3 = max(10, args.steps // 10)
-            e_, _lo, _hi = timed(pyr_filter, c3, WARM_NEW)
+            settle(pyr_filter)
+            e_, _lo, _hi = timed(pyr_filter, c3, 2)
             e2_, _lo, _hi = timed(lambda: fp3.pyramid(bigs[0], 5), c3, 2)
-            e3_, e3_lo, e3_hi = timed(pyr_whole, c3, WARM_NEW)
+            settle(pyr_whole)
+            e3_, e3_lo, e3_hi = timed(pyr_whole, c3, 2)
             e_, e2_, e3_ = e_ * c3, e2_ * c3, e3_ * c3
             # algorithmic bytes of the whole configuration: 4 B read + 28 B written per pixel of every level, plus the
             # 4 B written per pixel of every level that is made here (levels 1..4)
@@ -726,7 +863,7 @@ def main():
                                                 "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                 "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix, "timed_steps": c3,
                                                 "whole_ms_min": round(e3_lo, 4), "whole_ms_max": round(e3_hi, 4), "repeats": LR,
-                                                "placement": {"mode": args.placement, "windows_found": [bool(hnd.launch_info()["window_found"]) for hnd in hp]},
+                                                "launch_per_level": [launch_of(hnd) for hnd in hp],
                                                 "note": "whole = build + filter, level k+1 written by the filter launch of level k, two alternating images; "
                                                         "filter = five filter launches on a prebuilt pyramid; separate build + filter = filter_ms + pyramid_build_ms"}
             del bigs, lv, hp, fp3
@@ -737,6 +874,8 @@ def main():
             # are HIP events on the ranks' streams (slowest rank).  Never run on more than one GPU before the driver's node.
             try:
                 pb = batch.NativeBatch.from_torch_distributed(local_rank)
+                if distinct and pb.transport != "rccl":
+                    raise RuntimeError("%d ranks on distinct GPUs but transport %r" % (ws, pb.transport))
                 big = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32) if rank == 0 else None
                 reps, acc, wall3 = 3, {"broadcast": 0.0, "compute": 0.0, "gather": 0.0}, 0.0
                 for rep in range(reps + 1):
@@ -755,10 +894,14 @@ def main():
                     "compute_only_Mpix/s": round(ppix3 / (acc["compute"] * 1e-3) / 1e6, 1), "end_to_end_Mpix/s": round(ppix3 / wall3 / 1e6, 1),
                     "entry": "cvs_batch_pyramid_setup", "transport": pb.transport,
                     "note": "image on rank 0 -> ncclBroadcast -> every rank: pyramid + its row band of every level -> bands gathered into rank 0's state"}
+                out["multi_gpu"]["C3_band_split"] = {"phase_ms": extra["C3_pyramid_8192_5_levels_band_split"]["ms"], "ms_wall": round(wall3 * 1e3, 3),
+                                                     "end_to_end_Mpix/s": round(ppix3 / wall3 / 1e6, 1), "transport": pb.transport}
                 pb.close()
                 del big
             except Exception as ex:
                 extra["C3_pyramid_8192_5_levels_band_split"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                out["multi_gpu"]["C3_band_split"] = extra["C3_pyramid_8192_5_levels_band_split"]
+
     if not args.no_extra:
         try:
             run_extras()

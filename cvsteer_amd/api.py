@@ -35,6 +35,21 @@ def _is_torch(a):
     return torch is not None and isinstance(a, torch.Tensor)
 
 
+KIND_G2, KIND_G4 = L.KIND_G2, L.KIND_G4
+
+
+def alloc_planes(n, rows, cols, device=None):
+    """n output planes as rows of ONE block, [row][plane][column] -- the layout the engine gives its own state planes
+    (CVS_OPT_STATE_LAYOUT): a launch that writes all of them streams one linear sweep instead of n streams far apart.
+    Returns n strided (rows, cols) views, ordinary planes for every entry point (like cv::Mat ROIs: step = n * cols * 4).
+    device=None: numpy (host) planes."""
+    if device is None:
+        blk = np.empty((rows, n, cols), np.float32)
+    else:
+        blk = torch.empty((rows, n, cols), dtype=torch.float32, device=device)
+    return [blk[:, k, :] for k in range(n)]
+
+
 def num_basis(kind):
     return lib().cvs_num_basis(kind)
 
@@ -150,6 +165,12 @@ class SteerableFilters:
             return torch.empty(tuple(a.shape), dtype=torch.float32, device=a.device)
         return np.empty(a.shape, np.float32)
 
+    def _new_block_like(self, a, n):
+        """n fresh output planes shaped like `a`: device planes come as rows of one block (alloc_planes), host planes dense"""
+        if _is_torch(a) and a.is_cuda:
+            return alloc_planes(n, int(a.shape[0]), int(a.shape[1]), device=a.device)
+        return [self._new_like(a) for _ in range(n)]
+
     def set_option(self, option, value):
         self._check(lib().cvs_set_option(self._h, option, int(value)), "cvs_set_option")
 
@@ -212,7 +233,7 @@ class SteerableFilters:
         """setup(image) + steer(float theta) in one kernel launch -> (g, h)"""
         image = _as_input(image)
         self._like = image
-        g, h = out if out is not None else (self._new_like(image), self._new_like(image))
+        g, h = out if out is not None else self._new_block_like(image, 2)
         self._bind_stream(image, g, h)
         pi, pg, ph = _plane(image), _plane(g), _plane(h)
         self._check(lib().cvs_setup_steer(self._h, C.byref(pi), flags, float(theta), C.byref(pg), C.byref(ph)),
@@ -358,7 +379,7 @@ class SteerableFiltersG2(SteerableFilters):
         (g2, h2, e, magnitude, phase, edges, dark, bright)"""
         image = _as_input(image)
         self._like = image
-        outs = list(out) if out is not None else [self._new_like(image) for _ in range(8)]
+        outs = list(out) if out is not None else self._new_block_like(image, 8)
         self._bind_stream(image, *[o for o in outs if o is not None])
         pi = _plane(image)
         planes = [_plane(o) if o is not None else None for o in outs]

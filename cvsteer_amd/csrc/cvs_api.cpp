@@ -25,937 +25,11 @@
 #include <thread>
 #include <vector>
 
-#include "cvs_internal.h"
-#include "cvsteer_hip.h"
+#include "cvs_context.h"
 
 using namespace cvs;
 
-struct cvs_context {
-    int kind = 0, width = 0, nb = 0, device = 0;
-    float spacing = 0.f;
-    hipStream_t stream = nullptr;
-    float taps[kMaxBasis][kMaxTaps];
-    // state planes: nb basis, then c1,c2,c3,theta,strength
-    int rows = 0, cols = 0;
-    // geometry of the state: two groups of planes (nb basis planes; c1,c2,c3,theta,strength), each with its own row pitch
-    // and plane stride (elements) -- planar or row-interleaved, see ensure_state
-    size_t pitch = 0, plane_stride = 0;      // basis group
-    size_t opitch = 0, ostride = 0;          // orientation group
-    size_t orient_off = 0;                   // first orientation plane, elements from the frame's first basis plane
-    size_t dense_pitch = 0;                  // round_up(cols, 64): the length of one row of one plane
-    float* state = nullptr;      // = sb.base
-    size_t state_elems = 0;      // = sb.elems
-    StateBlock sb;               // owner of the state memory (cvs_state.cpp)
-    size_t placed_stride = 0;    // plane size the placement search has already run for (its answer may be "plain block")
-    size_t batch_searched_elems = 0;  // frame-batch state: block size the candidate search has already run for
-    bool have_basis = false, have_orient = false;
-    // batched state: num_frames blocks of (nb+5) planes; cur_frame selects the block all state
-    // accessors and steer calls address
-    int num_frames = 1, cur_frame = 0;
-    size_t frame_stride = 0;
-    BatchFrame* frame_tab = nullptr;
-    int frame_tab_cap = 0;
-    // staging arena for host planes and scratch (bump allocated per call)
-    float* arena = nullptr;
-    size_t arena_elems = 0, arena_used = 0;
-    float* point_out = nullptr;
-    unsigned long long* diag = nullptr;  // diagnostic builds only
-    const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
-    // placement = 0: the allocation-time placement search (cvs_state.cpp) is OPT-IN since round 3 -- on the judge's box of
-    // round 2 it cost 8 ms on first use and bought nothing, and it reserves address space for the life of the process
-    int layout = 1;   // CVS_OPT_STATE_LAYOUT: 0 = planar, 1 = row-interleaved (default)
-    int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 0, autotune = 1;
-    // what the last state allocation / the last basis launch of this handle did (cvs_get_launch_info)
-    int window_found = 0;
-    float probe_ms = 0.f;
-    cvs_launch_info last{};
-    int pyr_strip = 1;   // cvs_pyr_down as a strip march (CVS_PYR_STRIP=0: the stand-alone kernel; A/B only, same values)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // autotune timing (tune_block_order)
-    hipEvent_t ev_order = nullptr;            // cvs_set_stream: orders the new stream behind the old one
-    // overlapped host path (host_pipeline): copy streams and per-band events, created on first use
-    hipStream_t s_up = nullptr, s_down = nullptr;
-    std::vector<hipEvent_t> band_ev;
-    int host_overlap = 1;                     // CVS_OPT_HOST_OVERLAP
-    bool used = false;                        // any work queued on `stream` so far
-    std::string err;
-};
-
-// rows that are dense on both sides travel as ONE linear copy: over the host link a pitched 2-D copy of the same bytes
-// is served row by row and reaches a fraction of the rate (tools/d2h_probe.hip, tools/bytes_probe.py)
-static inline hipError_t copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
-                                   hipMemcpyKind kind, hipStream_t stream)
-{
-    if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * rows, kind, stream);
-    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, stream);
-}
-
 namespace {
-
-int fail(cvs_handle h, int code, const char* what)
-{
-    if (h) h->err = what;
-    return code;
-}
-
-int fail_hip(cvs_handle h, hipError_t e, const char* where)
-{
-    if (h) h->err = std::string(where) + ": " + hipGetErrorString(e);
-    return e == hipErrorOutOfMemory ? CVS_E_NOMEM : CVS_E_HIP;
-}
-
-#define HIP_TRY(h, expr)                                        \
-    do {                                                        \
-        hipError_t e__ = (expr);                                \
-        if (e__ != hipSuccess) return fail_hip(h, e__, #expr);  \
-    } while (0)
-
-size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
-
-bool is_u8(const cvs_plane* p) { return (p->mem & CVS_DEPTH_U8) != 0; }
-int mem_of(const cvs_plane* p) { return p->mem & 0xff; }
-
-int check_plane(cvs_handle h, const cvs_plane* p, const char* name, bool allow_u8 = false)
-{
-    if (!p) return fail(h, CVS_E_BADARG, name);
-    if (p->rows <= 0 || p->cols <= 0) return fail(h, CVS_E_SIZE, "empty plane");
-    if (!p->data) return fail(h, CVS_E_BADARG, name);
-    if ((p->mem & ~(0xff | CVS_DEPTH_U8)) || (is_u8(p) && !allow_u8)) return fail(h, CVS_E_BADARG, "bad mem / depth flags");
-    if (mem_of(p) != CVS_MEM_HOST && mem_of(p) != CVS_MEM_DEVICE) return fail(h, CVS_E_BADARG, "bad mem kind");
-    if (is_u8(p)) {
-        if (p->step < (size_t)p->cols) return fail(h, CVS_E_SIZE, "bad step");
-    } else if (p->step < (size_t)p->cols * sizeof(float) || p->step % sizeof(float)) {
-        return fail(h, CVS_E_SIZE, "bad step");
-    } else if (reinterpret_cast<uintptr_t>(p->data) % alignof(float)) {
-        return fail(h, CVS_E_BADARG, "f32 plane not aligned to 4 bytes");   // a float* the C language itself does not allow
-    }
-    return CVS_OK;
-}
-
-// Do two planes share a byte?  Same kind of memory only (a host plane and a device plane never do).  Planes with the same row
-// step are compared exactly -- two column ranges of one buffer side by side (ROI views) interleave in address space without
-// sharing anything --, planes with different steps by their address ranges (conservative).
-bool planes_overlap(const cvs_plane* a, const cvs_plane* b)
-{
-    if (!a || !b || !a->data || !b->data || mem_of(a) != mem_of(b)) return false;
-    auto width = [](const cvs_plane* p) { return (size_t)p->cols * (is_u8(p) ? 1 : sizeof(float)); };
-    auto extent = [&](const cvs_plane* p) { return (size_t)(p->rows - 1) * p->step + width(p); };
-    const uintptr_t pa = reinterpret_cast<uintptr_t>(a->data), pb = reinterpret_cast<uintptr_t>(b->data);
-    if (pa + extent(a) <= pb || pb + extent(b) <= pa) return false;
-    if (a->step != b->step || a->step == 0) return true;
-    const cvs_plane* lo = pa <= pb ? a : b;
-    const cvs_plane* hi = pa <= pb ? b : a;
-    const size_t d = (size_t)(reinterpret_cast<uintptr_t>(hi->data) - reinterpret_cast<uintptr_t>(lo->data));
-    const size_t r = d / lo->step, c = d % lo->step;   // hi's first pixel sits at (row r, byte column c) of lo's frame
-    return (r < (size_t)lo->rows && c < width(lo)) || (r + 1 < (size_t)lo->rows && c + width(hi) > lo->step);
-}
-
-// outputs of one call: none may share memory with the input it is computed from (the kernels read rows ahead of the rows
-// they write, and the overlapped host path downloads results while later rows are still being uploaded), nor with another output
-int check_no_overlap(cvs_handle h, const cvs_plane* input, const cvs_plane* const* outs, int n)
-{
-    for (int i = 0; i < n; ++i) {
-        if (!outs[i] || !outs[i]->data) continue;
-        if (input && planes_overlap(outs[i], input)) return fail(h, CVS_E_BADARG, "an output plane overlaps the input image");
-        for (int j = i + 1; j < n; ++j)
-            if (outs[j] && planes_overlap(outs[i], outs[j])) return fail(h, CVS_E_BADARG, "two output planes overlap each other");
-    }
-    return CVS_OK;
-}
-
-// per-pixel stages read a pixel and write the same pixel: an output may BE an input (same first pixel, same step -- the
-// reference itself calls wrap(m_theta, m_theta)), but it may not overlap one in any other way, nor another output
-int check_point_overlaps(cvs_handle h, std::initializer_list<const cvs_plane*> ins, std::initializer_list<const cvs_plane*> outs)
-{
-    for (auto o = outs.begin(); o != outs.end(); ++o) {
-        if (!*o || !(*o)->data) continue;
-        for (const cvs_plane* i : ins)
-            if (i && planes_overlap(*o, i) && !((*o)->data == i->data && (*o)->step == i->step))
-                return fail(h, CVS_E_BADARG, "an output plane overlaps an input plane without being it");
-        for (auto q = o + 1; q != outs.end(); ++q)
-            if (*q && planes_overlap(*o, *q)) return fail(h, CVS_E_BADARG, "two output planes overlap each other");
-    }
-    return CVS_OK;
-}
-
-int check_same(cvs_handle h, const cvs_plane* p, int rows, int cols)
-{
-    if (p->rows != rows || p->cols != cols) return fail(h, CVS_E_SIZE, "plane size mismatch");
-    return CVS_OK;
-}
-
-// ---- staging arena: device copies of host planes for the duration of one call ----
-struct Pending {
-    const cvs_plane* host;
-    float* dev;
-    size_t pitch;
-};
-
-struct Call {
-    cvs_handle h;
-    std::vector<Pending> outs;
-    bool touched_host = false;
-    size_t need = 0;
-    // overlapped host path: in_ref only reserves the device copy of a HOST image, host_pipeline moves the bytes
-    bool defer = false;
-    const cvs_plane* deferred_image = nullptr;
-    uint8_t* deferred_u8 = nullptr;   // device staging of an 8-bit host image
-    size_t deferred_u8_pitch = 0;
-    // 8-bit image read by the strip kernel itself (buffer_load_ubyte, widened in registers): no f32 copy of the image is made
-    bool u8_direct = false;
-};
-
-int arena_reserve(cvs_handle h, size_t elems)
-{
-    if (elems <= h->arena_elems) return CVS_OK;
-    if (h->arena) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        HIP_TRY(h, hipFree(h->arena));
-        h->arena = nullptr;
-        h->arena_elems = 0;
-    }
-    HIP_TRY(h, hipMalloc(&h->arena, elems * sizeof(float)));
-    h->arena_elems = elems;
-    return CVS_OK;
-}
-
-float* arena_take(cvs_handle h, size_t elems)
-{
-    float* p = h->arena + h->arena_used;
-    h->arena_used += round_up(elems, 64);
-    return p;
-}
-
-// bytes-as-floats of the device staging of an 8-bit HOST image (rows padded to 256 bytes)
-size_t u8_stage_elems(const cvs_plane* p) { return round_up(round_up((size_t)p->cols, 256) * p->rows / 4 + 64, 64); }
-
-size_t staged_elems(const cvs_plane* p)
-{
-    if (!p) return 0;
-    const size_t plane = round_up(round_up((size_t)p->cols, 64) * p->rows, 64);
-    if (is_u8(p))  // widened copy: f32 plane on the device, plus the byte image itself when it comes from the host
-        return plane + (mem_of(p) == CVS_MEM_HOST ? u8_stage_elems(p) : 0);
-    return mem_of(p) == CVS_MEM_HOST ? plane : 0;
-}
-
-// resolve an input plane to a device pointer (uploading host data)
-int in_ref(Call& c, const cvs_plane* p, PlaneRef& r)
-{
-    cvs_handle h = c.h;
-    if (is_u8(p) && c.u8_direct) {  // the strip kernel reads the bytes itself; r.pitch is then in BYTES (BasisArgs::in_u8)
-        if (mem_of(p) == CVS_MEM_DEVICE) {
-            r = {p->data, p->step};
-            return CVS_OK;
-        }
-        const size_t bpitch = round_up((size_t)p->cols, 256);
-        uint8_t* b = reinterpret_cast<uint8_t*>(arena_take(h, u8_stage_elems(p)));
-        HIP_TRY(h, copy_rows(b, bpitch, p->data, p->step, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, h->stream));
-        c.touched_host = true;
-        r = {reinterpret_cast<float*>(b), bpitch};
-        return CVS_OK;
-    }
-    if (is_u8(p)) {  // 8-bit image on a path the strip kernels do not cover (generic widths, tiny images, pyramid emission):
-                     // bytes cross PCIe, a widening pass makes the f32 plane on the device
-        const size_t pitch = round_up((size_t)p->cols, 64);
-        float* d = arena_take(h, pitch * p->rows);
-        const uint8_t* src = reinterpret_cast<const uint8_t*>(p->data);
-        size_t sstep = p->step;
-        if (mem_of(p) == CVS_MEM_HOST) {
-            const size_t bpitch = round_up((size_t)p->cols, 256);
-            uint8_t* b = reinterpret_cast<uint8_t*>(arena_take(h, round_up(bpitch * p->rows / 4 + 64, 64)));
-            if (c.defer) {
-                c.deferred_image = p;
-                c.deferred_u8 = b;
-                c.deferred_u8_pitch = bpitch;
-                r = {d, pitch};
-                return CVS_OK;
-            }
-            HIP_TRY(h, copy_rows(b, bpitch, p->data, p->step, (size_t)p->cols, p->rows, hipMemcpyHostToDevice, h->stream));
-            c.touched_host = true;
-            src = b;
-            sstep = bpitch;
-        }
-        HIP_TRY(h, launch_u8_to_f32(src, sstep, p->rows, p->cols, d, pitch, h->stream));
-        r = {d, pitch};
-        return CVS_OK;
-    }
-    if (p->mem == CVS_MEM_DEVICE) {
-        r = {p->data, p->step / sizeof(float)};
-        return CVS_OK;
-    }
-    const size_t pitch = round_up((size_t)p->cols, 64);
-    float* d = arena_take(h, pitch * p->rows);
-    if (c.defer) {
-        c.deferred_image = p;
-        r = {d, pitch};
-        return CVS_OK;
-    }
-    HIP_TRY(h, copy_rows(d, pitch * sizeof(float), p->data, p->step, (size_t)p->cols * sizeof(float), p->rows,
-                                hipMemcpyHostToDevice, h->stream));
-    c.touched_host = true;
-    r = {d, pitch};
-    return CVS_OK;
-}
-
-int out_ref(Call& c, const cvs_plane* p, PlaneRef& r)
-{
-    cvs_handle h = c.h;
-    if (!p) {
-        r = {nullptr, 0};
-        return CVS_OK;
-    }
-    if (p->mem == CVS_MEM_DEVICE) {
-        r = {p->data, p->step / sizeof(float)};
-        return CVS_OK;
-    }
-    const size_t pitch = round_up((size_t)p->cols, 64);
-    float* d = arena_take(h, pitch * p->rows);
-    c.outs.push_back({p, d, pitch});
-    r = {d, pitch};
-    return CVS_OK;
-}
-
-// download pending host outputs; host-touching calls return with the data landed
-int finish(Call& c)
-{
-    cvs_handle h = c.h;
-    for (const Pending& o : c.outs) {
-        HIP_TRY(h, copy_rows(o.host->data, o.host->step, o.dev, o.pitch * sizeof(float),
-                                    (size_t)o.host->cols * sizeof(float), o.host->rows, hipMemcpyDeviceToHost, h->stream));
-        c.touched_host = true;
-    }
-    if (c.touched_host) HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return CVS_OK;
-}
-
-int begin(cvs_handle h, Call& c, std::initializer_list<const cvs_plane*> planes, size_t extra = 0)
-{
-    c.h = h;
-    HIP_TRY(h, hipSetDevice(h->device));
-    h->used = true;
-    size_t need = extra;
-    for (const cvs_plane* p : planes) need += staged_elems(p);
-    if (need) {
-        int rc = arena_reserve(h, need);
-        if (rc) return rc;
-    }
-    h->arena_used = 0;
-    return CVS_OK;
-}
-
-float* state_plane(cvs_handle h, int idx)
-{
-    float* frame = h->state + (size_t)h->cur_frame * h->frame_stride;
-    return idx < h->nb ? frame + (size_t)idx * h->plane_stride : frame + h->orient_off + (size_t)(idx - h->nb) * h->ostride;
-}
-
-// a state plane with the row pitch of its group
-PlaneRef state_ref(cvs_handle h, int idx) { return {state_plane(h, idx), idx < h->nb ? h->pitch : h->opitch}; }
-
-// Process-wide cache of released state blocks.  The reference's usage model is one short-lived object per image
-// (example/steer.cpp:86 inside the parallel_for_ body; test/test.cpp:85): a hipMalloc + hipFree of the 0.8 GiB state
-// block per image costs more than the filtering itself, so cvs_destroy parks the block here (after its stream has
-// drained) and the next handle on the same device that needs a block of about that size takes it over.  Bounded:
-// CVS_STATE_POOL_MB megabytes in all (default 4096, 0 = off), blocks at most twice the size asked for;
-// cvs_release_cached_memory() empties it.
-std::mutex g_pool_mutex;
-std::vector<StateBlock> g_pool;
-std::set<std::tuple<int, int, int, size_t>> g_no_window;  // (device, planes, rows, pitch) whose placement probe found nothing
-
-size_t pool_limit_bytes()
-{
-    static const size_t lim = [] {
-        const char* e = std::getenv("CVS_STATE_POOL_MB");
-        const long mb = e ? std::atol(e) : 4096;
-        return mb > 0 ? (size_t)mb << 20 : (size_t)0;
-    }();
-    return lim;
-}
-
-// a plain block of about the size asked for, or a per-plane block of exactly the geometry asked for
-bool pool_take(int device, size_t elems, bool vmm, size_t piece_bytes_min, int nplanes, StateBlock& out)
-{
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    int best = -1;
-    for (int i = 0; i < (int)g_pool.size(); ++i) {
-        const StateBlock& b = g_pool[i];
-        if (b.device != device || b.vmm != vmm) continue;
-        const bool fits = vmm ? ((int)b.pieces.size() == nplanes && b.piece_bytes >= piece_bytes_min && b.piece_bytes <= piece_bytes_min + piece_bytes_min / 4 + ((size_t)2 << 20))
-                              : (b.elems >= elems && b.elems <= 2 * elems);
-        if (fits && (best < 0 || b.elems < g_pool[best].elems)) best = i;
-    }
-    if (best < 0) return false;
-    out = g_pool[best];
-    g_pool.erase(g_pool.begin() + best);
-    return true;
-}
-
-// blk.ready (if any) marks the end of the work that last used the block
-void pool_give(StateBlock& blk)
-{
-    const size_t lim = pool_limit_bytes(), bytes = blk.elems * sizeof(float);
-    std::vector<StateBlock> drop;
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        if (bytes > lim) drop.push_back(blk);
-        else {
-            size_t held = bytes;
-            for (const StateBlock& b : g_pool) held += b.elems * sizeof(float);
-            while (held > lim && !g_pool.empty()) {  // oldest first
-                held -= g_pool.front().elems * sizeof(float);
-                drop.push_back(g_pool.front());
-                g_pool.erase(g_pool.begin());
-            }
-            g_pool.push_back(blk);
-        }
-    }
-    blk = StateBlock();
-    for (StateBlock& d : drop) state_block_free(d);
-}
-
-// The handle lets go of its state block WITHOUT draining the device: an event recorded on its stream travels with the
-// parked block, and the next taker's stream waits for it (ensure_state).  The reference's callers build one object per
-// image (example/steer.cpp:86): object k+1's launch is queued while object k's is still running.
-void release_state(cvs_handle h)
-{
-    if (!h->state) return;
-    h->sb.ready = nullptr;
-    if (h->used) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(h->stream, &cap);
-        hipEvent_t ev = nullptr;
-        if (cap == hipStreamCaptureStatusNone && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess &&
-            hipEventRecord(ev, h->stream) == hipSuccess) {
-            h->sb.ready = ev;
-        } else {
-            if (ev) (void)hipEventDestroy(ev);
-            (void)hipGetLastError();
-            if (cap == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(h->stream);
-        }
-    }
-    pool_give(h->sb);
-    h->state = nullptr;
-    h->state_elems = 0;
-}
-
-// row-interleaved state planes (CVS_OPT_STATE_LAYOUT = 1, the default) while a whole group of planes stays below 2 GiB, i.e.
-// within the 32-bit buffer offsets of one launch (larger states -- 8192^2 G4, 16384^2 G2 -- stay planar and are banded)
-bool state_interleaved(cvs_handle h, int rows, size_t dense_pitch)
-{
-    return h->layout == 1 && (size_t)rows * dense_pitch * sizeof(float) * (size_t)std::max(h->nb, 5) <= (size_t)0x7ffffff0;
-}
-
-int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1)
-{
-    const size_t pitch = round_up((size_t)cols, 64);
-    size_t stride = round_up(pitch * rows, 64);
-    const int nplanes = h->nb + 5;
-    // Large single-image states get one physical allocation per plane, placed by a bounded search (cvs_state.cpp);
-    // small ones (they live in the Infinity Cache anyway) and frame batches take a plain block.
-    bool want_planes = h->placement != 0 && nframes == 1 && stride * sizeof(float) >= ((size_t)8 << 20) &&
-                       stride * sizeof(float) * nplanes >= ((size_t)256 << 20);
-    // a geometry whose probe found no window on this device takes plain blocks from now on (cvs_release_cached_memory()
-    // forgets that): the reference's callers build one object per image, and every new handle would search again
-    const auto geo = std::make_tuple(h->device, nplanes, rows, pitch);
-    if (want_planes) {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        if (g_no_window.count(geo)) want_planes = false;
-    }
-    bool reuse = h->state != nullptr;
-    if (reuse) {
-        if (want_planes && h->sb.vmm) reuse = (int)h->sb.pieces.size() == nplanes && h->sb.piece_bytes >= stride * sizeof(float) &&
-                                              h->sb.piece_bytes <= stride * sizeof(float) + stride + ((size_t)2 << 20);
-        else if (want_planes) reuse = h->placed_stride == stride && stride * nplanes <= h->state_elems;  // searched: a plain block it is
-        else reuse = !h->sb.vmm && stride * nplanes * (size_t)nframes <= h->state_elems;
-    }
-    if (!reuse) {
-        release_state(h);   // parked, not freed: a handle that alternates between two geometries gets its blocks back
-        const size_t elems = stride * nplanes * (size_t)nframes;
-        const bool from_pool = pool_take(h->device, elems, want_planes, stride * sizeof(float), nplanes, h->sb);
-        if (from_pool && h->sb.ready) {   // the previous owner's work on this block comes first
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(h->stream, &cap);
-            const hipError_t we = cap == hipStreamCaptureStatusNone ? hipStreamWaitEvent(h->stream, h->sb.ready, 0) : hipEventSynchronize(h->sb.ready);
-            (void)hipEventDestroy(h->sb.ready);
-            h->sb.ready = nullptr;
-            if (we != hipSuccess) return fail_hip(h, we, "waiting for a parked state block");
-        }
-        if (!from_pool) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(h->stream, &cap);
-            if (want_planes && cap == hipStreamCaptureStatusNone) HIP_TRY(h, state_block_alloc_planes(h->device, nplanes, rows, pitch, h->stream, h->placement, h->sb));
-            else HIP_TRY(h, state_block_alloc_plain(h->device, elems, h->sb));
-        }
-        if (want_planes && h->sb.searched) {
-            std::lock_guard<std::mutex> lock(g_pool_mutex);
-            g_no_window.insert(geo);
-        }
-        h->window_found = h->sb.vmm ? 1 : 0;
-        h->probe_ms = (!from_pool && h->sb.probed) ? h->sb.probe_ms : 0.f;  // a parked block was paid for by an earlier handle
-        h->state = h->sb.base;
-        h->state_elems = h->sb.elems;
-        h->placed_stride = want_planes ? stride : 0;
-    }
-    if (h->sb.vmm) stride = h->sb.piece_bytes / sizeof(float);  // planes start at piece boundaries
-    h->rows = rows;
-    h->cols = cols;
-    h->dense_pitch = pitch;
-    // Layout of the planes inside the block.  Round 4 (tools/layout_probe.py, profiles/r04_layout_probe.txt): where the rows
-    // of the planes lie relative to each other decides how fast a launch that writes 7..20 planes at once streams.  PLANAR
-    // (plane after plane, rounds 1-3): a wave's stores of one output row go to addresses 64 MiB apart, one stream per plane.
-    // ROW-INTERLEAVED (default): row r of all planes of a group lies side by side -- [row][plane][column] -- so the launch's
-    // write frontier is ONE linear sweep through the block (per group), and every plane is still an ordinary strided view
-    // (step = planes x row length), which is all the per-pixel kernels, cvs_state_plane and the facade ever ask for.  Two
-    // groups, basis and orientation, so that a basis-only setup writes a dense stream too.  On plain blocks, same handles
-    // side by side: basis 0.76 -> 0.80, fused steer 0.70 -> 0.80, full setup 0.65 -> 0.82, pipeline 0.66 -> 0.73 of the HBM
-    // roofline, fresh images +4-5 points.  Per-plane windows (the opt-in placement search) keep the planar form.
-    const bool inter = state_interleaved(h, rows, pitch) && !h->sb.vmm;
-    if (inter) {
-        h->pitch = pitch * h->nb;
-        h->plane_stride = pitch;
-        h->opitch = pitch * 5;
-        h->ostride = pitch;
-        h->orient_off = round_up(pitch * rows * h->nb, 64);
-        h->frame_stride = h->orient_off + round_up(pitch * rows * 5, 64);   // <= stride * (nb + 5): the block holds it
-    } else {
-        h->pitch = h->opitch = pitch;
-        h->plane_stride = h->ostride = stride;
-        h->orient_off = stride * h->nb;
-        h->frame_stride = stride * (h->nb + 5);
-    }
-    h->last.state_layout = inter ? 1 : 0;
-    h->num_frames = nframes;
-    if (h->cur_frame >= nframes) h->cur_frame = 0;
-    return CVS_OK;
-}
-
-int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input = false)
-{
-    if (h->strip_rows > 0) return h->strip_rows;
-    // strips whose (rows + 2W) is a multiple of the 2W+1-row unroll waste no loop iterations.
-    // Measured on MI355X at 4096x4096 (tools/ab.py, tools/ab_g4.py; streaming stores): short strips
-    // win -- 19 rows for the 7-plane G2 kernel (~14k waves keep every CU's store queues busy, the
-    // extra halo rows are cache hits), 40 rows for the G4 half banks run in one launch.
-    const int nt = 2 * h->width + 1, halo = 2 * h->width;
-    const long strips_x = (cols + 63) / 64;
-    const double ideal = (double)rows * (double)strips_x / 2048.0;
-    long k = std::lround((ideal + halo) / nt);
-    // launches of >= 32 Mpix are long enough that the shorter strips' faster drain wins (tools/tune.py 8192:
-    // 80.5 vs 77.8 % at 8192x8192, 81.6 vs 77.7 % at 4096x8192)
-    // ... and so do inputs that are not cache-resident: when consecutive calls bring DIFFERENT images, the
-    // halo rows of vertically adjacent strips only hit in cache if those strips run close in time
-    // (tools/ab_rot.py, 8 rotating 4096x4096 inputs: 10-row strips 66 %, 19-row strips 57 %)
-    // G4 half banks: 40-row strips (k = 4) filter 30 % more rows than they write, 27-row strips 44 %; the kernel is
-    // SIMD-bound, so the taller strip wins by 1-3 points (tools/ab_same.py AB_KIND=4 "2=27" "2=40" "2=53", round 2)
-    // ... and so do plain state blocks (the library default; late round 3, tools/ab_same.py on one handle each, two boxes): where
-    // the planes lie in one run of the allocator -- most plain blocks -- the 10-row strips with the tiles dealt 5:4 win every
-    // variant (basis 77 -> 80 %, fused steer 74.6 -> 79.3 %, full setup 70.7 -> 72.9 %, pipeline 67.5 -> 69.6 %); on a placement
-    // window the 19-row strips at 4:3 stay ahead by 1-2 %.  The launch tuner times the other combination on the second call.
-    const bool plain_block = !h->sb.vmm && h->sb.base != nullptr && h->num_frames == 1 &&
-                             (size_t)rows * cols * sizeof(float) * (size_t)(h->nb + 5) >= ((size_t)256 << 20);   // states the Infinity Cache cannot hold
-    const long kmax = h->kind == CVS_KIND_G4 ? 4 : (fresh_input || plain_block || (size_t)rows * cols >= ((size_t)32 << 20)) ? 2 : 3;
-    if (k < 2) k = 2;
-    if (k > kmax) k = kmax;
-    return (int)(k * nt - halo);
-}
-
-// Streaming (nontemporal) stores: measured on MI355X (tools/membench.hip), "1 plane in, 7 out"
-// reaches ~5.9 TB/s with nt stores vs ~4.0 TB/s with plain stores once the planes no longer fit
-// the 256 MiB Infinity Cache.  Small frames whose whole state stays cache-resident keep plain
-// stores so the next per-pixel kernel finds them on die.
-int use_nt_stores(cvs_handle h, size_t npix)
-{
-    if (h->store_policy == 1) return 0;
-    if (h->store_policy == 2) return 1;
-    const size_t state_bytes = npix * sizeof(float) * (size_t)(h->nb + 5);
-    return state_bytes > (size_t)96 << 20;
-}
-
-// process-wide autotune memory: (device, kernel variant, rows, cols, strip rows) -> {times seen, chosen order}.
-// Shared by all handles, because the reference's usage pattern is one short-lived object per image.
-struct TuneEntry {
-    int seen = 0;
-    int order = -1;      // -1 = not tuned yet
-    int xw = 403;
-    int strip_rows = 0;  // 0 = the default height
-    int g4_split = 2;        // order 1: tiles per period for even / odd XCDs, 100 * e + o
-};
-std::mutex g_tune_mutex;
-std::map<std::tuple<int, int, int, int, int, int, int>, TuneEntry> g_tune;
-
-// Launch-order autotune.  Measured on ONE handle (one state allocation; tools/ab_same.py -- comparisons across
-// handles are confounded by where each state block happens to live, tools/alloc_modes.py): the odd XCDs run the G2
-// kernels ~25 % slower per strip, so dealing the tiles 4:3 (or 5:4) towards the even XCDs (order 1) is worth +2-3 % on
-// every G2 variant; band-group / column-major orders (T >= 2), shorter strips and 8-wave workgroups never win; the
-// G4 pair kernel prefers the plain order (order 1: -7 %).  So G2 starts out with order 1 at 4:3 and G4 with order 0,
-// and the second launch of a (device, kind, variant, shape) times the few alternatives on the caller's stream and
-// keeps a challenger only if it wins by 2 % -- the XCD asymmetry is a property of the box, not of the code.
-// CVS_OPT_BLOCK_ORDER >= 0 pins the order (CVS_OPT_XCD_WEIGHTS the weights) and switches the timing off.
-int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input);
-
-// launch configuration for the basis kernel about to run: order / strip height, tuned once per shape
-int tune_block_order(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input = false)
-{
-    return tune_launch(h, a, scr, variant, fresh_input);
-}
-
-int tune_launch(cvs_handle h, BasisArgs& a, float* scr, int variant, bool fresh_input)
-{
-    const int xw_pinned = h->xcd_weights;
-    const bool short_default = h->kind == CVS_KIND_G2 && !h->sb.vmm && h->strip_rows <= 0 && a.batch == 0 &&   // see default_strip_rows
-                               (size_t)a.rows * a.cols * sizeof(float) * (size_t)(h->nb + 5) >= ((size_t)256 << 20);
-    a.xcd_even = xw_pinned ? xw_pinned / 100 : short_default ? 5 : 4;
-    a.xcd_odd = xw_pinned ? xw_pinned % 100 : short_default ? 4 : 3;
-    a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
-    const bool fast = basis_fast_path(h->kind, h->width, h->taps);
-    const bool big = (size_t)a.rows * a.cols >= ((size_t)1 << 20);
-    if (h->block_order >= 0) a.block_order = h->block_order;
-    else {
-        // launches of 32 Mpix and more are long enough for the plain order (8192^2, one handle: M1 80.7 vs 80.2 %, M4 87.0 vs 80.5 %)
-        const bool huge = (size_t)a.rows * a.cols * (a.batch > 0 ? (size_t)a.batch : 1) >= ((size_t)32 << 20);
-        // ... and the stateless pipeline is VALU-bound, not write-bound: nothing to balance (32 x 1080p: 106 -> 93 Gpix/s weighted)
-        // ... and when every call brings a new image (inputs come from HBM, not the Infinity Cache) the plain order wins
-        // too (8 rotating 4096^2 inputs, one handle: M2 70-72 % plain, 64-68 % weighted)
-        a.block_order = (fast && big && !huge && !a.no_state && !fresh_input && h->kind == CVS_KIND_G2) ? 1 : 0;
-        // fresh images in the plain order fetch 1.24 x the image into the L2s: the 128-B line at a tile's left / right edge
-        // is wanted by two XCDs.  With every XCD owning a contiguous range of column blocks it is 1.11 x, at the same launch
-        // time (8 rotating 4096^2 inputs 66.0 vs 65.9 %, two 8192^2 inputs 66.4 vs 66.4 %) -- less HBM traffic for nothing.
-        // Needs the column blocks to divide evenly among the 8 XCDs.
-        const int grid_x = ((a.cols + 63) / 64 + 3) / 4;
-        if (fresh_input && fast && big && h->kind == CVS_KIND_G2 && a.batch == 0 && grid_x % 8 == 0) a.block_order = kOrderXcdColumns;
-    }
-    // Placement windows (opt-in search), resident image: what the sweeps of late round 3 found best there on one handle at a
-    // time (profiles/r03_launch_config_sweeps.txt and the wider sweep recorded beside it): 10-row strips with every XCD on
-    // its own range of column blocks for the basis / fused-steer / full-setup launches (basis 82.0 -> 84.8 %, fused steer
-    // 84.4 -> 85.7 %, full setup 84.7 -> 87.3 %), 10-row strips in the plain order for the pipeline (79.1 -> 86.5 %).  The
-    // tuner below still times the 19-row weighted family against it.
-    if (h->sb.vmm && h->kind == CVS_KIND_G2 && fast && big && !fresh_input && a.batch == 0 && !a.no_state && h->block_order < 0 &&
-        h->strip_rows <= 0 && (size_t)a.rows * a.cols < ((size_t)32 << 20)) {
-        const int grid_x = ((a.cols + 63) / 64 + 3) / 4;
-        if (variant & 4) {
-            a.block_order = 0;
-            a.strip_rows = 2 * (2 * h->width + 1) - 2 * h->width;
-        } else if (grid_x % 8 == 0) {
-            a.block_order = kOrderXcdColumns;
-            a.strip_rows = 2 * (2 * h->width + 1) - 2 * h->width;
-            if (!xw_pinned && (variant & 2)) { a.xcd_even = 7; a.xcd_odd = 6; }   // fused steer: 85.4 -> 88.3 % against equal shares
-        }
-    }
-    // the XCD-column order deals equal shares unless something above (or the caller) asked otherwise: fresh images lose 6-9
-    // points to an uneven deal, the 7- and 12-plane launches of a resident image gain nothing from one
-    if (a.block_order == kOrderXcdColumns && !xw_pinned && !(a.xcd_even == 7 && a.xcd_odd == 6)) a.xcd_even = a.xcd_odd = 1;
-    // small images and the generic path keep the plain configuration
-    if (!fast || !big) return CVS_OK;
-    // what is still open: the order (unless pinned), the strip height (unless pinned or the input stream is fresh
-    // images, where short strips are a must), the G4 bank layout (unless pinned)
-    // a stream of fresh images keeps its defaults (plain order, 10-row strips): the timing loop below re-filters ONE
-    // image, i.e. it would measure the cache-resident case and pick for the wrong regime
-    if (fresh_input) return CVS_OK;
-    const bool free_order = h->block_order < 0;
-    // (frame batches with state kept have their strip height timed as well since late round 3: 32 x 1080p, one handle, 10-row
-    // strips dealt 5:4 in the weighted order 0.652 against 0.627 for the default; the stateless launch is bound by the SIMDs
-    // and loses 7 % on short strips, so it keeps its default)
-    const bool free_strip = h->strip_rows <= 0 && !fresh_input && (a.batch == 0 || !a.no_state);
-    const bool free_split = h->kind == CVS_KIND_G4 && h->g4_split < 0;
-    if (!h->autotune || (!free_order && !free_strip && !free_split)) return CVS_OK;
-    // what the caller pinned is part of the key, in a field of its own (the raw block order can be as large as 1e6)
-    const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->g4_split >= 0 ? 1 : 0);
-    // the batch size is part of the shape: the order tuned for an 8-frame chunk is not the one a 32-frame batch wants
-    // ... and so is the kind of state block: on a placement window the 19-row strips win, on a plain block of one run the
-    // 10-row ones (same handle, plain block: fused steer 74.6 -> 79.5 %, basis 77.4 -> 79.2 %) -- what was tuned on one must
-    // not be handed to the other
-    const auto key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->sb.vmm ? 1024 : 0) | (h->kind << 12) | (pins << 16), a.rows, a.cols,
-                                     xw_pinned, h->block_order, a.batch);
-    {
-        std::lock_guard<std::mutex> lock(g_tune_mutex);
-        TuneEntry& e = g_tune[key];
-        if (e.order >= 0) {
-            a.block_order = e.order;
-            if (!xw_pinned) { a.xcd_even = e.xw / 100; a.xcd_odd = e.xw % 100; }
-            if (e.strip_rows > 0) a.strip_rows = e.strip_rows;
-            a.g4_split = e.g4_split;
-            return CVS_OK;
-        }
-        // a shape seen for the first time runs on the defaults: one-off images never pay for tuning
-        if (++e.seen < 2) return CVS_OK;
-    }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return CVS_OK;
-    if (!h->ev0) {
-        HIP_TRY(h, hipEventCreate(&h->ev0));
-        HIP_TRY(h, hipEventCreate(&h->ev1));
-    }
-    struct Cand { int order, xw, strip, split; };
-    const int xw0 = a.xcd_even * 100 + a.xcd_odd, sr0 = a.strip_rows, sp0 = a.g4_split, o0 = a.block_order;
-    const int sr_short = 2 * (2 * h->width + 1) - 2 * h->width, sr_tall = 3 * (2 * h->width + 1) - 2 * h->width;
-    // candidate 0 is the default; the others change one thing each (measured alternatives, see above)
-    Cand list[10];
-    int ncand = 0;
-    list[ncand++] = {o0, xw0, sr0, sp0};
-    if (h->kind == CVS_KIND_G2) {
-        // the configurations that win SOMEWHERE (late round 3, one handle at a time; profiles/r03_launch_config_sweeps.txt):
-        //   19-row strips dealt 4:3        placement windows, plain blocks across a boundary (the old default everywhere)
-        //   10-row strips dealt 5:4        plain blocks inside one run of the allocator: every variant
-        //   10-row strips, plain order     placement windows: full setup and pipeline; fast batch state blocks
-        //   10-row strips, XCD columns     placement windows: basis, fused steer, full setup
-        // plus their neighbours.  Whatever the caller pinned stays pinned; the default is candidate 0.
-        const bool strip_alt_ok = free_strip && (size_t)a.rows * a.cols < ((size_t)32 << 20);
-        const int grid_x_t = ((a.cols + 63) / 64 + 3) / 4;
-        //   ... the same with the odd XCDs leaving a thirteenth of their range to their even neighbours (7:6): the fused steer
-        //   on a window, 85.4 -> 88.3 % (the basis, full-setup and pipeline launches and fresh images prefer equal shares)
-        const Cand fam[8] = {{1, 403, sr_tall, sp0}, {1, 504, sr_short, sp0}, {0, xw0, sr_short, sp0}, {kOrderXcdColumns, 101, sr_short, sp0},
-                             {kOrderXcdColumns, 706, sr_short, sp0}, {0, xw0, sr_tall, sp0}, {1, 504, sr_tall, sp0}, {1, 403, sr_short, sp0}};
-        for (const Cand& c : fam) {
-            if (ncand >= 10) break;
-            const bool deals = c.order == 1 || c.order == kOrderXcdColumns;   // orders in which the even : odd shares matter
-            if (c.order != o0 && !free_order) continue;
-            if (c.strip != sr0 && !strip_alt_ok) continue;
-            if (deals && xw_pinned && c.xw != xw0) continue;
-            if (c.order == kOrderXcdColumns && (grid_x_t % 8 != 0 || a.batch != 0)) continue;
-            const int cxw = deals ? c.xw : xw0;
-            if (c.order == o0 && c.strip == sr0 && (!deals || cxw == xw0)) continue;   // the default itself
-            list[ncand++] = {c.order, cxw, c.strip, sp0};
-        }
-    } else {
-        if (free_order) list[ncand++] = {1, xw0, sr0, sp0};
-        if (free_split) list[ncand++] = {o0, xw0, sr0, 0};  // one 11-plane kernel instead of the two half banks
-        const int sr_g4 = 3 * (2 * h->width + 1) - 2 * h->width;  // the shorter strip (27 rows at width 6)
-        if (free_strip && sr_g4 != sr0) list[ncand++] = {o0, xw0, sr_g4, sp0};
-    }
-    float tmin[10];
-    for (float& t : tmin) t = std::numeric_limits<float>::max();
-    auto apply = [&](const Cand& c) {
-        a.block_order = c.order;
-        a.xcd_even = c.xw / 100;
-        a.xcd_odd = c.xw % 100;
-        a.strip_rows = c.strip;
-        a.g4_split = c.split;
-    };
-    // one untimed launch first (first touch of fresh allocations, clock ramp), then the candidates
-    // interleaved over several rounds so that drift hits them equally; keep each candidate's fastest run
-    // What is timed is a BURST of back-to-back launches, not one launch: callers queue call after call, and a
-    // configuration's isolated launch time says little about its rate in a queue (measured: 10-row strips at 5:4 win
-    // an isolated launch by 4 % and lose the queue by 9 %; round 2).
-    constexpr int kBurst = 3;
-    HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
-    for (int round = 0; round < 3; ++round) {
-        for (int ci = 0; ci < ncand; ++ci) {
-            apply(list[ci]);
-            HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-            for (int k = 0; k < kBurst; ++k) HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
-            HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-            HIP_TRY(h, hipEventSynchronize(h->ev1));
-            float ms = 0.f;
-            HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-            ms /= kBurst;
-            if (round > 0 && ms < tmin[ci]) tmin[ci] = ms;  // round 0 warms each candidate's own pattern
-        }
-    }
-    // Second stage: the short bursts above are biased against configurations whose launches feed on what the previous launch
-    // of the SAME configuration left in the L2s (the XCD-column order: 8 % slower in interleaved bursts of three, 1.7 % FASTER
-    // than the weighted order in a queue of its own launches).  The three best of the first stage -- and the default -- are
-    // timed again after ten settling launches each, in bursts of twelve; a challenger displaces the default only if it wins there by 2 %.
-    {
-        int order_by_time[10];
-        for (int i = 0; i < ncand; ++i) order_by_time[i] = i;
-        std::sort(order_by_time, order_by_time + ncand, [&](int x, int y) { return tmin[x] < tmin[y]; });
-        int fin[6], nfin = 0;
-        fin[nfin++] = 0;
-        for (int i = 0; i < ncand && nfin < 2; ++i)
-            if (order_by_time[i] != 0 && tmin[order_by_time[i]] < tmin[order_by_time[0]] * 1.10f) fin[nfin++] = order_by_time[i];
-        for (int i = 1; i < ncand && nfin < 4; ++i) {   // the XCD-column candidates always: they are the ones the short bursts misjudge
-            bool have = false;
-            for (int fi = 0; fi < nfin; ++fi) have = have || fin[fi] == i;
-            if (!have && list[i].order == kOrderXcdColumns) fin[nfin++] = i;
-        }
-        if (nfin > 1) {
-            // twenty launches per burst: the uneven XCD-column deal needs a queue of about ten of its own launches to show what
-            // it does in a loop (bursts of 8: 0.1020 ms, of 24: 0.0963 ms per launch; the equal deal 0.0974 either way)
-            constexpr int kLong = 12, kSettle = 10;
-            float t2[6];
-            for (float& t : t2) t = std::numeric_limits<float>::max();
-            for (int round = 0; round < 2; ++round)
-                for (int fi = 0; fi < nfin; ++fi) {
-                    apply(list[fin[fi]]);
-                    // ten launches to settle on this configuration (about a millisecond: the uneven XCD-column deal runs its first
-                    // ten launches after a change of configuration at 0.102 ms and the following ones at 0.093), then the timed ones
-                    for (int k = 0; k < kSettle; ++k) HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
-                    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-                    for (int k = 0; k < kLong; ++k) HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
-                    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-                    HIP_TRY(h, hipEventSynchronize(h->ev1));
-                    float ms = 0.f;
-                    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-                    t2[fi] = std::min(t2[fi], ms / kLong);   // both rounds count: every burst starts settled
-                }
-            for (int fi = 0; fi < nfin; ++fi) tmin[fin[fi]] = t2[fi];
-            for (int i = 0; i < ncand; ++i) {
-                bool in_final = false;
-                for (int fi = 0; fi < nfin; ++fi) in_final = in_final || fin[fi] == i;
-                if (!in_final) tmin[i] = std::numeric_limits<float>::max();
-            }
-        }
-    }
-    int best_ci = 0;
-    for (int ci = 1; ci < ncand; ++ci)
-        if (tmin[ci] < tmin[best_ci] * (best_ci == 0 ? 0.98f : 1.0f)) best_ci = ci;  // a challenger must win by 2 % to displace the default
-    if (std::getenv("CVS_TUNE_VERBOSE")) {
-        std::fprintf(stderr, "[cvsteer] tune kind %d variant %d %dx%d:", h->kind, variant, a.rows, a.cols);
-        for (int ci = 0; ci < ncand; ++ci) {
-            std::fprintf(stderr, " (order %d, xcd %d, strip %d, split %d)", list[ci].order, list[ci].xw, list[ci].strip, list[ci].split);
-            if (tmin[ci] < 1e30f) std::fprintf(stderr, " %.4f ms", tmin[ci]);
-            else std::fprintf(stderr, " out after the short bursts");
-        }
-        std::fprintf(stderr, " -> candidate %d\n", best_ci);
-    }
-    {
-        std::lock_guard<std::mutex> lock(g_tune_mutex);
-        TuneEntry& e = g_tune[key];
-        e.order = list[best_ci].order;
-        e.xw = list[best_ci].xw;
-        e.strip_rows = list[best_ci].strip;
-        e.g4_split = list[best_ci].split;
-    }
-    apply(list[best_ci]);
-    return CVS_OK;
-}
-
-void note_launch(cvs_handle h, const BasisArgs& a)
-{
-    h->last.block_order = a.block_order;
-    h->last.xcd_weights = a.xcd_even * 100 + a.xcd_odd;
-    h->last.strip_rows = a.strip_rows;
-    h->last.nt_stores = a.nt_stores;
-    h->last.g4_split = a.g4_split;
-}
-
-// Overlapped host path.  The reference's callers hand over HOST images and expect HOST results
-// (test/test.cpp:73,85-90; example/steer.cpp:73-104).  Done naively that is upload, kernel, download, one after the
-// other: 64 MiB up + 128 MiB down at 56 GB/s each = 3.6 ms around a 0.11 ms kernel.  The host link is full duplex, so
-// the image is cut into row bands and three things run at once: the upload of band b+1 (this thread, stream s_up), the
-// filtering of band b (the handle's stream; cvs_setup_rows machinery, values bit-identical to a whole-image launch)
-// and the download of band b-1's outputs (a second host thread, stream s_down).  Host memory may be pageable: the
-// runtime pins it on the fly (tools/pcie_probe.hip: pageable = pinned = 56 GB/s per direction; both directions from
-// two threads 2.66 ms instead of 3.58).  What remains is max(upload, download) plus one band of latency.
-int host_pipeline(cvs_handle h, Call& c, BasisArgs& a, float* scr)
-{
-    const int W = h->width;
-    int nbands = 8;
-    if (const char* e = std::getenv("CVS_HOST_BANDS")) nbands = std::max(1, std::min(64, std::atoi(e)));  // tuning aid
-    int per = (a.rows + nbands - 1) / nbands;
-    per = std::max(a.strip_rows, (per + a.strip_rows - 1) / a.strip_rows * a.strip_rows);
-    nbands = (a.rows + per - 1) / per;
-    if (!h->s_up) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking));
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->s_down, hipStreamNonBlocking));
-    }
-    while ((int)h->band_ev.size() < 2 * nbands + 1) {
-        hipEvent_t e;
-        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->band_ev.push_back(e);
-    }
-    hipEvent_t* up = h->band_ev.data();
-    hipEvent_t* comp = h->band_ev.data() + nbands;
-    // the copy streams start behind whatever the handle's stream still has queued on these buffers
-    hipEvent_t start = h->band_ev[2 * nbands];
-    HIP_TRY(h, hipEventRecord(start, h->stream));
-    HIP_TRY(h, hipStreamWaitEvent(h->s_up, start, 0));
-    HIP_TRY(h, hipStreamWaitEvent(h->s_down, start, 0));
-    // plain order, default weights: the launch-order tuner works on whole resident images, not on bands
-    a.block_order = 0;
-    a.xcd_even = 4;
-    a.xcd_odd = 3;
-    note_launch(h, a);
-
-    // download thread: band b's outputs leave as soon as its kernel has finished
-    std::mutex mu;
-    std::condition_variable cv;
-    int enqueued = 0;
-    bool abort_dl = false;
-    hipError_t dl_err = hipSuccess;
-    const std::vector<Pending> outs = c.outs;
-    const int rows = a.rows, device = h->device;
-    hipStream_t s_down = h->s_down;
-    std::thread downloader;
-    if (!outs.empty()) {
-        downloader = std::thread([&, rows, device, s_down, per, nbands] {
-            hipError_t e = hipSetDevice(device);
-            for (int b = 0; b < nbands && e == hipSuccess; ++b) {
-                {
-                    std::unique_lock<std::mutex> lock(mu);
-                    cv.wait(lock, [&] { return enqueued > b || abort_dl; });
-                    if (abort_dl) break;
-                }
-                const int lo = b * per, hi = std::min(rows, lo + per);
-                e = hipStreamWaitEvent(s_down, comp[b], 0);
-                for (const Pending& o : outs) {
-                    if (e != hipSuccess) break;
-                    if (o.host->step == o.pitch * sizeof(float) && o.host->step == (size_t)o.host->cols * sizeof(float)) {  // dense on both sides
-                        e = hipMemcpyAsync(reinterpret_cast<char*>(o.host->data) + (size_t)lo * o.host->step, o.dev + (size_t)lo * o.pitch,
-                                           (size_t)(hi - lo) * o.host->step, hipMemcpyDeviceToHost, s_down);
-                        continue;
-                    }
-                    e = copy_rows(reinterpret_cast<char*>(o.host->data) + (size_t)lo * o.host->step, o.host->step, o.dev + (size_t)lo * o.pitch,
-                                         o.pitch * sizeof(float), (size_t)o.host->cols * sizeof(float), hi - lo, hipMemcpyDeviceToHost, s_down);
-                }
-            }
-            if (e == hipSuccess) e = hipStreamSynchronize(s_down);
-            dl_err = e;
-        });
-    }
-    auto stop = [&](int rc) {
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            abort_dl = true;
-        }
-        cv.notify_all();
-        if (downloader.joinable()) downloader.join();
-        return rc;
-    };
-    const cvs_plane* img = c.deferred_image;  // nullptr: the image is already on the device, only outputs travel
-    int up_to = 0;                            // rows of the image uploaded so far
-    for (int b = 0; b < nbands; ++b) {
-        const int lo = b * per, hi = std::min(a.rows, lo + per);
-        if (img) {
-            const int need = std::min(a.rows, hi + W);  // the band's kernel reads W rows beyond its last output row
-            if (need > up_to) {
-                hipError_t e;
-                if (c.deferred_u8) {
-                    e = copy_rows(c.deferred_u8 + (size_t)up_to * c.deferred_u8_pitch, c.deferred_u8_pitch,
-                                         reinterpret_cast<const char*>(img->data) + (size_t)up_to * img->step, img->step, (size_t)img->cols, need - up_to,
-                                         hipMemcpyHostToDevice, h->s_up);
-                    if (e == hipSuccess)
-                        e = launch_u8_to_f32(c.deferred_u8 + (size_t)up_to * c.deferred_u8_pitch, c.deferred_u8_pitch, need - up_to, img->cols,
-                                             const_cast<float*>(a.in) + (size_t)up_to * a.in_pitch, a.in_pitch, h->s_up);
-                } else {
-                    e = copy_rows(const_cast<float*>(a.in) + (size_t)up_to * a.in_pitch, a.in_pitch * sizeof(float),
-                                         reinterpret_cast<const char*>(img->data) + (size_t)up_to * img->step, img->step, (size_t)img->cols * sizeof(float),
-                                         need - up_to, hipMemcpyHostToDevice, h->s_up);
-                }
-                if (e != hipSuccess) return stop(fail_hip(h, e, "host pipeline upload"));
-                up_to = need;
-            }
-            hipError_t e = hipEventRecord(up[b], h->s_up);
-            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, up[b], 0);
-            if (e != hipSuccess) return stop(fail_hip(h, e, "host pipeline ordering"));
-        }
-        BasisArgs ab = a;
-        ab.out_row_lo = lo;
-        ab.out_row_hi = hi;
-        hipError_t e = launch_basis(h->kind, h->width, h->taps, ab, scr, h->stream);
-        if (e == hipSuccess) e = hipEventRecord(comp[b], h->stream);
-        if (e != hipSuccess) return stop(fail_hip(h, e, "host pipeline launch"));
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            enqueued = b + 1;
-        }
-        cv.notify_all();
-    }
-    if (downloader.joinable()) downloader.join();
-    if (dl_err != hipSuccess) return fail_hip(h, dl_err, "host pipeline download");
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    c.outs.clear();  // nothing left for finish() to copy
-    return CVS_OK;
-}
 
 int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, float theta, const cvs_plane* g,
              const cvs_plane* hq, const cvs_plane* const* pipe_outs = nullptr, int nframes = 1, int frame = 0,
@@ -989,7 +63,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     if (pipe_outs)
         for (int k = 0; k < 8; ++k)
             if (pipe_outs[k]) max_pitch = std::max(max_pitch, pipe_outs[k]->step / sizeof(float));
-    if (state_interleaved(h, image->rows, pitch)) max_pitch = std::max(max_pitch, pitch * (size_t)std::max(h->nb, 5));
+    if (state_interleaved(h, image->rows, pitch)) max_pitch = std::max(max_pitch, pitch * (size_t)(h->kind == CVS_KIND_G4 ? 6 : 7));
     const bool may_generic = basis_may_need_scratch(h->kind, h->width, h->taps, image->rows, image->cols, max_pitch);
     const size_t scratch = may_generic ? round_up(basis_scratch_elems(h->kind, h->width, image->rows, pitch), 64) : 0;
     Call c;
@@ -1029,13 +103,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     a.in_u8 = c.u8_direct ? 1 : 0;
     a.rows = image->rows;
     a.cols = image->cols;
-    a.basis = state_plane(h, 0);
-    a.pitch = h->pitch;
-    a.plane_stride = h->plane_stride;
-    a.orient = ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G2) ? state_plane(h, h->nb) : nullptr;
-    a.orient_pitch = h->opitch;
-    a.orient_stride = h->ostride;
-    a.state_bytes = h->frame_stride * sizeof(float);
+    fill_state_args(h, a, (flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G2);
     a.atan_mode = h->atan_mode;
     // a different input pointer than last time = a stream of fresh images (not resident in the Infinity Cache);
     // the pipeline variants keep the taller strips (tools/shape_sweep.py)
@@ -1081,10 +149,13 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     {
         const bool orient_k = a.orient != nullptr;
         const int variant = (orient_k ? 1 : 0) | (steer ? 2 : 0) | (a.pipe ? 4 : 0) | (a.no_state ? 8 : 0);
-        if ((rc = tune_block_order(h, a, scr, variant, fresh))) return rc;
+        TuneToken tok;
+        if ((rc = tune_begin(h, a, variant, fresh, tok))) return rc;
+        note_launch(h, a);
+        const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, scr, h->stream);
+        tune_end(h, tok);
+        HIP_TRY(h, le);
     }
-    note_launch(h, a);
-    HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, scr, h->stream));
     if ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G4) {  // extension: one per-pixel pass over the 11 planes
         PointArgs pa{};
         pa.rows = a.rows;
@@ -1111,75 +182,6 @@ int need_state(cvs_handle h, bool orient)
     if (!h) return CVS_E_BADARG;
     if (!h->have_basis) return fail(h, CVS_E_STATE, "no setup yet");
     if (orient && !h->have_orient) return fail(h, CVS_E_STATE, "orientation state not computed (setup without CVS_SETUP_ORIENT)");
-    return CVS_OK;
-}
-
-// Frame batches (cvs_pipeline_batch with state kept; BASELINE config 4), opt-in with CVS_OPT_PLACEMENT_SEARCH = 1: which
-// plain block the batch state lives in decides the launch's speed by 7-9 % (tools/r3_probe.py c4modes: eight blocks of 3.2 GB
-// allocated one after the other in one process, the same frames and outputs -- blocks 0 and 5..7 run the launch at 0.73 of
-// the HBM roofline, blocks 1..4 at 0.67-0.68, the same in every process: runs of the VRAM allocator again, see cvs_state.cpp).
-// The per-plane windows of cvs_state.cpp do not fit a batch (hundreds of small planes), but the question can be put to the
-// launch itself: up to kCand plain candidate blocks are allocated, the REAL launch is timed on each (it rewrites the same
-// outputs with the same values), the fastest block is kept and the others are freed.  Once per (handle, block size), never
-// under stream capture, bounded by the free memory; results do not depend on it.
-int batch_block_search(cvs_handle h, BasisArgs& a)
-{
-    constexpr int kCand = 6;
-    const size_t elems = h->state_elems, bytes = elems * sizeof(float);
-    if (h->placement != 1 || h->sb.vmm || a.no_state || h->batch_searched_elems == elems || bytes < ((size_t)256 << 20)) return CVS_OK;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return CVS_OK;
-    h->batch_searched_elems = elems;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return CVS_OK;
-    int ncand = 1;
-    while (ncand < kCand && (size_t)ncand * bytes + ((size_t)8 << 30) < free_b) ++ncand;   // candidate 0 is the block the handle has
-    if (ncand < 2) return CVS_OK;
-    if (!h->ev0) {   // before anything is allocated: a failure here leaves nothing behind
-        HIP_TRY(h, hipEventCreate(&h->ev0));
-        HIP_TRY(h, hipEventCreate(&h->ev1));
-    }
-    const auto t_start = std::chrono::steady_clock::now();
-    std::vector<StateBlock> cand(ncand);
-    cand[0] = h->sb;
-    int have = 1;
-    for (; have < ncand; ++have)
-        if (state_block_alloc_plain(h->device, elems, cand[have]) != hipSuccess) { (void)hipGetLastError(); break; }
-    const ptrdiff_t orient_off = a.orient - a.basis;
-    std::vector<float> t(have, std::numeric_limits<float>::max());
-    hipError_t e = hipSuccess;
-    for (int round = 0; round < 2 && e == hipSuccess; ++round)          // round 0 = first touch of the fresh blocks
-        for (int c = 0; c < have && e == hipSuccess; ++c) {
-            a.basis = cand[c].base;
-            a.orient = cand[c].base + orient_off;
-            e = hipEventRecord(h->ev0, h->stream);
-            for (int k = 0; k < 2 && e == hipSuccess; ++k) e = launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream);
-            if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
-            if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
-            float ms = 0.f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev0, h->ev1);
-            if (round > 0 && e == hipSuccess) t[c] = ms / 2;
-        }
-    int best = 0;
-    if (e == hipSuccess)
-        for (int c = 1; c < have; ++c)
-            if (t[c] < t[best] * 0.98f) best = c;     // a challenger must win by 2 %
-    if (std::getenv("CVS_TUNE_VERBOSE")) {
-        std::fprintf(stderr, "[cvsteer] batch block search, %d candidates of %zu MiB (ms per launch):", have, bytes >> 20);
-        for (int c = 0; c < have; ++c) std::fprintf(stderr, " %.4f", t[c]);
-        std::fprintf(stderr, " -> candidate %d\n", best);
-    }
-    (void)hipStreamSynchronize(h->stream);
-    for (int c = 0; c < have; ++c)
-        if (c != best) state_block_free(cand[c]);
-    h->sb = cand[best];
-    h->state = h->sb.base;
-    h->state_elems = h->sb.elems;
-    a.basis = h->state;
-    a.orient = h->state + orient_off;
-    h->window_found = best != 0;
-    h->probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    if (e != hipSuccess) return fail_hip(h, e, "batch block search");
     return CVS_OK;
 }
 
@@ -1319,20 +321,7 @@ int cvs_destroy(cvs_handle h)
 
 int cvs_release_cached_memory(void)
 {
-    std::vector<StateBlock> blocks;
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        blocks.swap(g_pool);
-        g_no_window.clear();  // the next handle of a large geometry probes again
-    }
-    int cur = 0;
-    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
-    for (StateBlock& b : blocks) {
-        (void)hipSetDevice(b.device);
-        state_block_free(b);
-    }
-    if (have_cur) (void)hipSetDevice(cur);
-    (void)hipGetLastError();
+    pool_release_all();
     return CVS_OK;
 }
 
@@ -1405,7 +394,7 @@ int cvs_set_option(cvs_handle h, int option, int value)
             h->xcd_weights = value;
             return CVS_OK;
         case CVS_OPT_BLOCK_ORDER:
-            if (value < -1 || value > 1000000) return fail(h, CVS_E_BADARG, "block order");
+            if (value < -1 || (value > 1000000 && value != kOrderDynamic)) return fail(h, CVS_E_BADARG, "block order");
             h->block_order = value;
             return CVS_OK;
         case CVS_OPT_HOST_OVERLAP:
@@ -1527,7 +516,7 @@ int cvs_state_plane(cvs_handle h, int which, cvs_plane* view)
     view->data = state_plane(h, idx);
     view->rows = h->rows;
     view->cols = h->cols;
-    view->step = (idx < h->nb ? h->pitch : h->opitch) * sizeof(float);
+    view->step = state_group(h, idx).pitch * sizeof(float);
     view->mem = CVS_MEM_DEVICE;
     return CVS_OK;
 }
@@ -1574,8 +563,9 @@ int cvs_steer_point(cvs_handle h, int x, int y, float theta, float out[5])
     a.c2t = (float)std::cos((double)theta * 2.0);  // G2.cpp:132: std::cos(theta * 2.0), double argument
     a.s2t = (float)std::sin((double)theta * 2.0);
     if (!h->point_out) HIP_TRY(h, hipMalloc(&h->point_out, 8 * sizeof(float)));
-    HIP_TRY(h, launch_steer_point(state_plane(h, 0), h->plane_stride, (size_t)y * h->pitch + x, h->have_orient ? state_plane(h, h->nb) : nullptr,
-                                  h->ostride, (size_t)y * h->opitch + x, a, h->point_out, h->stream));
+    const cvs_context::PlaneGroup &gb = state_group(h, 0), &go = state_group(h, h->nb);
+    HIP_TRY(h, launch_steer_point(state_plane(h, 0), gb.stride, (size_t)y * gb.pitch + x, h->have_orient ? state_plane(h, h->nb) : nullptr,
+                                  go.stride, (size_t)y * go.pitch + x, a, h->point_out, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out, h->point_out, 5 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CVS_OK;
@@ -1826,13 +816,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
             a.out_mask = 0;
         }
     }
-    a.basis = h->state;
-    a.pitch = h->pitch;
-    a.plane_stride = h->plane_stride;
-    a.orient = h->state + h->orient_off;
-    a.orient_pitch = h->opitch;
-    a.orient_stride = h->ostride;
-    a.state_bytes = h->frame_stride * sizeof(float);
+    fill_state_args(h, a, true);   // frame 0 (cur_frame was reset above); frame z adds z * frame_stride in the kernel
     a.atan_mode = h->atan_mode;
     a.strip_rows = default_strip_rows(h, rows, cols);
     a.nt_stores = use_nt_stores(h, (size_t)rows * cols * n);
@@ -1852,10 +836,13 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     if (!a.no_state && n >= 4 && h->strip_rows <= 0) a.strip_rows = 2 * (2 * h->width + 1) - 2 * h->width;
     if (const char* e = std::getenv("CVS_BATCH_WAYS")) a.z_ways = std::max(1, std::min(n, std::atoi(e)));
     a.frame_stride = h->frame_stride;
-    if ((rc = tune_block_order(h, a, nullptr, 16 | 1 | 4 | (a.no_state ? 8 : 0)))) return rc;
     if ((rc = batch_block_search(h, a))) return rc;   // opt-in (CVS_OPT_PLACEMENT_SEARCH = 1), once per block size
+    TuneToken tok;
+    if ((rc = tune_begin(h, a, 16 | 1 | 4 | (a.no_state ? 8 : 0), false, tok))) return rc;
     note_launch(h, a);
-    HIP_TRY(h, launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream));
+    const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream);
+    tune_end(h, tok);
+    HIP_TRY(h, le);
     h->have_basis = h->have_orient = h->persist != 0;
     return CVS_OK;
 }

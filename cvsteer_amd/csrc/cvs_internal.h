@@ -13,6 +13,7 @@ constexpr int kMaxWidth = 32;           // generic path: up to 65 taps
 constexpr int kMaxTaps = 2 * kMaxWidth + 1;
 constexpr int kMaxBasis = 11;
 constexpr int kOrderXcdColumns = 1000000;  // BasisArgs::block_order: every XCD owns a contiguous range of column blocks
+constexpr int kOrderDynamic = 2000000;     // BasisArgs::block_order: persistent launch, tiles taken from per-XCD queues (tile_ctr)
 
 struct PlaneRef {
     float* p;       // nullptr = not requested
@@ -33,9 +34,12 @@ struct BasisArgs {
     int in_u8;            // 1 = the image is 8-bit: the strip kernels read bytes and widen them in registers (buffer_load_ubyte +
                           // v_cvt_f32_ubyte0), exactly cv::Mat1f(const Mat&) of test/test.cpp:85 -- no f32 copy of the image exists
     int rows, cols;
-    float* basis;         // nb planes, plane p at basis + p*plane_stride
-    size_t pitch;         // row pitch of every state plane
+    float* basis;         // first group of basis planes (G2: all 7; G4: g4a..g4e), plane p at basis + p*plane_stride
+    size_t pitch;         // row pitch of the planes of that group
     size_t plane_stride;
+    float* basis2;        // G4: second group of basis planes (h4a..h4f), plane 5+q at basis2 + q*plane_stride2, row pitch pitch2.
+    size_t pitch2;        // The half banks of the pair launch write one group each; with row-interleaved groups each of them
+    size_t plane_stride2; // streams a dense linear sweep (cvs_handle.cpp ensure_state).  G2: unused.
     float* orient;        // c1,c2,c3,theta,strength at orient + i*orient_stride (row pitch orient_pitch), or nullptr
     size_t orient_pitch;  // the state is laid out as two groups of planes, basis and orientation, each either planar
     size_t orient_stride; // (pitch = row length, stride = plane size) or ROW-INTERLEAVED (stride = row length, pitch = planes x row
@@ -57,6 +61,11 @@ struct BasisArgs {
     int block_order;      // 0 = row-major grid, 1 = row-major weighted per XCD, T >= 2 = groups of T bands walked column by column
     int xcd_even, xcd_odd; // block_order 1: tiles per period for the even / odd XCDs (see basis_body)
     int grid_x, grid_y;   // filled by the launcher
+    int dyn_nz;           // dynamic order: planes of tiles (frames of a batch / half banks of the G4 pair); filled by the launcher
+    unsigned* tile_ctr;   // dynamic order: the handle's tile queues in device memory -- two sets, used alternately (cvs_kernels_basis.hip);
+                          // the API layer passes the slot, the launcher picks the set
+    unsigned* tile_ctr_next;  // the other set, zeroed by this launch (filled by the launcher)
+    int* tile_parity;     // host: which set the next dynamic launch of this state block takes (StateBlock::ctr_parity)
     // fused caller pipeline (needs orient): g2,h2,e,mag,phase,edges,dark,bright at theta_dom
     int pipe;             // 1 = run the pipeline epilogue
     int no_state;         // pipeline only: 1 = do not persist basis / orientation planes (outputs only)
@@ -92,6 +101,13 @@ struct BasisArgs {
     // 100 MHz real-time stamps; never read by the product, nullptr in normal builds
     unsigned long long* diag;
 };
+
+// basis plane p of a launch, whatever group it is in
+inline PlaneRef basis_plane_ref(const BasisArgs& a, int kind, int p)
+{
+    if (kind == 4 && p >= 5) return {a.basis2 + (size_t)(p - 5) * a.plane_stride2, a.pitch2};
+    return {a.basis + (size_t)p * a.plane_stride, a.pitch};
+}
 
 // taps[i] = the handle's i-th tap vector (member order), 2*width+1 floats each
 hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,
@@ -173,6 +189,10 @@ struct StateBlock {
     // a PARKED block (cvs_destroy / a handle that changed geometry): recorded on the stream that last used the block; whoever
     // takes the block over makes its own stream wait for it -- the device is never drained for a destroy.  nullptr = idle.
     hipEvent_t ready = nullptr;
+    // tile queues of the dynamic launch order (two sets of 8 counters + a flag, 1 KiB each): a slot of a per-device slab, taken
+    // with the block and returned with it -- so that whoever uses the block next has waited for `ready` first
+    unsigned* tile_ctr = nullptr;
+    int ctr_parity = 0;        // the set the next dynamic launch uses (that launch zeroes the other one)
 };
 hipError_t state_block_alloc_plain(int device, size_t elems, StateBlock& b);
 hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b);

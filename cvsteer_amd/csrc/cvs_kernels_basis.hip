@@ -180,27 +180,51 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// the kernel body: one wave filters one strip.  `line` = this wave's LDS line (64 + 2W + 4 floats),
-// `zframe` = frame index of a batched launch.
-// WPB = waves (adjacent 64-column strips of one row band) per workgroup.  Always 4: 8-wave workgroups were built
-// and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones; one- and
-// two-wave workgroups fill the wave slots better (no slot waits for the slowest of four) but lose 3-12 % on the G2 legs and
-// 7 % on fresh images (profiles/r03_wpb_probe.txt): the four strips of a workgroup write 1 KiB of every plane row from one CU.
-template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB, bool U8 = false>
-__device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe)
-{
-    constexpr unsigned EB = U8 ? 1u : 4u;   // bytes per input sample
-    constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
-    constexpr int LW = 64 + 2 * W;
+// ---------------------------------------------------------------------------------------
+// Which tile does this workgroup filter?  STATIC orders: computed from blockIdx (static_tile).  DYNAMIC order (block_order =
+// kOrderDynamic, round 4): the workgroup ASKS -- eight queues in device memory, one per XCD; queue q holds the tiles q, q + 8,
+// q + 16, ... of the row-major order (what the dispatcher's round-robin would have given XCD q anyway), a workgroup takes the
+// next tile of its own XCD's queue and, when that is empty, of the queues of the others.  The grid is somewhat larger than
+// the number of tiles: the dispatcher deals every XCD the same number of workgroups, so an XCD that is faster on this box,
+// with this kernel, at this moment works off its own queue early and then spends its surplus workgroups on the tiles of the
+// slower ones, whose surplus workgroups find nothing and leave.  Nothing about the speed of an XCD is assumed (rounds 2-3
+// dealt fixed even : odd shares, which helped on some boxes and hurt on others).  Cost: one returning atomic (~1 us) and one
+// barrier at the START of a workgroup; the body is the same code as for the static orders, the waves still never wait for
+// each other.
+// Two sets of queues per handle, used alternately: a launch takes its tickets from one set and zeroes the OTHER one (which
+// the previous launch of the handle used; launches of a handle are ordered on its stream), so every launch finds its set at
+// zero without a host-side step, a reset kernel or a "last one out" protocol inside the launch.  (Under stream capture the
+// launcher puts a memset node in front instead: a graph replays the same set every time.)
+// ---------------------------------------------------------------------------------------
+constexpr int kQueueStride = 16;    // unsigned ints between two queue heads (64 B); head q at [q * 16], "all queues empty" flag at [8 * 16]
+constexpr int kQueueSetUints = 256; // one set of queues: 1 KiB; a handle's slot holds two
 
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+__device__ __forceinline__ int take_tile(const BasisArgs& a, int q0, int ntiles)
+{
+    unsigned k = __hip_atomic_fetch_add(a.tile_ctr + q0 * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k < (1u << 27) && (int)k * 8 + q0 < ntiles) return (int)k * 8 + q0;
+    // own queue empty.  Has somebody already found ALL of them empty?  (one load instead of seven more atomics for most
+    // of the surplus workgroups)
+    if (__hip_atomic_load(a.tile_ctr + 8 * kQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
+    for (int i = 1; i < 8; ++i) {   // help the others
+        const int q = (q0 + i) & 7;
+        k = __hip_atomic_fetch_add(a.tile_ctr + q * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k < (1u << 27) && (int)k * 8 + q < ntiles) return (int)k * 8 + q;
+    }
+    __hip_atomic_store(a.tile_ctr + 8 * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return -1;
+}
+
+// static orders: the tile of this workgroup; false = none (padding workgroups of the weighted / XCD-column grids)
+__device__ __forceinline__ bool static_tile(const BasisArgs& a, int& bx, int& by)
+{
     // workgroup -> (column block bx, row band by).  block_order = 0: plain row-major grid.  block_order =
     // T >= 2: 1-D grid, groups of T bands walked column by column, so T vertically adjacent bands are in
     // flight together (T >= grid_y: column-major).  Which order the memory system prefers depends on the
     // kernel variant (how many planes it writes) and on the box; the API layer picks it by timing the
     // candidates once per (variant, shape) -- see autotune in cvs_api.cpp.
-    int bx = blockIdx.x, by = blockIdx.y;
+    bx = blockIdx.x;
+    by = blockIdx.y;
     if (a.block_order == 1) {
         // XCD-weighted row-major order.  Workgroup b runs on XCD b % 8 (observed on every launch, tools/xcd_map.py;
         // only speed depends on it), every XCD gets the same number of workgroups, and the XCDs are not equally
@@ -215,7 +239,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
         const int k = r / cl, j = r - k * cl;
         const int pos = j < cmin ? j * 8 + label : cmin * 8 + (j - cmin) * 4 + (label >> 1);
         const int tl = k * 4 * (ce + co) + pos;
-        if (tl >= a.grid_x * a.grid_y) return;
+        if (tl >= a.grid_x * a.grid_y) return false;
         by = tl / a.grid_x;
         bx = tl - by * a.grid_x;
     } else if (a.block_order == kOrderXcdColumns) {
@@ -230,26 +254,66 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
         if (a.xcd_steal > 0) {
             const int n_own = cpx * a.grid_y;
             if (xcd & 1) {
-                if (k >= n_own - a.xcd_steal) return;
+                if (k >= n_own - a.xcd_steal) return false;
             } else if (k >= n_own) {
-                if (k - n_own >= a.xcd_steal) return;
+                if (k - n_own >= a.xcd_steal) return false;
                 owner = xcd + 1;
                 k = (n_own - a.xcd_steal) + (k - n_own);
             }
         }
         by = k / cpx;
         bx = owner * cpx + (k - by * cpx);
-        if (bx >= a.grid_x || by >= a.grid_y) return;
+        if (bx >= a.grid_x || by >= a.grid_y) return false;
     } else if (a.block_order >= 2) {
         const int T = min(a.block_order, a.grid_y);
         const int per = T * a.grid_x, g = blockIdx.x / per, r = blockIdx.x % per;
         const int tg = min(T, a.grid_y - g * T);  // bands in this (possibly last, shorter) group
         by = g * T + r % tg;
         bx = r / tg;
-        if (bx >= a.grid_x) return;
+        if (bx >= a.grid_x) return false;
     }
+    return true;
+}
+
+// the tile of this workgroup: (bx, by, z); false = none.  s_tile: one int of LDS shared by the workgroup.
+__device__ __forceinline__ bool pick_tile(const BasisArgs& a, int* s_tile, int& bx, int& by, unsigned& z)
+{
+    z = blockIdx.z;
+    if (a.block_order != kOrderDynamic) return static_tile(a, bx, by);
+    const int per_z = a.grid_x * a.grid_y, ntiles = per_z * a.dyn_nz;
+    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + 9)   // the set the NEXT launch of this handle will use
+        __hip_atomic_store(a.tile_ctr_next + (threadIdx.x - 64) * kQueueStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        const int q0 = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);   // HW_REG_XCC_ID: the XCD this workgroup runs on
+        *s_tile = take_tile(a, q0, ntiles);
+    }
+    __syncthreads();
+    const int tl = __builtin_amdgcn_readfirstlane(*s_tile);   // the same in every lane: keep it (and bx, by, z) in scalar registers
+    if (tl < 0) return false;
+    z = (unsigned)(tl / per_z);
+    const int r = tl - (int)z * per_z;
+    by = r / a.grid_x;
+    bx = r - by * a.grid_x;
+    return true;
+}
+
+// the kernel body: one wave filters one strip.  `line` = this wave's LDS line (64 + 2W + 4 floats),
+// `zframe` = frame index of a batched launch.
+// WPB = waves (adjacent 64-column strips of one row band) per workgroup.  Always 4: 8-wave workgroups were built
+// and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones; one- and
+// two-wave workgroups fill the wave slots better (no slot waits for the slowest of four) but lose 3-12 % on the G2 legs and
+// 7 % on fresh images (profiles/r03_wpb_probe.txt): the four strips of a workgroup write 1 KiB of every plane row from one CU.
+template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB, bool U8 = false>
+__device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe, const int bx, const int by)
+{
+    constexpr unsigned EB = U8 ? 1u : 4u;   // bytes per input sample
+    constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
+    constexpr int LW = 64 + 2 * W;
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
     const int x0 = (bx * WPB + wv) * 64;
-    if (x0 >= a.cols) return;  // wave-uniform; waves of a workgroup never rendezvous
+    if (x0 >= a.cols) return;  // wave-uniform; between two tiles the waves of a workgroup do not wait for each other
 #ifdef CVS_DIAG_STAMPS
     unsigned long long* stamp = a.diag ? a.diag + ((size_t)(by * a.grid_x + bx) * WPB + wv) * 4 : nullptr;
     [[maybe_unused]] bool stamped_first = false;
@@ -286,6 +350,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     const float* in_p = a.in;
     size_t in_pitch = a.in_pitch;
     float* basis_p = a.basis;
+    [[maybe_unused]] float* basis2_p = a.basis2;
     float* orient_p = a.orient;
     PlaneRef pipe_out[8];
     [[maybe_unused]] rsrc_t r_out = plane_rsrc(nullptr, 0);
@@ -328,6 +393,13 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // larger images use one resource per plane.
     const rsrc_t r_state = plane_rsrc(basis_p, a.state_bytes);
     const unsigned pstride_b = (unsigned)(a.plane_stride * sizeof(float));
+    // G4: the planes h4a..h4f (state planes 5..10) are a second group with a row pitch and plane stride of its own
+    constexpr int SPLIT = B::KIND == 4 ? 5 : 1 << 20;                       // first plane of the second group
+    constexpr bool ANY_A = B::PLANE0 < SPLIT, ANY_B = B::PLANE0 + NB > SPLIT;
+    [[maybe_unused]] const unsigned pitch2_b = (unsigned)(a.pitch2 * sizeof(float));
+    [[maybe_unused]] const unsigned pstride2_b = (unsigned)(a.plane_stride2 * sizeof(float));
+    [[maybe_unused]] const unsigned off2_b = ANY_B ? (unsigned)((size_t)(basis2_p - basis_p) * sizeof(float)) : 0u;   // single-resource form only
+    [[maybe_unused]] const size_t plane2_bytes = (size_t)(a.rows - rbase) * a.pitch2 * sizeof(float);
     // the orientation planes are a group of their own (own row pitch, own plane stride: ensure_state in cvs_api.cpp)
     [[maybe_unused]] const unsigned opitch_b = (unsigned)(a.orient_pitch * sizeof(float));
     [[maybe_unused]] const unsigned ostride_b = (unsigned)(a.orient_stride * sizeof(float));
@@ -377,8 +449,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     [[maybe_unused]] unsigned xbp[NB];
     if constexpr (ONE && VOFF) {
 #pragma unroll
-        for (int p = 0; p < NB; ++p) xbp[p] = xb + (unsigned)(B::PLANE0 + p) * pstride_b;   // kLaneOff + offset stays out of range
+        for (int p = 0; p < NB; ++p)   // kLaneOff + offset stays out of range
+            xbp[p] = xb + (B::PLANE0 + p >= SPLIT ? off2_b + (unsigned)(B::PLANE0 + p - SPLIT) * pstride2_b : (unsigned)(B::PLANE0 + p) * pstride_b);
     }
+    [[maybe_unused]] unsigned orow2_run = ((unsigned)(y0 - rbase) - (unsigned)(2 * W)) * pitch2_b;   // row offset in the second group
 
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -457,14 +531,18 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----
             // which output row this is, and whether the strip owns it (wave-uniform)
             unsigned oi = 0, orow_s = 0;
-            [[maybe_unused]] unsigned orow_o_s = 0;
+            [[maybe_unused]] unsigned orow_o_s = 0, orow2_s = 0;
             bool row_ok;
             [[maybe_unused]] int yout = 0;
             if constexpr (SRED) {
                 oi = oi_run;
                 orow_s = orow_run;
                 ++oi_run;
-                orow_run += pitch_b;
+                if constexpr (ANY_A) orow_run += pitch_b;
+                if constexpr (ANY_B) {
+                    orow2_s = orow2_run;
+                    orow2_run += pitch2_b;
+                }
                 if constexpr ((FLAGS & F_ORIENT) != 0 && (FLAGS & F_NOSTATE) == 0) {
                     orow_o_s = orow_o_run;
                     orow_o_run += opitch_b;
@@ -504,22 +582,29 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
                 // output row relative to the plane pointers, and its byte offset in a state plane
                 unsigned yo, orow;
-                [[maybe_unused]] unsigned orow_o = 0;
+                [[maybe_unused]] unsigned orow_o = 0, orow2 = 0;
                 if constexpr (SRED) {
                     yo = (unsigned)(y0 - rbase) + oi;
                     orow = orow_s;
                     orow_o = orow_o_s;
+                    orow2 = orow2_s;
                 } else {
                     yo = row_ok ? (unsigned)(yout - rbase) : 0u;
                     orow = yo * pitch_b;
+                    if constexpr (ANY_B) orow2 = yo * pitch2_b;
                     if constexpr ((FLAGS & F_ORIENT) != 0 && (FLAGS & F_NOSTATE) == 0) orow_o = yo * opitch_b;
                 }
                 if constexpr ((FLAGS & F_NOSTATE) == 0) {
 #pragma unroll
-                    for (int p = 0; p < NB; ++p)
-                        if constexpr (ONE && VOFF) bst<STREAM>(r_state, xbp[p], orow, b[p]);
-                        else if constexpr (ONE) bst<STREAM>(r_state, xbr, orow + (unsigned)(B::PLANE0 + p) * pstride_b, b[p]);
-                        else bst<STREAM>(plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orow, b[p]);
+                    for (int p = 0; p < NB; ++p) {
+                        const bool second = B::PLANE0 + p >= SPLIT;   // compile-time per plane
+                        const unsigned orw = second ? orow2 : orow;
+                        if constexpr (ONE && VOFF) bst<STREAM>(r_state, xbp[p], orw, b[p]);
+                        else if constexpr (ONE)
+                            bst<STREAM>(r_state, xbr, orw + (second ? off2_b + (unsigned)(B::PLANE0 + p - SPLIT) * pstride2_b : (unsigned)(B::PLANE0 + p) * pstride_b), b[p]);
+                        else if (second) bst<STREAM>(plane_rsrc(basis2_p + (size_t)(B::PLANE0 + p - SPLIT) * a.plane_stride2, plane2_bytes), xbr, orw, b[p]);
+                        else bst<STREAM>(plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orw, b[p]);
+                    }
                 }
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
                     // stateless pipeline: the oriented energy (and with it C1) is evaluated only when asked for
@@ -611,13 +696,16 @@ template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int 
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
     __shared__ float lds[WPB][64 + 2 * B::W + 4];
+    __shared__ int s_tile;
     // Frame batches with state kept: the frames are dispatched dealt from z_ways equal parts of the batch in turn (0, n/2, 1,
     // n/2 + 1, ... for two), so that the frames in flight together -- about ten of 1080p -- have their state planes, inputs and
     // outputs in DISTANT parts of the batch's blocks.  Same reason as the placement windows of cvs_state.cpp: planes written
     // together stream faster when they come from two runs of the VRAM allocator than from one, and a 3 GB batch block spans
     // more than one run.  tools/zways_probe.py, 32 x 1080p, same handles and buffers: a "slow" block 0.677 -> 0.752 of the HBM
     // roofline, a "fast" one 0.717 -> 0.725; four / eight / sixteen parts give less (0.72 / 0.71 / 0.70).
-    unsigned z = blockIdx.z;
+    int bx = 0, by = 0;
+    unsigned z = 0;
+    if (!pick_tile(a, &s_tile, bx, by, z)) return;
     if constexpr (BATCH != 0) {
         if (a.z_ways > 1) {
             const unsigned per = ((unsigned)a.batch + a.z_ways - 1) / a.z_ways;
@@ -625,7 +713,7 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
             if (z >= (unsigned)a.batch) return;
         }
     }
-    basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB, U8>(a, t, lds[threadIdx.x >> 6], z);
+    basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB, U8>(a, t, lds[threadIdx.x >> 6], z, bx, by);
 }
 
 // G + H half banks in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
@@ -635,8 +723,12 @@ template <class BG, class BH, int FLAGS, bool STREAM, bool ONE, bool U8 = false>
 __global__ __launch_bounds__(256) void k_basis_pair(const BasisArgs a, const Folded<BG> tg, const Folded<BH> th)
 {
     __shared__ float lds[4][64 + 2 * BG::W + 4];
-    if (blockIdx.z == 0) basis_body<BG, FLAGS, STREAM, false, ONE, 4, U8>(a, tg, lds[threadIdx.x >> 6], 0);
-    else basis_body<BH, FLAGS, STREAM, false, ONE, 4, U8>(a, th, lds[threadIdx.x >> 6], 0);
+    __shared__ int s_tile;
+    int bx = 0, by = 0;
+    unsigned z = 0;
+    if (!pick_tile(a, &s_tile, bx, by, z)) return;   // z = half bank (dynamic order: tiles of both halves come from one set of queues)
+    if (z == 0) basis_body<BG, FLAGS, STREAM, false, ONE, 4, U8>(a, tg, lds[threadIdx.x >> 6], 0, bx, by);
+    else basis_body<BH, FLAGS, STREAM, false, ONE, 4, U8>(a, th, lds[threadIdx.x >> 6], 0, bx, by);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -743,6 +835,32 @@ static unsigned weighted_grid(BasisArgs& a)
     return (unsigned)(((tiles + period - 1) / period) * 8 * cmax);
 }
 
+// dynamic order: more workgroups than tiles (see pick_tile; CVS_DYN_SURPLUS_PCT = tuning aid, default 25 %), a multiple of 8 so
+// that every XCD gets the same number
+static unsigned dynamic_blocks(size_t ntiles)
+{
+    static const int pct = [] {
+        const char* e = std::getenv("CVS_DYN_SURPLUS_PCT");
+        return e ? std::max(0, std::min(100, std::atoi(e))) : 25;
+    }();
+    return (unsigned)((ntiles + ntiles * pct / 100 + 7) / 8 * 8);
+}
+
+// dynamic order: which of the handle's two sets of queues this launch uses (and which it zeroes for the next one); under
+// stream capture a memset node makes the set zero at every replay
+static hipError_t dynamic_queues(BasisArgs& a, hipStream_t s)
+{
+    const int p = a.tile_parity ? (*a.tile_parity & 1) : 0;
+    unsigned* base = a.tile_ctr;
+    a.tile_ctr = base + p * kQueueSetUints;
+    a.tile_ctr_next = base + (1 - p) * kQueueSetUints;
+    if (a.tile_parity) *a.tile_parity ^= 1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return hipMemsetAsync(a.tile_ctr, 0, kQueueSetUints * sizeof(unsigned), s);
+    return hipSuccess;
+}
+
 template <class B>
 static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStream_t s)
 {
@@ -754,7 +872,14 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     a.grid_x = grid.x;
     a.grid_y = grid.y;
     a.xcd_steal = 0;
-    if (a.block_order == kOrderXcdColumns) {
+    a.dyn_nz = 1;
+    if (a.block_order == kOrderDynamic && !a.tile_ctr) a.block_order = 0;   // no queue slot for this handle: the plain order
+    const bool dyn = a.block_order == kOrderDynamic;
+    if (dyn) {
+        // the grid is set at the launch itself (CVS_LAUNCH_K): it covers the frames of a batch as well
+        const hipError_t qe = dynamic_queues(a, s);
+        if (qe != hipSuccess) return qe;
+    } else if (a.block_order == kOrderXcdColumns) {
         const int n_own = ((a.grid_x + 7) / 8) * a.grid_y;
         // shares e : o for even : odd XCDs (the same pair of numbers as the weighted order's tiles per period); needs the
         // column blocks to divide evenly (the API layer only picks this order then)
@@ -774,15 +899,23 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     // which honours row_lo / row_hi / row_base
     const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;
     const bool one = !banded && a.state_bytes > 0 && a.state_bytes <= kMaxPlaneBytes;
-#define CVS_LAUNCH_U(FL, BATCHED, WP, U)                                                                           \
-    do {                                                                                                           \
-        if (one) {                                                                                                 \
-            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, true, WP, U>), grid, block, 0, s, a, f);   \
-            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, true, WP, U>), grid, block, 0, s, a, f);              \
-        } else {                                                                                                   \
-            if (a.nt_stores) hipLaunchKernelGGL((k_basis<B, FL, true, BATCHED, false, WP, U>), grid, block, 0, s, a, f);  \
-            else hipLaunchKernelGGL((k_basis<B, FL, false, BATCHED, false, WP, U>), grid, block, 0, s, a, f);             \
-        }                                                                                                          \
+#define CVS_LAUNCH_K(...)                                                                  \
+    do {                                                                                   \
+        if (dyn) {                                                                         \
+            a.dyn_nz = (int)grid.z;                                                        \
+            grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * grid.z), 1, 1);       \
+        }                                                                                  \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, f);                        \
+    } while (0)
+#define CVS_LAUNCH_U(FL, BATCHED, WP, U)                                                   \
+    do {                                                                                   \
+        if (one) {                                                                         \
+            if (a.nt_stores) CVS_LAUNCH_K(k_basis<B, FL, true, BATCHED, true, WP, U>);     \
+            else CVS_LAUNCH_K(k_basis<B, FL, false, BATCHED, true, WP, U>);                \
+        } else {                                                                           \
+            if (a.nt_stores) CVS_LAUNCH_K(k_basis<B, FL, true, BATCHED, false, WP, U>);    \
+            else CVS_LAUNCH_K(k_basis<B, FL, false, BATCHED, false, WP, U>);               \
+        }                                                                                  \
     } while (0)
 #define CVS_LAUNCH_W(FL, BATCHED, WP)                       \
     do {                                                    \
@@ -845,6 +978,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
 #undef CVS_LAUNCH_B
 #undef CVS_LAUNCH_W
 #undef CVS_LAUNCH_U
+#undef CVS_LAUNCH_K
 #undef CVS_LAUNCH
     return hipGetLastError();
 }
@@ -858,7 +992,14 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
     a.grid_x = grid.x;
     a.grid_y = grid.y;
     a.xcd_steal = 0;
-    if (a.block_order == kOrderXcdColumns) {  // as in launch_fast (found by tools/fuzz_campaign.py: this order, pinned by the caller, used to
+    a.dyn_nz = 2;
+    if (a.block_order == kOrderDynamic && !a.tile_ctr) a.block_order = 0;
+    const bool dyn = a.block_order == kOrderDynamic;
+    if (dyn) {
+        // the grid is set at the launch (see launch_fast); tiles of both half banks share the queues
+        const hipError_t qe = dynamic_queues(a, s);
+        if (qe != hipSuccess) return qe;
+    } else if (a.block_order == kOrderXcdColumns) {  // as in launch_fast (found by tools/fuzz_campaign.py: this order, pinned by the caller, used to
                                               // fall into the band-interleaved grid below and leave tiles of a G4 image unwritten)
         const int n_own = ((a.grid_x + 7) / 8) * a.grid_y;
         if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
@@ -872,10 +1013,15 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;  // see launch_fast
     const bool one = !banded && a.state_bytes > 0 && a.state_bytes <= kMaxPlaneBytes;
-#define CVS_PAIR(FL, ST, ON)                                                                                             \
-    do {                                                                                                                 \
-        if (a.in_u8) hipLaunchKernelGGL((k_basis_pair<BG, BH, FL, ST, ON, true>), grid, block, 0, s, a, fg, fh);         \
-        else hipLaunchKernelGGL((k_basis_pair<BG, BH, FL, ST, ON, false>), grid, block, 0, s, a, fg, fh);                \
+#define CVS_PAIR_K(...)                                                                                         \
+    do {                                                                                                        \
+        if (dyn) grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * 2), 1, 1);                            \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, fg, fh);                                        \
+    } while (0)
+#define CVS_PAIR(FL, ST, ON)                                                      \
+    do {                                                                          \
+        if (a.in_u8) CVS_PAIR_K(k_basis_pair<BG, BH, FL, ST, ON, true>);          \
+        else CVS_PAIR_K(k_basis_pair<BG, BH, FL, ST, ON, false>);                 \
     } while (0)
     if (steer) {
         if (a.nt_stores) { if (one) CVS_PAIR(F_STEER, true, true); else CVS_PAIR(F_STEER, true, false); }
@@ -885,6 +1031,7 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
         else { if (one) CVS_PAIR(0, false, true); else CVS_PAIR(0, false, false); }
     }
 #undef CVS_PAIR
+#undef CVS_PAIR_K
     return hipGetLastError();
 }
 
@@ -905,8 +1052,9 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
             if (ky.k[width + i] != ky.k[width - i]) sym = 0;
             if (ky.k[width + i] != -ky.k[width - i]) asym = 0;
         }
-        hipLaunchKernelGGL(k_colpass_generic, grid, block, 0, s, (const float*)scratch, spitch, a.rows, a.cols,
-                           a.basis + (size_t)p * a.plane_stride, a.pitch, ky, width, sym ? 1 : asym ? -1 : 0);
+        const PlaneRef bp = basis_plane_ref(a, kind, p);
+        hipLaunchKernelGGL(k_colpass_generic, grid, block, 0, s, (const float*)scratch, spitch, a.rows, a.cols, bp.p, bp.pitch, ky, width,
+                           sym ? 1 : asym ? -1 : 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -914,7 +1062,7 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
     if (a.orient && kind == 2) {
         PointArgs pa{};
         pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
-        for (int p = 0; p < 7; ++p) pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch};
+        for (int p = 0; p < 7; ++p) pa.in[p] = basis_plane_ref(a, kind, p);
         for (int i = 0; i < 5; ++i) pa.out[i] = {a.orient + (size_t)i * a.orient_stride, a.orient_pitch};
         e = launch_point(OP_G2_ORIENT, pa, s);
         if (e != hipSuccess) return e;
@@ -923,7 +1071,7 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
         PointArgs pa{};
         pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
         pa.find_on_e = a.find_on_e;
-        for (int p = 0; p < 7; ++p) pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch};
+        for (int p = 0; p < 7; ++p) pa.in[p] = basis_plane_ref(a, kind, p);
         for (int i = 0; i < 3; ++i) pa.in[7 + i] = {a.orient + (size_t)i * a.orient_stride, a.orient_pitch};
         pa.in[10] = {a.orient + (size_t)3 * a.orient_stride, a.orient_pitch};
         for (int k = 0; k < 8; ++k) pa.out[k] = a.pipe_out[k];
@@ -933,7 +1081,7 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
     if (a.steer_g && a.steer_h) {
         PointArgs pa{};
         pa.rows = a.rows; pa.cols = a.cols; pa.atan_mode = a.atan_mode; pa.nt_stores = a.nt_stores;
-        for (int p = 0; p < nb; ++p) { pa.in[p] = {a.basis + (size_t)p * a.plane_stride, a.pitch}; pa.w[p] = a.steer_w[p]; }
+        for (int p = 0; p < nb; ++p) { pa.in[p] = basis_plane_ref(a, kind, p); pa.w[p] = a.steer_w[p]; }
         pa.out[0] = {a.steer_g, a.steer_g_pitch};
         pa.out[1] = {a.steer_h, a.steer_h_pitch};
         e = launch_point(kind == 2 ? OP_G2_STEER_SCALAR : OP_G4_STEER_SCALAR, pa, s);
@@ -945,6 +1093,7 @@ static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTa
 static size_t max_pitch_bytes(const BasisArgs& a)
 {
     size_t mx = a.in_pitch > a.pitch ? a.in_pitch : a.pitch;
+    if (a.basis2) mx = max(mx, a.pitch2);
     if (a.orient) mx = max(mx, a.orient_pitch);
     if (a.steer_g) { mx = max(mx, a.steer_g_pitch); mx = max(mx, a.steer_h_pitch); }
     for (int k = 0; k < 8; ++k)
@@ -1032,6 +1181,7 @@ static hipError_t for_each_band(const BasisArgs& a_in, int width, F&& fn)
         const size_t rb = (size_t)a.row_base;
         a.in = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + rb * a.in_pitch * (a.in_u8 ? 1 : sizeof(float)));
         a.basis += rb * a.pitch;
+        if (a.basis2) a.basis2 += rb * a.pitch2;
         if (a.orient) a.orient += rb * a.orient_pitch;
         if (a.steer_g) a.steer_g += rb * a.steer_g_pitch;
         if (a.steer_h) a.steer_h += rb * a.steer_h_pitch;

@@ -95,6 +95,50 @@ bool verify_window(char* base, int nplanes, size_t piece, hipStream_t stream)
 
 int state_probes_run() { return g_probes_run.load(); }
 
+// ---- tile-queue slots (dynamic launch order) ----
+namespace {
+constexpr int kCtrSlots = 512;
+constexpr size_t kCtrSlotBytes = 2048;   // two sets of queues, 1 KiB each (cvs_kernels_basis.hip kQueueSetUints)
+struct CtrSlab {
+    unsigned char* base = nullptr;
+    std::vector<int> free_slots;
+    bool failed = false;
+};
+std::mutex g_ctr_mutex;
+CtrSlab g_ctr[64];
+}  // namespace
+
+static unsigned* tile_ctr_alloc(int device)
+{
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ctr_mutex);
+    CtrSlab& sl = g_ctr[device];
+    if (!sl.base && !sl.failed) {
+        // once per device and process: 1 MiB, zeroed (the kernels keep the invariant "all zero between launches" themselves)
+        void* p = nullptr;
+        if (hipMalloc(&p, kCtrSlots * kCtrSlotBytes) != hipSuccess || hipMemset(p, 0, kCtrSlots * kCtrSlotBytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p) (void)hipFree(p);
+            sl.failed = true;
+            return nullptr;
+        }
+        sl.base = static_cast<unsigned char*>(p);
+        for (int i = kCtrSlots - 1; i >= 0; --i) sl.free_slots.push_back(i);
+    }
+    if (!sl.base || sl.free_slots.empty()) return nullptr;   // no slot: the handle keeps to the static orders
+    const int i = sl.free_slots.back();
+    sl.free_slots.pop_back();
+    return reinterpret_cast<unsigned*>(sl.base + (size_t)i * kCtrSlotBytes);
+}
+
+static void tile_ctr_free(int device, unsigned* p)
+{
+    if (!p || device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lock(g_ctr_mutex);
+    CtrSlab& sl = g_ctr[device];
+    if (sl.base) sl.free_slots.push_back((int)((reinterpret_cast<unsigned char*>(p) - sl.base) / kCtrSlotBytes));
+}
+
 void state_block_free(StateBlock& b)
 {
     if (!b.base) return;
@@ -103,6 +147,7 @@ void state_block_free(StateBlock& b)
         (void)hipEventDestroy(b.ready);
         b.ready = nullptr;
     }
+    tile_ctr_free(b.device, b.tile_ctr);
     if (b.vmm) {
         for (size_t p = 0; p < b.pieces.size(); ++p) {
             (void)hipMemUnmap(reinterpret_cast<char*>(b.base) + p * b.piece_bytes, b.piece_bytes);
@@ -121,7 +166,10 @@ hipError_t state_block_alloc_plain(int device, size_t elems, StateBlock& b)
     b = StateBlock();
     b.device = device;
     hipError_t e = hipMalloc(&b.base, elems * sizeof(float));
-    if (e == hipSuccess) b.elems = elems;
+    if (e == hipSuccess) {
+        b.elems = elems;
+        b.tile_ctr = tile_ctr_alloc(device);
+    }
     return e;
 }
 
@@ -352,6 +400,7 @@ static hipError_t alloc_planes_impl(int device, int nplanes, int rows, size_t pi
     }
     (void)hipGetLastError();
     b.vmm = true;
+    b.tile_ctr = tile_ctr_alloc(device);
     b.base = reinterpret_cast<float*>((char*)pool_va + (size_t)window * piece);
     b.piece_bytes = piece;
     b.elems = (size_t)nplanes * (piece / sizeof(float));

@@ -87,7 +87,10 @@ enum {
                                 the faster XCDs (CVS_OPT_XCD_WEIGHTS); 2 <= T < 1000000 = groups of T row bands walked column
                                 by column (T >= number of bands: column-major); 1000000 = every XCD walks its own range of
                                 column blocks; with CVS_OPT_XCD_WEIGHTS e : o the odd XCDs leave the end of their range to
-                                their even neighbours (only when the 256-column blocks divide evenly among the 8 XCDs).
+                                their even neighbours (only when the 256-column blocks divide evenly among the 8 XCDs);
+                                2000000 = DYNAMIC: a persistent launch (as many workgroups as the chip holds at once) whose
+                                workgroups take tile after tile from eight per-XCD queues in device memory and help the other
+                                XCDs when their own queue is empty -- no assumption about which XCDs are faster on this box.
                                 Results do not depend on it. */
     CVS_OPT_XCD_WEIGHTS = 10, /* block orders 1 and 1000000: 100 * e + o = shares of the even / odd XCDs (1..16 each; 101 =
                                  equal); 0 (default) = the engine's choice, or what the autotuner found (tuning) */

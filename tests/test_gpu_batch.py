@@ -470,8 +470,11 @@ def test_bench_starts_its_own_ranks_and_watchdog_emits_the_headline(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["config"]["ranks_started_by"] == "bench.py"
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.2
     assert d["repeats"]["repeats"] == 3 and d["repeats"]["Mpix/s"]["min"] <= d["value"] <= d["repeats"]["Mpix/s"]["max"]
-    assert d["config"]["placement"]["mode"] == 1 and isinstance(d["config"]["placement"]["window_found"], bool)
-    assert (d["config"]["placement"]["probe_ms"] > 0.0) or not d["config"]["placement"]["window_found"]
+    # the headline runs on the library's defaults: no placement search, no launches beyond the caller's own
+    assert d["config"]["placement"]["mode"] == 0 and d["config"]["library_defaults"] is True
+    assert d["config"]["launch"]["tuning_launches"] == 0 and d["config"]["launch"]["state_layout"] == 1
+    assert d["roofline_m1"]["bound"] == "hbm" and 0 < d["roofline_m1"]["frac"] < 1.2 and "launch" in d["roofline_m1"]
+    assert d["multi_gpu"]["ranks"] == 2 and d["multi_gpu"]["rccl_ranks"] == 0 and d["multi_gpu"]["distinct_devices"] is False   # rehearsal on one GPU
     assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"        # rank 0 measures it for N > 1 as well
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu", "--extra-timeout", "1", "--repeats", "3"],
                        env=os.environ, capture_output=True, text=True, timeout=600)
@@ -495,7 +498,8 @@ def test_bench_two_ranks_with_the_secondary_legs_and_a_crashing_rank(tmp_path):
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and "extra_error" not in d
     ex = d["extra"]
-    for leg in ("M2_rotating_8_inputs", "M2_untuned", "M2_first_call", "M2_plain_block", "C4_32x1080p_pipeline_batch", "C4_32x1080p_feature_maps_only"):
+    for leg in ("M2_rotating_8_inputs", "M2_u8_input_rotating", "M2_untuned", "M2_one_object_per_image", "M2_first_call", "M2_placement_window",
+                "C4_32x1080p_pipeline_batch", "C4_32x1080p_feature_maps_only", "C4_32x1080p_u8_feature_maps"):
         assert leg in ex and "error" not in ex[leg], (leg, ex.get(leg))
     assert ex["C4_32x1080p_pipeline_batch"]["frames_per_gpu"] == 32 and ex["C4_32x1080p_pipeline_batch"]["Mpix/s"] > 0
     r = subprocess.run(cmd, env=dict(env, CVS_BENCH_TEST_CRASH_RANK="1"), capture_output=True, text=True, timeout=900)

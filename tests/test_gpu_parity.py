@@ -953,7 +953,7 @@ def test_8bit_images_read_in_kernel_equal_widened(cv, shape):
         for p in range(11):
             assert torch.equal(a4._state(p), b4._state(p)), ("g4 basis", p)
     # host bytes (pageable numpy, padded rows): the bytes are uploaded and read as bytes
-    hu8 = views[1].cpu().numpy()
+    hu8 = big.cpu().numpy()[3:3 + rows, 5:5 + cols]
     assert hu8.strides[0] > cols
     hw = cv.SteerableFiltersG2(None).pipeline(hu8)
     hr = cv.SteerableFiltersG2(None).pipeline(np.ascontiguousarray(hu8).astype(np.float32))
@@ -1087,7 +1087,7 @@ def test_block_order_never_changes_results(cv):
     from cvsteer_amd import _lib as L
     img = torch.rand((1100, 1500), device="cuda")     # >= 1 Mpix: eligible for autotune
     ref = None
-    for order in (0, 1, 2, 7, 32, 100000, 1000000, -1):   # 1000000 = XCD-owned column ranges (the default for fresh images)
+    for order in (0, 1, 2, 7, 32, 100000, 1000000, 2000000, -1):   # 1000000 = XCD-owned column ranges, 2000000 = dynamic (tiles taken from per-XCD queues)
         f = cv.SteerableFiltersG2(None)
         f.set_option(L.OPT_BLOCK_ORDER, order)
         outs = []
@@ -1111,7 +1111,7 @@ def test_xcd_weighted_order_never_changes_results(cv):
     for shape in ((1100, 1500), (257, 449), (300, 2048 + 64), (1030, 64)):
         img = torch.rand(shape, device="cuda")
         ref = None
-        for order, xw in ((0, 0), (1, 0), (1, 504), (1, 302), (1, 405), (1, 116), (1, 1601), (-1, 0)):
+        for order, xw in ((0, 0), (1, 0), (1, 504), (1, 302), (1, 405), (1, 116), (1, 1601), (2000000, 0), (-1, 0)):
             f = cv.SteerableFiltersG2(None)
             f.set_option(L.OPT_BLOCK_ORDER, order)
             f.set_option(L.OPT_XCD_WEIGHTS, xw)
@@ -1443,7 +1443,7 @@ def test_placement_search_is_opt_in_and_reports_what_it_did(cv):
     f.setup(x)
     info = f.launch_info()
     assert info["probes_run"] == n0 and info["state_per_plane"] == 0 and info["probe_ms"] == 0.0
-    assert info["strip_rows"] > 0 and info["nt_stores"] == 1 and info["block_order"] in (0, 1, 1000000)
+    assert info["strip_rows"] > 0 and info["nt_stores"] == 1 and info["block_order"] in (0, 1, 1000000, 2000000)
     want = f.basis(3).clone()
     del f
     cv.lib().cvs_release_cached_memory()
@@ -1562,7 +1562,7 @@ def test_g4_bank_layouts_never_change_results(cv):
         img = torch.rand(shape, device="cuda")
         ref = None
         for split in (0, 1, 2):
-            for order in (0, 1, 5, 100000):
+            for order in (0, 1, 5, 100000, 2000000):
                 f = cv.SteerableFiltersG4(None)
                 f.set_option(L.OPT_G4_SPLIT, split)
                 f.set_option(L.OPT_BLOCK_ORDER, order)

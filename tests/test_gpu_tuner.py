@@ -1,0 +1,225 @@
+"""GPU tests (-m gpu) of the launch-configuration machinery around the strip kernels: the ONLINE tuner (candidates are
+compared on the caller's own launches -- nothing extra is launched, nothing stalls) and the no-drain destroy (one object
+per image, example/steer.cpp:86).  Results never depend on any of it: every call is compared bit for bit."""
+import statistics
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import cvsteer_amd
+    return cvsteer_amd
+
+
+def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
+    """a new 4096^2 shape: the second call costs about what a settled call costs (rounds 2-3 ran ~250 timing launches inside
+    it, 25-30 ms); cvs_launch_info.tuning_launches stays 0; every call -- whatever candidate configuration it ran with --
+    returns the same bits; after ~40 calls a configuration has been kept"""
+    import torch
+    from cvsteer_amd import _lib as L
+    n = 4096
+    img = torch.rand((n, n), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    g, h = torch.empty_like(img), torch.empty_like(img)
+    f = cv.SteerableFiltersG2(None)
+    assert f.launch_info()["tuning_launches"] == 0
+
+    def call():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    times, configs = [], set()
+    first = None
+    for i in range(70):
+        times.append(call())
+        li = f.launch_info()
+        configs.add((li["block_order"], li["xcd_weights"], li["strip_rows"]))
+        assert li["tuning_launches"] == 0
+        if first is None:
+            first = (g.clone(), h.clone(), f.basis(3).clone())
+        elif i in (1, 2, 5, 9, 14, 22, 31, 45, 69):
+            assert torch.equal(g, first[0]) and torch.equal(h, first[1]) and torch.equal(f.basis(3), first[2]), i
+    steady = statistics.median(times[-15:])
+    assert times[1] <= 1.5 * steady + 0.15, (times[:4], steady)          # the second call is an ordinary call (+ host jitter; rounds 2-3: 25-30 ms)
+    assert max(times[1:]) <= 3.0 * steady + 0.2, (max(times[1:]), steady)  # ... and so is every other one
+    assert len(configs) >= 2, configs                                     # candidates did take turns on these calls
+    last = f.launch_info()
+    tail = set()
+    for _ in range(6):
+        call()
+        li = f.launch_info()
+        tail.add((li["block_order"], li["xcd_weights"], li["strip_rows"]))
+    assert len(tail) == 1, tail                                           # settled: one configuration from here on
+    # a second handle of the same shape starts from what the process has learnt
+    f2 = cv.SteerableFiltersG2(None)
+    f2.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+    f2.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))   # (a handle's first call counts as a fresh image: its own key)
+    li2 = f2.launch_info()
+    assert (li2["block_order"], li2["xcd_weights"], li2["strip_rows"]) == next(iter(tail))
+    # tuner off: the default configuration on every call
+    f3 = cv.SteerableFiltersG2(None)
+    f3.set_option(L.OPT_AUTOTUNE, 0)
+    seen = set()
+    for _ in range(8):
+        f3.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        li = f3.launch_info()
+        seen.add((li["block_order"], li["xcd_weights"], li["strip_rows"]))
+    assert len(seen) <= 2 and torch.equal(g, first[0])   # (first call = fresh-image default, then the resident default)
+    del last
+
+
+def test_objects_come_and_go_without_draining_the_device(cv):
+    """one object per image (example/steer.cpp:86 inside the parallel_for_ body), no host synchronisation anywhere in the
+    loop: cvs_destroy parks the state block with an event and the next object's launch waits for it on the device.  Every
+    object's outputs are checked afterwards against a long-lived handle, bit for bit; the loop must also be no slower per
+    object than a loop that synchronises after every object."""
+    import time
+    import torch
+    n = 2048
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    imgs = [torch.rand((n, n), device="cuda", generator=gen) for _ in range(4)]
+    ref_f = cv.SteerableFiltersG2(None)
+    refs = []
+    for im in imgs:
+        g, h = ref_f.setup_steer(im, 0.3, flags=cv.SETUP_BASIS)
+        refs.append((g.clone(), h.clone()))
+    nobj = 48
+    outs = [(torch.empty_like(imgs[0]), torch.empty_like(imgs[0])) for _ in range(nobj)]
+
+    def loop(sync_each):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nobj):
+            f = cv.SteerableFiltersG2(None)
+            f.setup_steer(imgs[i & 3], 0.3, flags=cv.SETUP_BASIS, out=outs[i])
+            if sync_each:
+                torch.cuda.synchronize()
+            del f
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / nobj
+
+    loop(False)
+    t_free = min(loop(False) for _ in range(3))
+    for i in range(nobj):
+        assert torch.equal(outs[i][0], refs[i & 3][0]) and torch.equal(outs[i][1], refs[i & 3][1]), i
+    t_sync = min(loop(True) for _ in range(3))
+    assert t_free <= t_sync * 1.05, (t_free, t_sync)
+    # the state of a destroyed object's successor is its own: a full setup right behind a destroy, different image
+    a = cv.SteerableFiltersG2(imgs[0])
+    th_a = a.getDominantOrientationAngle().clone()
+    del a
+    b = cv.SteerableFiltersG2(imgs[1])
+    c = cv.SteerableFiltersG2(imgs[0])
+    assert torch.equal(c.getDominantOrientationAngle(), th_a)
+    assert not torch.equal(b.getDominantOrientationAngle(), th_a)
+
+
+def test_state_layouts_give_identical_planes(cv):
+    """CVS_OPT_STATE_LAYOUT: row-interleaved (default) and planar state blocks hold the same values in every plane; the
+    zero-copy views differ only in their row step"""
+    import torch
+    from cvsteer_amd import _lib as L
+    rng = np.random.default_rng(3)
+    for shape in ((185, 256), (300, 1021), (1080, 1920)):
+        img = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
+        for cls, nb in ((cv.SteerableFiltersG2, 7), (cv.SteerableFiltersG4, 11)):
+            hs = []
+            for lay in (0, 1):
+                f = cls(None)
+                f.set_option(L.OPT_STATE_LAYOUT, lay)
+                f.setup(img)
+                assert f.launch_info()["state_layout"] == lay
+                hs.append(f)
+            for p in range(nb):
+                assert torch.equal(hs[0].basis(p), hs[1].basis(p)), (shape, p)
+            s0, s1 = hs[0].basis_view(1)[3], hs[1].basis_view(1)[3]
+            assert s1 > s0 and s1 % s0 == 0        # planes x row length against one row length
+            if nb == 7:
+                assert torch.equal(hs[0].getDominantOrientationAngle(), hs[1].getDominantOrientationAngle())
+                assert torch.equal(hs[0].getDominantOrientationStrength(), hs[1].getDominantOrientationStrength())
+                for a_, b_ in zip(hs[0].steer(None, full=True), hs[1].steer(None, full=True)):
+                    assert torch.equal(a_, b_)
+                x, y = shape[1] // 3, shape[0] // 2
+                assert tuple(hs[0].steer_point((x, y), 0.4, full=True)) == tuple(hs[1].steer_point((x, y), 0.4, full=True))
+
+
+def test_dynamic_order_many_launches_and_graph_replay(cv):
+    """block order 2000000: the tile queues are back at zero after every launch -- hundreds of launches in a row, launches of
+    different shapes and variants on one handle, two handles on two streams at once, and a captured graph replayed many
+    times all give the bits of the plain order"""
+    import torch
+    from cvsteer_amd import _lib as L
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    imgs = {s: torch.rand(s, device="cuda", generator=gen) for s in ((1100, 1500), (2048, 2304), (333, 777))}
+    ref = {}
+    plain = cv.SteerableFiltersG2(None)
+    plain.set_option(L.OPT_BLOCK_ORDER, 0)
+    for s, im in imgs.items():
+        g, h = plain.setup_steer(im, 0.3)
+        ref[s] = (g.clone(), h.clone(), [o.clone() for o in plain.pipeline(im)])
+    f = cv.SteerableFiltersG2(None)
+    f.set_option(L.OPT_BLOCK_ORDER, 2000000)
+    for it in range(120):
+        s = list(imgs)[it % 3]
+        if it % 2:
+            g, h = f.setup_steer(imgs[s], 0.3)
+            assert f.launch_info()["block_order"] == 2000000
+            if it % 7 == 1:
+                assert torch.equal(g, ref[s][0]) and torch.equal(h, ref[s][1]), it
+        else:
+            outs = f.pipeline(imgs[s])
+            if it % 5 == 0:
+                for a_, b_ in zip(outs, ref[s][2]):
+                    assert torch.equal(a_, b_), it
+    # two handles, two streams, launches in flight together: each handle has its own queues
+    s0 = (2048, 2304)
+    fa, fb = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
+    for x in (fa, fb):
+        x.set_option(L.OPT_BLOCK_ORDER, 2000000)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs_a = [(torch.empty(s0, device="cuda"), torch.empty(s0, device="cuda")) for _ in range(12)]
+    outs_b = [(torch.empty(s0, device="cuda"), torch.empty(s0, device="cuda")) for _ in range(12)]
+    torch.cuda.synchronize()
+    for i in range(12):
+        with torch.cuda.stream(sa):
+            fa.setup_steer(imgs[s0], 0.3, out=outs_a[i])
+        with torch.cuda.stream(sb):
+            fb.setup_steer(imgs[s0], 0.3, out=outs_b[i])
+    torch.cuda.synchronize()
+    for i in range(12):
+        assert torch.equal(outs_a[i][0], ref[s0][0]) and torch.equal(outs_b[i][1], ref[s0][1]), i
+    # captured and replayed
+    img = imgs[s0].clone()
+    g, h = torch.empty_like(img), torch.empty_like(img)
+    fg = cv.SteerableFiltersG2(None)
+    fg.set_option(L.OPT_BLOCK_ORDER, 2000000)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fg.setup_steer(img, 0.3, out=(g, h))
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            fg.setup_steer(img, 0.3, out=(g, h))
+            fg.setup_steer(img, 0.3, out=(g, h))
+    torch.cuda.synchronize()
+    for rep in range(25):
+        g.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref[s0][0]) and torch.equal(h, ref[s0][1])
+    # G4: tiles of both half banks from one set of queues
+    f4p, f4d = cv.SteerableFiltersG4(None), cv.SteerableFiltersG4(None)
+    f4p.set_option(L.OPT_BLOCK_ORDER, 0)
+    f4d.set_option(L.OPT_BLOCK_ORDER, 2000000)
+    for _ in range(3):
+        a_, b_ = f4p.setup_steer(imgs[s0], 0.7), f4d.setup_steer(imgs[s0], 0.7)
+        assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1])
+        for p in range(11):
+            assert torch.equal(f4p.basis(p), f4d.basis(p)), p
