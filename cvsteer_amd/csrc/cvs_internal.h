@@ -13,6 +13,7 @@ constexpr int kMaxWidth = 32;           // generic path: up to 65 taps
 constexpr int kMaxTaps = 2 * kMaxWidth + 1;
 constexpr int kMaxBasis = 11;
 constexpr int kOrderXcdColumns = 1000000;  // BasisArgs::block_order: every XCD owns a contiguous range of column blocks
+constexpr int kOrderSkewed = 3000000;      // BasisArgs::block_order: row-major with the columns rotated by xcd_odd blocks per band
 constexpr int kOrderDynamic = 2000000;     // BasisArgs::block_order: persistent launch, tiles taken from per-XCD queues (tile_ctr)
 
 struct PlaneRef {
@@ -61,6 +62,7 @@ struct BasisArgs {
     int block_order;      // 0 = row-major grid, 1 = row-major weighted per XCD, T >= 2 = groups of T bands walked column by column
     int xcd_even, xcd_odd; // block_order 1: tiles per period for the even / odd XCDs (see basis_body)
     int grid_x, grid_y;   // filled by the launcher
+    int dyn_static;       // dynamic order: the first dyn_static tiles are dealt statically (tile = workgroup index); filled by the launcher
     int dyn_nz;           // dynamic order: planes of tiles (frames of a batch / half banks of the G4 pair); filled by the launcher
     unsigned* tile_ctr;   // dynamic order: the handle's tile queues in device memory -- two sets, used alternately (cvs_kernels_basis.hip);
                           // the API layer passes the slot, the launcher picks the set

@@ -182,15 +182,18 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 
 // ---------------------------------------------------------------------------------------
 // Which tile does this workgroup filter?  STATIC orders: computed from blockIdx (static_tile).  DYNAMIC order (block_order =
-// kOrderDynamic, round 4): the workgroup ASKS -- eight queues in device memory, one per XCD; queue q holds the tiles q, q + 8,
-// q + 16, ... of the row-major order (what the dispatcher's round-robin would have given XCD q anyway), a workgroup takes the
-// next tile of its own XCD's queue and, when that is empty, of the queues of the others.  The grid is somewhat larger than
-// the number of tiles: the dispatcher deals every XCD the same number of workgroups, so an XCD that is faster on this box,
-// with this kernel, at this moment works off its own queue early and then spends its surplus workgroups on the tiles of the
-// slower ones, whose surplus workgroups find nothing and leave.  Nothing about the speed of an XCD is assumed (rounds 2-3
-// dealt fixed even : odd shares, which helped on some boxes and hurt on others).  Cost: one returning atomic (~1 us) and one
-// barrier at the START of a workgroup; the body is the same code as for the static orders, the waves still never wait for
-// each other.
+// kOrderDynamic, round 4): the first 90 % of the tiles are dealt exactly like the plain order (tile = workgroup index); the
+// TAIL of the launch is handed out on demand -- eight queues in device memory, one per XCD; queue q holds the tail tiles q,
+// q + 8, q + 16, ... (what the dispatcher's round-robin would have given XCD q anyway); a late workgroup takes the next tile of
+// its own XCD's queue and, when that is empty, of the queues of the others.  The grid has a quarter more tail workgroups than
+// tail tiles: the dispatcher deals every XCD the same number of workgroups, so an XCD that is ahead (on this box, with this
+// kernel, with this placement of the planes) works off its own queue early and spends its surplus workgroups on the tiles of
+// the others, whose surplus workgroups find nothing and leave.  Nothing about the speed of an XCD is assumed (rounds 2-3
+// dealt fixed even : odd shares, order 1, which helps in some processes and hurts in others).  Cost: one returning atomic
+// (~1 us) and one barrier at the START of a tail workgroup; the body is the same code as for the static orders.  Handing out
+// ALL tiles this way was measured too: 20-40 % slower (every workgroup then starts with that microsecond).
+// Measured (profiles/r04_order_probe.txt, six processes on one box): level with the plain order where that is at its best,
+// +3 % for the 12- and 20-plane launches in processes where the weighted order gains 5 %, +2 % for the G4 pair launch.
 // Two sets of queues per handle, used alternately: a launch takes its tickets from one set and zeroes the OTHER one (which
 // the previous launch of the handle used; launches of a handle are ordered on its stream), so every launch finds its set at
 // zero without a host-side step, a reset kernel or a "last one out" protocol inside the launch.  (Under stream capture the
@@ -199,7 +202,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 constexpr int kQueueStride = 16;    // unsigned ints between two queue heads (64 B); head q at [q * 16], "all queues empty" flag at [8 * 16]
 constexpr int kQueueSetUints = 256; // one set of queues: 1 KiB; a handle's slot holds two
 
-__device__ __forceinline__ int take_tile(const BasisArgs& a, int q0, int ntiles)
+__device__ __forceinline__ int take_tile(const BasisArgs& a, int q0, int ntiles)   // ntiles = tiles in the queues (the tail)
 {
     unsigned k = __hip_atomic_fetch_add(a.tile_ctr + q0 * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k < (1u << 27) && (int)k * 8 + q0 < ntiles) return (int)k * 8 + q0;
@@ -264,6 +267,13 @@ __device__ __forceinline__ bool static_tile(const BasisArgs& a, int& bx, int& by
         by = k / cpx;
         bx = owner * cpx + (k - by * cpx);
         if (bx >= a.grid_x || by >= a.grid_y) return false;
+    } else if (a.block_order == kOrderSkewed) {
+        // plain row-major order with the columns rotated by xcd_odd blocks per band: with 8 | grid_x the plain order has XCD q
+        // filter column blocks q, q + 8, ... of EVERY band, i.e. each XCD writes the same byte ranges of every row for the whole
+        // launch; here the XCD <-> column assignment shifts from band to band
+        const int tl = (int)blockIdx.x;
+        by = tl / a.grid_x;
+        bx = (tl - by * a.grid_x + by * a.xcd_odd) % a.grid_x;
     } else if (a.block_order >= 2) {
         const int T = min(a.block_order, a.grid_y);
         const int per = T * a.grid_x, g = blockIdx.x / per, r = blockIdx.x % per;
@@ -283,12 +293,18 @@ __device__ __forceinline__ bool pick_tile(const BasisArgs& a, int* s_tile, int& 
     const int per_z = a.grid_x * a.grid_y, ntiles = per_z * a.dyn_nz;
     if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + 9)   // the set the NEXT launch of this handle will use
         __hip_atomic_store(a.tile_ctr_next + (threadIdx.x - 64) * kQueueStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 0) {
-        const int q0 = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);   // HW_REG_XCC_ID: the XCD this workgroup runs on
-        *s_tile = take_tile(a, q0, ntiles);
+    // the first dyn_static tiles are dealt like the plain order (tile = workgroup index, no ticket, no barrier): only the TAIL
+    // of the launch -- where an XCD that is ahead would otherwise go idle -- is handed out through the queues
+    int tl = (int)blockIdx.x;
+    if (tl >= a.dyn_static) {
+        if (threadIdx.x == 0) {
+            const int q0 = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);   // HW_REG_XCC_ID: the XCD this workgroup runs on
+            const int t = take_tile(a, q0, ntiles - a.dyn_static);
+            *s_tile = t < 0 ? t : t + a.dyn_static;
+        }
+        __syncthreads();
+        tl = __builtin_amdgcn_readfirstlane(*s_tile);   // the same in every lane: keep it (and bx, by, z) in scalar registers
     }
-    __syncthreads();
-    const int tl = __builtin_amdgcn_readfirstlane(*s_tile);   // the same in every lane: keep it (and bx, by, z) in scalar registers
     if (tl < 0) return false;
     z = (unsigned)(tl / per_z);
     const int r = tl - (int)z * per_z;
@@ -837,13 +853,21 @@ static unsigned weighted_grid(BasisArgs& a)
 
 // dynamic order: more workgroups than tiles (see pick_tile; CVS_DYN_SURPLUS_PCT = tuning aid, default 25 %), a multiple of 8 so
 // that every XCD gets the same number
-static unsigned dynamic_blocks(size_t ntiles)
+static unsigned dynamic_blocks(size_t ntiles, int* dyn_static)
 {
     static const int pct = [] {
         const char* e = std::getenv("CVS_DYN_SURPLUS_PCT");
         return e ? std::max(0, std::min(100, std::atoi(e))) : 25;
     }();
-    return (unsigned)((ntiles + ntiles * pct / 100 + 7) / 8 * 8);
+    static const int tail_pct = [] {   // share of the tiles handed out through the queues (the rest: tile = workgroup index)
+        const char* e = std::getenv("CVS_DYN_TAIL_PCT");
+        return e ? std::max(1, std::min(100, std::atoi(e))) : 10;
+    }();
+    const size_t tail = std::max<size_t>(8, ntiles * tail_pct / 100);
+    const size_t stat = ntiles > tail ? (ntiles - tail) / 8 * 8 : 0;
+    *dyn_static = (int)stat;
+    const size_t queued = ntiles - stat;
+    return (unsigned)(stat + (queued + queued * pct / 100 + 7) / 8 * 8);
 }
 
 // dynamic order: which of the handle's two sets of queues this launch uses (and which it zeroes for the next one); under
@@ -885,6 +909,9 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
         // column blocks to divide evenly (the API layer only picks this order then)
         if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
         grid = dim3(8u * (unsigned)(n_own + a.xcd_steal), 1);
+    } else if (a.block_order == kOrderSkewed) {
+        if (a.xcd_odd < 1 || a.xcd_odd > 16) a.xcd_odd = 1;
+        grid = dim3((unsigned)a.grid_x * a.grid_y, 1);
     } else if (a.block_order >= 2) {
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1);
@@ -903,7 +930,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     do {                                                                                   \
         if (dyn) {                                                                         \
             a.dyn_nz = (int)grid.z;                                                        \
-            grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * grid.z), 1, 1);       \
+            grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * grid.z, &a.dyn_static), 1, 1); \
         }                                                                                  \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, f);                        \
     } while (0)
@@ -1004,6 +1031,9 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
         const int n_own = ((a.grid_x + 7) / 8) * a.grid_y;
         if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
         grid = dim3(8u * (unsigned)(n_own + a.xcd_steal), 1, 2);
+    } else if (a.block_order == kOrderSkewed) {
+        if (a.xcd_odd < 1 || a.xcd_odd > 16) a.xcd_odd = 1;
+        grid = dim3((unsigned)a.grid_x * a.grid_y, 1, 2);
     } else if (a.block_order >= 2) {  // same 1-D band-interleaved walk as launch_fast; z still picks the half bank
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1, 2);
@@ -1015,7 +1045,7 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
     const bool one = !banded && a.state_bytes > 0 && a.state_bytes <= kMaxPlaneBytes;
 #define CVS_PAIR_K(...)                                                                                         \
     do {                                                                                                        \
-        if (dyn) grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * 2), 1, 1);                            \
+        if (dyn) grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * 2, &a.dyn_static), 1, 1);             \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, fg, fh);                                        \
     } while (0)
 #define CVS_PAIR(FL, ST, ON)                                                      \

@@ -102,6 +102,7 @@ constexpr size_t kCtrSlotBytes = 2048;   // two sets of queues, 1 KiB each (cvs_
 struct CtrSlab {
     unsigned char* base = nullptr;
     std::vector<int> free_slots;
+    std::vector<char> used;      // the slot has been handed out before
     bool failed = false;
 };
 std::mutex g_ctr_mutex;
@@ -124,11 +125,22 @@ static unsigned* tile_ctr_alloc(int device)
         }
         sl.base = static_cast<unsigned char*>(p);
         for (int i = kCtrSlots - 1; i >= 0; --i) sl.free_slots.push_back(i);
+        sl.used.assign(kCtrSlots, 0);
     }
     if (!sl.base || sl.free_slots.empty()) return nullptr;   // no slot: the handle keeps to the static orders
     const int i = sl.free_slots.back();
+    unsigned* p = reinterpret_cast<unsigned*>(sl.base + (size_t)i * kCtrSlotBytes);
+    if (sl.used[i]) {
+        // a slot that has served another block: the set its last launch took its tickets from is not at zero, and the new block
+        // starts with set 0 again.  (The block that held the slot was idle when it was freed: state_block_free waits for it.)
+        if (hipMemset(p, 0, kCtrSlotBytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
     sl.free_slots.pop_back();
-    return reinterpret_cast<unsigned*>(sl.base + (size_t)i * kCtrSlotBytes);
+    sl.used[i] = 1;
+    return p;
 }
 
 static void tile_ctr_free(int device, unsigned* p)

@@ -223,3 +223,30 @@ def test_dynamic_order_many_launches_and_graph_replay(cv):
         assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1], b_[1])
         for p in range(11):
             assert torch.equal(f4p.basis(p), f4d.basis(p)), p
+
+
+def test_dynamic_order_survives_recycled_queue_slots(cv):
+    """the tile queues travel with the state block; a slot that comes back from a freed block is zeroed before it serves the
+    next one (found by test_steering_under_transpose_and_mirror: a block that started on the dirty set of a recycled slot
+    left its tail tiles unwritten)"""
+    import torch
+    from cvsteer_amd import _lib as L
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    shapes = [(1080, 1920), (1200, 1600), (1536, 2048), (1100, 1500)]
+    imgs = [torch.rand(s, device="cuda", generator=gen) for s in shapes]
+    refs = []
+    for im in imgs:
+        f = cv.SteerableFiltersG4(None)
+        f.set_option(L.OPT_BLOCK_ORDER, 0)
+        f.setup(im)
+        refs.append([f.basis(p).clone() for p in range(11)])
+    for rnd in range(3):
+        for k, im in enumerate(imgs):
+            f = cv.SteerableFiltersG4(None)
+            f.set_option(L.OPT_BLOCK_ORDER, 2000000)
+            for _ in range(1 + (rnd + k) % 2):          # odd and even numbers of launches: either set may be the dirty one
+                f.setup(im)
+            for p in range(11):
+                assert torch.equal(f.basis(p), refs[k][p]), (rnd, k, p)
+            del f
+            cv.lib().cvs_release_cached_memory()         # the block is freed, its slot goes back to the slab
