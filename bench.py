@@ -846,12 +846,18 @@ def main():
                     else:
                         hnd.setup(cur, flags=cv.SETUP_BASIS)
 
+            def pyr_one_call():
+                flip3["i"] ^= 1
+                cv.pyramid_setup(hp, bigs[flip3["i"]], level_images=lv[1:], flags=cv.SETUP_BASIS)
+
             c3 = max(10, args.steps // 10)
             settle(pyr_filter)
             e_, _lo, _hi = timed(pyr_filter, c3, 2)
             e2_, _lo, _hi = timed(lambda: fp3.pyramid(bigs[0], 5), c3, 2)
             settle(pyr_whole)
-            e3_, e3_lo, e3_hi = timed(pyr_whole, c3, 2)
+            e4_, e4_lo, e4_hi = timed(pyr_whole, c3, 2)
+            settle(pyr_one_call)
+            e3_, e3_lo, e3_hi = timed(pyr_one_call, c3, 2)
             e_, e2_, e3_ = e_ * c3, e2_ * c3, e3_ * c3
             # algorithmic bytes of the whole configuration: 4 B read + 28 B written per pixel of every level, plus the
             # 4 B written per pixel of every level that is made here (levels 1..4)
@@ -863,8 +869,11 @@ def main():
                                                 "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                 "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix, "timed_steps": c3,
                                                 "whole_ms_min": round(e3_lo, 4), "whole_ms_max": round(e3_hi, 4), "repeats": LR,
+                                                "whole_entry": "cvs_pyramid_setup (the chain in one native call)",
+                                                "chain_of_five_calls_ms": round(e4_, 4),
+                                                "chain_of_five_calls_frac_hbm": round(whole_bytes / (e4_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                 "launch_per_level": [launch_of(hnd) for hnd in hp],
-                                                "note": "whole = build + filter, level k+1 written by the filter launch of level k, two alternating images; "
+                                                "note": "whole = build + filter in one cvs_pyramid_setup call (level k+1 written by the filter launch of level k), two alternating images; chain_of_five_calls = the same as five cvs_setup_pyr / cvs_setup calls from Python; "
                                                         "filter = five filter launches on a prebuilt pyramid; separate build + filter = filter_ms + pyramid_build_ms"}
             del bigs, lv, hp, fp3
         if ws > 1 and not test_backend:

@@ -82,6 +82,7 @@ SIGNATURES = {
     "cvs_num_frames": (C.c_int, [C.c_void_p, _IP]),
     "cvs_pyr_down": (C.c_int, [C.c_void_p, _PP, _PP]),
     "cvs_setup_pyr": (C.c_int, [C.c_void_p, _PP, C.c_uint, _PP]),
+    "cvs_pyramid_setup": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _PP, C.c_uint, _PP]),
     "cvs_normalize_u8": (C.c_int, [C.c_void_p, _PP, C.c_void_p, C.c_size_t, C.c_int]),
     "cvs_convert_u8": (C.c_int, [C.c_void_p, _PP, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_int]),
     "cvs_normalize_u8_batch": (C.c_int, [C.c_void_p, _PP, C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int]),

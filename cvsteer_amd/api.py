@@ -113,6 +113,31 @@ def _as_input(a):
     return a if a.dtype in (np.float32, np.uint8) else a.astype(np.float32)
 
 
+def pyramid_setup(handles, image, level_images=None, flags=SETUP_BASIS):
+    """BASELINE config 3 in one call (cvs_pyramid_setup): handles[l].setup(level l) for every level of the Gaussian pyramid of
+    `image`, the pyramid built on the way (the filter launch of a level writes the next level).  level_images: the levels - 1 planes that receive levels 1.. (allocated when None).
+    Returns [image, level 1, ...]."""
+    n = len(handles)
+    image = _as_input(image)
+    if level_images is None:
+        level_images, shape = [], tuple(image.shape)
+        for _ in range(n - 1):
+            shape = ((shape[0] + 1) // 2, (shape[1] + 1) // 2)
+            level_images.append(torch.empty(shape, dtype=torch.float32, device=image.device) if _is_torch(image) else np.empty(shape, np.float32))
+    for hnd in handles:
+        hnd._bind_stream(image, *level_images)
+    arr = (C.c_void_p * n)(*[hnd._h for hnd in handles])
+    planes = (Plane * max(1, n - 1))(*[_plane(l) for l in level_images])
+    pi = _plane(image)
+    rc = lib().cvs_pyramid_setup(arr, n, C.byref(pi), int(flags), planes)
+    if rc:
+        raise CvsError(rc, "cvs_pyramid_setup", lib().cvs_last_error(handles[0]._h).decode())
+    for hnd, l in zip(handles, [image] + list(level_images)):
+        hnd._like = l
+        hnd._image_keepalive = l
+    return [image] + list(level_images)
+
+
 class SteerableFilters:
     """fa::SteerableFilters (SteerableFilters.h:41-50): setup(image), steer(theta) -> (g, h)."""
 

@@ -286,6 +286,12 @@ int cvs_pyr_down(cvs_handle h, const cvs_plane* src, const cvs_plane* dst);
  * planes of 2 GiB and more take the two launches internally. */
 int cvs_setup_pyr(cvs_handle h, const cvs_plane* image, unsigned flags, const cvs_plane* next_level);
 
+/* BASELINE config 3 in one call: `levels` handles (one per pyramid level, same device and stream), the level-0 image, and
+ * levels - 1 caller-owned planes that receive the pyramid levels 1 .. levels-1 (sizes as for cvs_pyr_down).  The chain
+ * cvs_setup_pyr(hs[0], image, ..), cvs_setup_pyr(hs[1], level 1, ..), ..., cvs_setup(hs[levels-1], last level): every level
+ * image is read once (the filter launch of a level writes the next one).  Afterwards handle l holds the state of level l. */
+int cvs_pyramid_setup(cvs_handle* hs, int levels, const cvs_plane* image, unsigned flags, const cvs_plane* level_images);
+
 /* per-image min/max (cv::normalize NORM_MINMAX, test.cpp:92-94 / steer.cpp:96-98) and the
  * 8-bit quantise that follows; dst is rows*cols bytes with dst_step bytes per row. */
 int cvs_normalize_u8(cvs_handle h, const cvs_plane* src, uint8_t* dst, size_t dst_step, int dst_mem);

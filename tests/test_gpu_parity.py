@@ -609,6 +609,35 @@ def test_pyramid_5_levels_8192(cv, ora):
             assert np.abs(f.basis(p)[:44].cpu().numpy() - band[p][:44]).max() <= TOL
 
 
+@pytest.mark.parametrize("shape,levels", [((8192, 8192), 5), ((4100, 3001), 4), ((1000, 1500), 3), ((640, 480), 1)])
+def test_pyramid_setup_one_call_equals_the_chain(cv, shape, levels):
+    """cvs_pyramid_setup (config 3 in one call): every level image and every basis / orientation plane of every level equals,
+    bit for bit, the chain of cvs_setup_pyr calls -- repeated on alternating images, so that a stale plane would show"""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(shape[0] + levels)
+    imgs = [torch.rand(shape, device="cuda", generator=gen) for _ in range(2)]
+    hs = [cv.SteerableFiltersG2(None) for _ in range(levels)]
+    ref_h = [cv.SteerableFiltersG2(None) for _ in range(levels)]
+    for rnd in range(3):
+        x = imgs[rnd & 1]
+        lv = cv.pyramid_setup(hs, x, flags=cv.SETUP_FULL)
+        assert len(lv) == levels
+        cur = x
+        for l in range(levels):
+            if l + 1 < levels:
+                nxt = ref_h[l].setup_pyr(cur, flags=cv.SETUP_FULL)
+                assert torch.equal(lv[l + 1], nxt), (rnd, l)
+            else:
+                ref_h[l].setup(cur, flags=cv.SETUP_FULL)
+                nxt = None
+            for p in range(7):
+                assert torch.equal(hs[l].basis(p), ref_h[l].basis(p)), (rnd, l, p)
+            assert torch.equal(hs[l].getDominantOrientationAngle(), ref_h[l].getDominantOrientationAngle()), (rnd, l)
+            cur = nxt
+    with pytest.raises(cv.CvsError):
+        cv.pyramid_setup([hs[0], hs[0]], imgs[0])          # one handle per level
+
+
 # ----------------------------------------------------------------------------- batch axis + CLI driver
 def test_batch_process_frames_single_rank(cv, ora):
     """the per-frame loop of cvsteer_amd.batch with the HIP engine as the frame function (world = 1)"""
