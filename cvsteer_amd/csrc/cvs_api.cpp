@@ -394,7 +394,7 @@ int cvs_set_option(cvs_handle h, int option, int value)
             h->xcd_weights = value;
             return CVS_OK;
         case CVS_OPT_BLOCK_ORDER:
-            if (value < -1 || (value > 1000000 && value != kOrderDynamic && value != kOrderSkewed)) return fail(h, CVS_E_BADARG, "block order");
+            if (value < -1 || (value > 1000000 && value != kOrderDynamic)) return fail(h, CVS_E_BADARG, "block order");
             h->block_order = value;
             return CVS_OK;
         case CVS_OPT_HOST_OVERLAP:

@@ -191,6 +191,10 @@ int init_slot(cvs_batch b, Slot& s)
     B_HIP(b, hipSetDevice(s.device));
     B_HIP(b, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     for (hipEvent_t& e : s.ev) B_HIP(b, hipEventCreate(&e));
+    // the 16 bytes the status agreement of a multi-process world travels in: allocated HERE, where a failure is a clean
+    // create error -- inside agree() a rank that could not allocate them would drop out of the all-reduce and leave its
+    // peers waiting, which is exactly what the agreement exists to prevent
+    B_HIP(b, hipMalloc(&s.agree, 4 * sizeof(int)));
     int rc = cvs_create(b->kind, b->width, b->spacing, s.device, &s.h);
     if (rc != CVS_OK) return fail(b, rc, "cvs_create");
     B_CVS(b, s.h, cvs_set_stream(s.h, s.stream));
@@ -312,20 +316,19 @@ int agree(cvs_batch b, int local_rc, uint32_t geometry_hash)
     int rc = CVS_OK;
     std::string err;
     for (Slot& s : b->slots) {
-        if (hipSetDevice(s.device) != hipSuccess || (!s.agree && hipMalloc(&s.agree, 4 * sizeof(int)) != hipSuccess) ||
-            hipMemcpyAsync(s.agree, mine, sizeof(mine), hipMemcpyHostToDevice, s.stream) != hipSuccess) {
-            // even the agreement cannot be prepared here: take part with an error status if at all possible, so that the
-            // peers do not wait -- without device memory for it there is no way to tell them
+        if (hipSetDevice(s.device) != hipSuccess || hipMemcpyAsync(s.agree, mine, sizeof(mine), hipMemcpyHostToDevice, s.stream) != hipSuccess) {
+            // the status could not be staged: this rank still takes part in the all-reduce below (its peers must not wait),
+            // and reports the failure afterwards
             (void)hipGetLastError();
             rc = CVS_E_HIP;
-            err = "status agreement: no device memory";
+            err = "status agreement: the status could not be staged on the device";
         }
     }
     {
         GroupGuard g(R);
         g.start();
         for (Slot& s : b->slots) {
-            if (!g.ok() || !s.agree) break;
+            if (!g.ok()) break;
             g.hip(hipSetDevice(s.device), "hipSetDevice");
             if (g.ok()) g.nccl(R->AllReduce(s.agree, s.agree, 4, ncclInt32, ncclMin, s.comm, s.stream), "ncclAllReduce");
         }

@@ -13,7 +13,6 @@ constexpr int kMaxWidth = 32;           // generic path: up to 65 taps
 constexpr int kMaxTaps = 2 * kMaxWidth + 1;
 constexpr int kMaxBasis = 11;
 constexpr int kOrderXcdColumns = 1000000;  // BasisArgs::block_order: every XCD owns a contiguous range of column blocks
-constexpr int kOrderSkewed = 3000000;      // BasisArgs::block_order: row-major with the columns rotated by xcd_odd blocks per band
 constexpr int kOrderDynamic = 2000000;     // BasisArgs::block_order: persistent launch, tiles taken from per-XCD queues (tile_ctr)
 
 struct PlaneRef {

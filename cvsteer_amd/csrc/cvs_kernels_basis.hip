@@ -267,13 +267,6 @@ __device__ __forceinline__ bool static_tile(const BasisArgs& a, int& bx, int& by
         by = k / cpx;
         bx = owner * cpx + (k - by * cpx);
         if (bx >= a.grid_x || by >= a.grid_y) return false;
-    } else if (a.block_order == kOrderSkewed) {
-        // plain row-major order with the columns rotated by xcd_odd blocks per band: with 8 | grid_x the plain order has XCD q
-        // filter column blocks q, q + 8, ... of EVERY band, i.e. each XCD writes the same byte ranges of every row for the whole
-        // launch; here the XCD <-> column assignment shifts from band to band
-        const int tl = (int)blockIdx.x;
-        by = tl / a.grid_x;
-        bx = (tl - by * a.grid_x + by * a.xcd_odd) % a.grid_x;
     } else if (a.block_order >= 2) {
         const int T = min(a.block_order, a.grid_y);
         const int per = T * a.grid_x, g = blockIdx.x / per, r = blockIdx.x % per;
@@ -909,9 +902,6 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
         // column blocks to divide evenly (the API layer only picks this order then)
         if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
         grid = dim3(8u * (unsigned)(n_own + a.xcd_steal), 1);
-    } else if (a.block_order == kOrderSkewed) {
-        if (a.xcd_odd < 1 || a.xcd_odd > 16) a.xcd_odd = 1;
-        grid = dim3((unsigned)a.grid_x * a.grid_y, 1);
     } else if (a.block_order >= 2) {
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1);
@@ -1031,9 +1021,6 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
         const int n_own = ((a.grid_x + 7) / 8) * a.grid_y;
         if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
         grid = dim3(8u * (unsigned)(n_own + a.xcd_steal), 1, 2);
-    } else if (a.block_order == kOrderSkewed) {
-        if (a.xcd_odd < 1 || a.xcd_odd > 16) a.xcd_odd = 1;
-        grid = dim3((unsigned)a.grid_x * a.grid_y, 1, 2);
     } else if (a.block_order >= 2) {  // same 1-D band-interleaved walk as launch_fast; z still picks the half bank
         const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
         grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1, 2);

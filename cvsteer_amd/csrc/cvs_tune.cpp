@@ -216,7 +216,7 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     const Cand def{a.block_order, xw0, a.strip_rows, a.g4_split};
     e.cand.assign(1, def);
     auto add = [&](Cand c) {
-        const bool deals = c.order == 1 || c.order == kOrderXcdColumns || c.order == kOrderSkewed;   // orders in which the even : odd shares matter
+        const bool deals = c.order == 1 || c.order == kOrderXcdColumns;   // orders in which the even : odd shares matter
         if (c.order == kOrderDynamic && !a.tile_ctr) return;
         if (c.order != def.order && !free_order) return;
         if (c.strip != def.strip && !free_strip) return;

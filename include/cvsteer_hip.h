@@ -105,7 +105,8 @@ enum {
                                       of pieces straddles the end of a run of the VRAM allocator, that window becomes the block
                                       (such planes stream at ~7.2 instead of ~5.7 TB/s, see cvs_state.cpp); the spare pieces are
                                       released again, else everything is and the block is a plain hipMalloc.  Bounded: at most six
-                                      extra blocks of transient memory and never more than 8 GiB; one search at a time per
+                                      extra blocks of transient memory and never more than 8 GiB per pool (a search that finds nothing
+                                      retries ONCE on a second pool while the first is still held: 16 GiB at the most); one search at a time per
                                       process; none under stream capture; each search keeps its virtual range reserved for the
                                       life of the process (address space only, capped at 4 TiB); a chosen window is verified by
                                       a fill + sampled readback before use and is made accessible to the peer devices of the

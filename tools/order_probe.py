@@ -25,7 +25,7 @@ imgs8 = [torch.rand((n, n), device="cuda") for _ in range(8)]
 img = imgs8[0]
 g, h = torch.empty_like(img), torch.empty_like(img)
 outs = cv.alloc_planes(8, n, n, device="cuda")
-cfgs = {"plain10": (0, 10, 0), "w504_10": (1, 10, 504), "xcdcol10": (1000000, 10, 101), "dyn10": (2000000, 10, 0), "skew1": (3000000, 10, 101), "skew3": (3000000, 10, 103), "skew5": (3000000, 10, 105)}
+cfgs = {"plain10": (0, 10, 0), "w504_10": (1, 10, 504), "xcdcol10": (1000000, 10, 101), "dyn10": (2000000, 10, 0), "plain19": (0, 19, 0)}
 want = set(sys.argv[1:])
 rot = {"i": 0}
 
@@ -66,7 +66,7 @@ for lay in (1,):
 for lay in (0, 1):
     f4 = cv.SteerableFiltersG4(None)
     f4.set_option(L.OPT_STATE_LAYOUT, lay)
-    c4 = {"plain40": (0, 40, 0), "w504_40": (1, 40, 504), "dyn40": (2000000, 40, 0), "skew1": (3000000, 40, 101), "skew3": (3000000, 40, 103)}
+    c4 = {"plain40": (0, 40, 0), "w504_40": (1, 40, 504), "dyn40": (2000000, 40, 0), "plain27": (0, 27, 0), "plain53": (0, 53, 0)}
     run("G4 L%d" % lay, f4, {"M6": (lambda: f4.setup(img), 48), "M6s": (lambda: f4.setup_steer(img, 0.3, out=(g, h)), 56)}, c4)
     del f4
 del imgs8, outs
@@ -83,7 +83,7 @@ for lay in (0, 1):
         alt["i"] ^= 1
         ff.pipeline_batch(fsets[alt["i"]], out=fout)
 
-    cb = {"plain10": (0, 10, 0), "w504_10": (1, 10, 504), "dyn10": (2000000, 10, 0), "skew1": (3000000, 10, 101), "skew3": (3000000, 10, 103), "plain19": (0, 19, 0)}
+    cb = {"plain10": (0, 10, 0), "w504_10": (1, 10, 504), "dyn10": (2000000, 10, 0), "plain19": (0, 19, 0)}
     run("C4 L%d" % lay, ff, {"C4": (c4s, 84)}, cb, rounds=3, steps=6, npix=nfr * 1080 * 1920)
     ff.set_persist(False)
 
