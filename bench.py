@@ -678,7 +678,7 @@ def main():
             leg("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40, pix=4 * npix, steps=bsteps, warm=2, handle=fb)
             # ... and with two images taking turns: the two legs above re-filter ONE 256 MiB image, most of which is still in
             # the 256 MiB Infinity Cache when the next step starts (the streaming stores do not displace it); any launch in
-            # between that touches 64 MiB ends that (tools/c3_between.py), and so does a second image
+            # between that touches 64 MiB ends that (round 2, profiles/r02_issue_and_c3_probes.txt), and so does a second image
             big3 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
             flipb = {"i": 0}
 

@@ -80,7 +80,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     // host planes on the fast path of a large enough image: upload, filtering and download overlap band by band
     // (it pays when a sizeable upload can hide behind the downloads: an f32 host image with host outputs -- measured
     // 3.06 vs 3.70 ms per 4096^2 image; with an 8-bit or device image the downloads alone set the pace and the bands
-    // only add per-copy overhead, 2.98 vs 2.85 ms: tools/host_probe.py)
+    // only add per-copy overhead, 2.98 vs 2.85 ms: round 2, profiles/HISTORY_rounds_1_3.md)
     bool any_host = false;
     for (const cvs_plane* o : {steer ? g : nullptr, steer ? hq : nullptr, po[0], po[1], po[2], po[3], po[4], po[5], po[6], po[7]})
         any_host = any_host || (o && o->mem == CVS_MEM_HOST);
@@ -106,7 +106,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     fill_state_args(h, a, (flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G2);
     a.atan_mode = h->atan_mode;
     // a different input pointer than last time = a stream of fresh images (not resident in the Infinity Cache);
-    // the pipeline variants keep the taller strips (tools/shape_sweep.py)
+    // the pipeline variants keep the taller strips (round 1 shape sweep)
     // (a handle's FIRST call counts as a fresh image too: the reference's callers build one object per image,
     // example/steer.cpp:86 -- only a handle that is handed the same pointer again is re-filtering a resident image)
     const bool fresh = h->last_image != (const void*)image->data && !pipe_outs;
@@ -862,7 +862,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     // state kept: frames from the two halves of the batch in flight together (see k_basis); the stateless launch is bound by
     // the SIMDs and does not care.  CVS_BATCH_WAYS=<n> is a tuning aid (1 = frames in order).
     a.z_ways = (!a.no_state && n >= 4) ? 2 : 1;
-    // ... and on 10-row strips: tools/c4_config_sweep.py, 32 x 1080p, five state blocks of the allocation lottery, one handle
+    // ... and on 10-row strips: round 3 sweep (profiles/r03_c4_strip_probe.txt), 32 x 1080p, five state blocks of the allocation lottery, one handle
     // each: against 19 rows in the plain order 0.634 / 0.70 / 0.70 / 0.796 / 0.795 for 0.644 / 0.70 / 0.70 / 0.762 / 0.764 --
     // level on the slow and middle blocks, +4.5 % on the fast ones; the launch tuner then times the 19-row family and the
     // weighted order (which wins another 3 % on the slow blocks)

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
     // n/2 + 1, ... for two), so that the frames in flight together -- about ten of 1080p -- have their state planes, inputs and
     // outputs in DISTANT parts of the batch's blocks.  Same reason as the placement windows of cvs_state.cpp: planes written
     // together stream faster when they come from two runs of the VRAM allocator than from one, and a 3 GB batch block spans
-    // more than one run.  tools/zways_probe.py, 32 x 1080p, same handles and buffers: a "slow" block 0.677 -> 0.752 of the HBM
+    // more than one run.  profiles/r03_batch_ways_probe.txt, 32 x 1080p, same handles and buffers: a "slow" block 0.677 -> 0.752 of the HBM
     // roofline, a "fast" one 0.717 -> 0.725; four / eight / sixteen parts give less (0.72 / 0.71 / 0.70).
     int bx = 0, by = 0;
     unsigned z = 0;

@@ -1,7 +1,7 @@
 // cvs_state.cpp -- where a handle's state planes live in device memory.
 //
 // Round 1 found the many-plane kernels running at one of "two speeds" depending on the allocation, and sampled
-// whole blocks for a fast one.  Round 2 narrowed it down (tools/frag_probe*.hip, profiles/r02_placement_probes.txt):
+// whole blocks for a fast one.  Round 2 narrowed it down (tools/frag_probe.hip and its round-2 variants, profiles/r02_placement_probes.txt):
 //   * physical pieces that the VRAM allocator hands out one after the other form runs.  Nine planes taken from ONE
 //     run stream at ~5.7 TB/s whatever their spacing, order or padding inside the run; nine planes MIXED from two
 //     runs stream at ~7.2 TB/s (1 plane from the second run: 6.3, 2: 6.9, >= 3: 7.2) -- reproducibly, at the same

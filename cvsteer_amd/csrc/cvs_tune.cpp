@@ -26,25 +26,18 @@ namespace cvs {
 int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input)
 {
     if (h->strip_rows > 0) return h->strip_rows;
-    // strips whose (rows + 2W) is a multiple of the 2W+1-row unroll waste no loop iterations.
-    // Measured on MI355X at 4096x4096 (tools/ab.py, tools/ab_g4.py; streaming stores): short strips
-    // win -- 19 rows for the 7-plane G2 kernel (~14k waves keep every CU's store queues busy, the
-    // extra halo rows are cache hits), 40 rows for the G4 half banks run in one launch.
+    // Heights of k * (2W+1) - 2W rows waste no iteration of the unrolled row loop.  Small images: enough strips for about
+    // 2048 waves.  Large ones:
+    //   G2  10 rows (k = 2): ~14k waves per 4096^2 launch keep every CU's store queues busy, the extra halo rows are cache
+    //       hits, and on a stream of new images vertically adjacent strips must run close in time for their shared rows to
+    //       hit (8 rotating images, round 2: 10-row strips 66 %, 19-row strips 57 %).  19 rows (k = 3) remain the default on a
+    //       placement window (planar planes) and for states the Infinity Cache holds; the tuner compares both heights.
+    //   G4  40 rows (k = 4) for the half banks: the pair launch is close to SIMD-bound, and 27-row strips filter 44 % more
+    //       rows than they write against 30 % (-3..-6 %, profiles/r04_order_probe.txt).
     const int nt = 2 * h->width + 1, halo = 2 * h->width;
     const long strips_x = (cols + 63) / 64;
     const double ideal = (double)rows * (double)strips_x / 2048.0;
     long k = std::lround((ideal + halo) / nt);
-    // launches of >= 32 Mpix are long enough that the shorter strips' faster drain wins (tools/tune.py 8192:
-    // 80.5 vs 77.8 % at 8192x8192, 81.6 vs 77.7 % at 4096x8192)
-    // ... and so do inputs that are not cache-resident: when consecutive calls bring DIFFERENT images, the
-    // halo rows of vertically adjacent strips only hit in cache if those strips run close in time
-    // (tools/ab_rot.py, 8 rotating 4096x4096 inputs: 10-row strips 66 %, 19-row strips 57 %)
-    // G4 half banks: 40-row strips (k = 4) filter 30 % more rows than they write, 27-row strips 44 %; the kernel is
-    // SIMD-bound, so the taller strip wins by 1-3 points (tools/ab_same.py AB_KIND=4 "2=27" "2=40" "2=53", round 2)
-    // ... and so do plain state blocks (the library default; late round 3, tools/ab_same.py on one handle each, two boxes): where
-    // the planes lie in one run of the allocator -- most plain blocks -- the 10-row strips with the tiles dealt 5:4 win every
-    // variant (basis 77 -> 80 %, fused steer 74.6 -> 79.3 %, full setup 70.7 -> 72.9 %, pipeline 67.5 -> 69.6 %); on a placement
-    // window the 19-row strips at 4:3 stay ahead by 1-2 %.  The launch tuner times the other combination on the second call.
     const bool plain_block = !h->sb.vmm && h->sb.base != nullptr && h->num_frames == 1 &&
                              (size_t)rows * cols * sizeof(float) * (size_t)(h->nb + 5) >= ((size_t)256 << 20);   // states the Infinity Cache cannot hold
     const long kmax = h->kind == CVS_KIND_G4 ? 4 : (fresh_input || plain_block || (size_t)rows * cols >= ((size_t)32 << 20)) ? 2 : 3;
@@ -53,7 +46,7 @@ int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input)
     return (int)(k * nt - halo);
 }
 
-// Streaming (nontemporal) stores: measured on MI355X (tools/membench.hip), "1 plane in, 7 out"
+// Streaming (nontemporal) stores: "1 plane in, 7 out" (tools/membench.hip, profiles/r01_membench.txt)
 // reaches ~5.9 TB/s with nt stores vs ~4.0 TB/s with plain stores once the planes no longer fit
 // the 256 MiB Infinity Cache.  Small frames whose whole state stays cache-resident keep plain
 // stores so the next per-pixel kernel finds them on die.
@@ -69,9 +62,10 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // Launch configuration: defaults, and the ONLINE comparison of a few alternatives on the caller's own launches.
 //
 // What a basis launch leaves open is the order in which its tiles are dealt to the chip (block_order / XCD shares), the strip
-// height and, for G4, the bank layout.  Which combination is fastest depends on the BOX (round 4, three boxes, same handles:
-// the XCD-weighted order +5 % for the full setup on two of them and -4 % for the pipeline on the third; the XCD-column order
-// best on one, worst on another), so a short list is compared where the code runs.  Rounds 2-3 did that with a burst of
+// height and, for G4, the bank layout.  Which combination is fastest depends on the box and -- more -- on the PROCESS, i.e. on
+// where the allocator put the planes (round 4, six processes on one box, profiles/r04_order_probe.txt: the XCD-weighted order
+// +5 % for the 12- and 20-plane launches in two of them, -4..-7 % in the other four; the XCD-column order best for the basis
+// pass everywhere and worst for the pipeline in some), so a short list is compared where the code runs.  Rounds 2-3 did that with a burst of
 // ~250 extra launches on the second call of a shape -- 25-30 ms during which the caller's stream stalled and the caller's
 // output planes were rewritten over and over.  Since round 4 NOTHING extra is launched: while a shape is being tuned, each of
 // the caller's own calls runs one candidate, bracketed by a pair of events on the caller's stream; candidates take turns in
@@ -107,7 +101,7 @@ typedef std::tuple<int, int, int, int, int, int, int> TuneKey;
 static std::mutex g_tune_mutex;
 static std::map<TuneKey, TuneEntry> g_tune;          // node-based: TuneEntry* stays valid
 static std::vector<Sample> g_samples;                // in flight
-static std::vector<hipEvent_t> g_free_events;        // timing events are recycled, never destroyed while the process lives
+static std::map<int, std::vector<hipEvent_t>> g_free_events;   // per device: timing events are recycled, never destroyed while the process lives
 
 constexpr int kBlock = 3, kRounds = 2;
 
@@ -142,8 +136,8 @@ static void harvest()
         }
         (void)hipGetLastError();
         --e.pending;
-        g_free_events.push_back(sm.e0);
-        g_free_events.push_back(sm.e1);
+        g_free_events[sm.device].push_back(sm.e0);
+        g_free_events[sm.device].push_back(sm.e1);
         g_samples[i] = g_samples.back();
         g_samples.pop_back();
         if (e.done_issuing && e.pending == 0 && e.chosen < 0) {
@@ -163,11 +157,12 @@ static void harvest()
     }
 }
 
-static hipEvent_t take_event()
+static hipEvent_t take_event(int device)   // the caller has made `device` current
 {
-    if (!g_free_events.empty()) {
-        hipEvent_t e = g_free_events.back();
-        g_free_events.pop_back();
+    std::vector<hipEvent_t>& pool = g_free_events[device];
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
         return e;
     }
     hipEvent_t e = nullptr;
@@ -273,12 +268,13 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     (void)hipGetLastError();
     std::lock_guard<std::mutex> lock(g_tune_mutex);
     if (!capturing) harvest();
-    if (!capturing && g_tune.empty()) {
-        // the process's first tunable launch (it also pays for the state allocation): a few timing events ahead of need, so
-        // that no later call creates one on its way to the launch
+    if (!capturing && g_free_events.find(h->device) == g_free_events.end()) {
+        // the first tunable launch on this device (it also pays for the state allocation): a few timing events ahead of need,
+        // so that no later call creates one on its way to the launch
+        std::vector<hipEvent_t>& pool = g_free_events[h->device];
         for (int i = 0; i < 8; ++i) {
             hipEvent_t ev = nullptr;
-            if (hipEventCreate(&ev) == hipSuccess) g_free_events.push_back(ev);
+            if (hipEventCreate(&ev) == hipSuccess) pool.push_back(ev);
             else (void)hipGetLastError();
         }
     }
@@ -293,15 +289,15 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     apply(a, e.cand[c], xw_pinned != 0);
     const bool counted = e.in_block > 0;    // a configuration's first launch after a change is not representative
     if (counted) {
-        hipEvent_t e0 = take_event(), e1 = take_event();
+        hipEvent_t e0 = take_event(h->device), e1 = take_event(h->device);
         if (e0 && e1 && hipEventRecord(e0, h->stream) == hipSuccess) {
             tok.e0 = e0;
             tok.e1 = e1;
             tok.entry = &e;
             tok.cand = c;
         } else {
-            if (e0) g_free_events.push_back(e0);
-            if (e1) g_free_events.push_back(e1);
+            if (e0) g_free_events[h->device].push_back(e0);
+            if (e1) g_free_events[h->device].push_back(e1);
             (void)hipGetLastError();
         }
     }
@@ -325,8 +321,8 @@ void tune_end(cvs_handle h, const TuneToken& tok)
         ++e->pending;
     } else {
         (void)hipGetLastError();
-        g_free_events.push_back(tok.e0);
-        g_free_events.push_back(tok.e1);
+        g_free_events[h->device].push_back(tok.e0);
+        g_free_events[h->device].push_back(tok.e1);
     }
     if (e->done_issuing && e->pending == 0 && e->chosen < 0) e->chosen = 0;   // every sample failed to record: the default it is
 }
@@ -342,7 +338,7 @@ void note_launch(cvs_handle h, const BasisArgs& a)
 }
 
 // Frame batches (cvs_pipeline_batch with state kept; BASELINE config 4), opt-in with CVS_OPT_PLACEMENT_SEARCH = 1: which
-// plain block the batch state lives in decides the launch's speed by 7-9 % (tools/r3_probe.py c4modes: eight blocks of 3.2 GB
+// plain block the batch state lives in decides the launch's speed by 7-9 % (profiles/r03_c4_modes_probe.txt: eight blocks of 3.2 GB
 // allocated one after the other in one process, the same frames and outputs -- blocks 0 and 5..7 run the launch at 0.73 of
 // the HBM roofline, blocks 1..4 at 0.67-0.68, the same in every process: runs of the VRAM allocator again, see cvs_state.cpp).
 // The per-plane windows of cvs_state.cpp do not fit a batch (hundreds of small planes), but the question can be put to the

@@ -97,6 +97,7 @@ def test_config4_batched_pipeline_32x1080p_state_kept_and_outputs_only(cv, ora):
         assert single.launch_info()["nt_stores"] == 0       # the single 1080p frame stays under the streaming threshold
         for k in range(8):
             assert torch.equal(out[i, k], ref[k]), (i, k)
+    basis_err = {}
     for i in (0, 15, 31):
         eng.select_frame(i)
         img = frames[i].cpu().numpy()
@@ -107,7 +108,9 @@ def test_config4_batched_pipeline_32x1080p_state_kept_and_outputs_only(cv, ora):
             sl = slice(lo, hi)
             b = np.stack([s[sl].cpu().numpy() for s in state])
             assert np.abs(b - _oracle_basis_rows(ora, img, lo, hi)).max() <= TOL, (i, lo)
-            assert np.abs(b - _oracle_basis_rows(ora, img, lo, hi, f64=False)).max() <= TOL, (i, lo)
+            d32 = float(np.abs(b - _oracle_basis_rows(ora, img, lo, hi, f64=False)).max())
+            assert d32 <= TOL, (i, lo)
+            basis_err[(i, lo)] = d32      # how far the GPU's basis planes are from the oracle's on this band (used below)
             _check_pipeline_rows(ora, b, tuple(c[sl].cpu().numpy() for c in coeff), th[sl].cpu().numpy(), st[sl].cpu().numpy(),
                                  [out[i, k][sl].cpu().numpy() for k in range(8)], ("state kept", i, lo))
     # outputs only (what example/steer.cpp keeps): the stateless instance, same values
@@ -126,11 +129,25 @@ def test_config4_batched_pipeline_32x1080p_state_kept_and_outputs_only(cv, ora):
             o1, o2, o3, oth, ost = ora.g2_orientation(b32)
             og, oh, oe, om, op = ora.g2_steer_map(b32, oth, (o1, o2, o3))
             got = [fo3[i, k][lo:hi].cpu().numpy() for k in range(3)]
-            # compare where the chain is well conditioned: away from the phase-weight gates nothing amplifies the <= 1e-6
-            # differences of the basis planes beyond the stated tolerance
+            # The chain basis -> C2, C3 -> theta_dom -> (g2, h2) at theta_dom -> magnitude, phase -> magnitude * lambda(phase)
+            # amplifies a basis difference d_b per pixel as follows (first order, worst-case coefficients):
+            #   |dC2|, |dC3| <= 5.75 * 2 * bmax * d_b            (C3 of G2.cpp:95: coefficient sum 5.75, products of two planes)
+            #   |dtheta|     <= 0.5 * sqrt(2) * |dC| / strength   (theta = atan2(C3, C2) / 2; the cut at +-pi/2 flips h2's sign only,
+            #                                                      and the three maps are even in the phase)
+            #   |dg|, |dh|   <= 4 d_b + 12 * bmax * |dtheta|      (sum of |weights| <= 4; |d weights / d theta| <= 3 per plane, 4 planes)
+            #   |d out|      <= sqrt(2) |dg| + mag * |dphase|, mag * |dphase| <= |dg|   (lambda = cos^2, gated continuously: |lambda'| <= 1)
+            # i.e. bound(pixel) = 2.5 * d_b * (4 + 98 * bmax^2 / strength) -- inversely proportional to the orientation strength,
+            # which is why a single constant only ever held on "well conditioned" pixels.  d_b = the measured distance of the
+            # GPU's basis planes from the oracle's on this band (<= 1e-5 asserted above, ~5e-7 in practice) + one f32 ulp of the
+            # epilogue's own arithmetic.  Held on EVERY pixel with strength and magnitude above 1e-3.
+            bmax = float(np.abs(b32).max())
+            d_b = basis_err[(i, lo)] + 2e-7 * max(1.0, bmax)
+            bound = 2.5 * d_b * (4.0 + 98.0 * bmax * bmax / np.maximum(ost, 1e-3))
+            ok = (ost > 1e-3) & (om > 1e-3)
             for gk, want in zip(got, ora.find(om, op)):
-                ok = (ost > 1e-2) & (om > 1e-2)
-                assert np.abs(gk - want)[ok].max() <= 5e-4, (i, lo)
+                assert (np.abs(gk - want)[ok] <= bound[ok]).all(), (i, lo, float((np.abs(gk - want) / bound)[ok].max()))
+                well = (ost > 1e-2) & (om > 1e-2)      # ... and the constant of rounds 1-3 where the chain is well conditioned
+                assert np.abs(gk - want)[well].max() <= 5e-4, (i, lo)
 
 
 def test_headline_fused_filter_steer_4096_streaming(cv, ora):
