@@ -322,8 +322,9 @@ def main():
         f.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
     if args.strip_rows:
         f.set_strip_rows(args.strip_rows)
-    g = torch.empty_like(img)
-    h = torch.empty_like(img)
+    # the two output planes as the Python API itself allocates them when the caller passes none: rows of one block
+    # ([row][plane][column], cv.alloc_planes), strided views like any cv::Mat ROI
+    g, h = cv.alloc_planes(2, ROWS, COLS, device=dev)
     npix = ROWS * COLS
 
     # ---- headline: filter + steer (M2), one fused launch per step ----
@@ -414,6 +415,7 @@ def main():
                    "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective",
                    "init_calls": INIT_CALLS, "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process"),
                    "library_defaults": not args.placement and not args.strip_rows,
+                   "output_planes": "g, h = cv.alloc_planes(2, rows, cols): rows of one block, what setup_steer() allocates by itself",
                    "placement": {"mode": info["placement_mode"], "window_found": bool(info["window_found"]), "probe_ms": round(info["probe_ms"], 3),
                                  "note": "CVS_OPT_PLACEMENT_SEARCH of the headline handle; 0 = plain hipMalloc block, the library default "
                                          "(the opt-in search is reported as extra.M2_placement_window)"},
