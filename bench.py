@@ -36,10 +36,10 @@ THETA = 0.3
 BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56, "M2_u8": 37, "C4_u8_feat3": 13}
 # Everything here runs on the library's DEFAULTS (round 4): plain hipMalloc state block, row-interleaved state planes, the
 # online launch tuner.  The tuner compares a handful of launch configurations on the caller's own calls (no extra launches):
-# a new (handle kind, entry point, shape) needs about 40 calls to settle, which every leg makes before its timed region
+# a new (handle kind, entry point, shape) needs 40-55 calls to settle, which every leg makes before its timed region
 # (SETTLE_CALLS).  The allocation-time placement search stays an opt-in knob of the library; `extra.M2_placement_window`
 # shows what it is worth on the box the run landed on.  `M2_untuned` = CVS_OPT_AUTOTUNE 0.
-SETTLE_CALLS = 44
+SETTLE_CALLS = 60
 INIT_CALLS = SETTLE_CALLS
 EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
 EXIT_LEGS_FAILED = 5  # a secondary leg raised: headline + the legs finished so far are printed first

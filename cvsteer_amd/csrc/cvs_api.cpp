@@ -151,6 +151,10 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         const int variant = (orient_k ? 1 : 0) | (steer ? 2 : 0) | (a.pipe ? 4 : 0) | (a.no_state ? 8 : 0);
         TuneToken tok;
         if ((rc = tune_begin(h, a, variant, fresh, tok))) return rc;
+        if ((a.merge_orient != 0) != (h->ngrp == 1 && h->kind == CVS_KIND_G2)) {   // the configuration wants the other grouping of the planes
+            layout_state(h, a.merge_orient != 0);
+            fill_state_args(h, a, orient_k);
+        }
         note_launch(h, a);
         const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, scr, h->stream);
         tune_end(h, tok);

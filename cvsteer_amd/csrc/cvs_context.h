@@ -32,6 +32,7 @@ struct cvs_context {
     PlaneGroup grp[3];
     int ngrp = 0;
     size_t dense_pitch = 0;                  // round_up(cols, 64): the length of one row of one plane
+    size_t layout_stride = 0;                // planar form: plane to plane (the block's plane stride)
     float* state = nullptr;      // = sb.base
     size_t state_elems = 0;      // = sb.elems
     StateBlock sb;               // owner of the state memory (cvs_state.cpp)
@@ -150,6 +151,7 @@ void pool_release_all();
 void release_state(cvs_handle h);
 bool state_interleaved(cvs_handle h, int rows, size_t dense_pitch);
 int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1);
+void layout_state(cvs_handle h, bool merge_orient);   // (re)lays the planes out inside the block; ensure_state leaves the two-group form
 
 // ---- cvs_tune.cpp ----
 int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input = false);

@@ -275,7 +275,7 @@ void fill_state_args(cvs_handle h, BasisArgs& a, bool orient)
         a.pitch2 = g1.pitch;
         a.plane_stride2 = g1.stride;
     }
-    const cvs_context::PlaneGroup& go = h->grp[h->ngrp - 1];
+    const cvs_context::PlaneGroup& go = state_group(h, h->nb);   // the orientation planes' group (group 0 itself when merged)
     a.orient = orient ? state_plane(h, h->nb) : nullptr;
     a.orient_pitch = go.pitch;
     a.orient_stride = go.stride;
@@ -389,6 +389,48 @@ void release_state(cvs_handle h)
     h->state_elems = 0;
 }
 
+// Where the planes of the current geometry (h->rows, h->dense_pitch, h->layout_stride) lie inside a frame's block.
+// merge_orient (G2, interleaved layout): the five orientation planes join the basis planes in ONE group of twelve -- a full
+// setup or a pipeline launch then writes one sweep instead of two.  Which of the two is faster depends on the process: two
+// groups run the 12-plane launch at 0.755 or at 0.854 of the HBM roofline depending on where the allocator put the block,
+// one group at 0.81-0.82 either way (profiles/r04_groups_probe.txt), so the launch tuner compares them on the spot for the
+// launches that write orientation planes (cvs_tune.cpp); a basis-only launch always uses the two-group form (dense stream).
+void layout_state(cvs_handle h, bool merge_orient)
+{
+    const size_t pitch = h->dense_pitch, stride = h->layout_stride;
+    const int rows = h->rows;
+    const bool inter = state_interleaved(h, rows, pitch) && !h->sb.vmm;
+    // groups: G2 = 7 basis planes | 5 orientation planes; G4 = the 5 G planes | the 6 H planes | 5 orientation planes (the
+    // half banks of the G4 pair launch write one group each, so each of them streams a dense sweep as well)
+    int counts[3] = {h->kind == CVS_KIND_G4 ? 5 : h->nb, h->kind == CVS_KIND_G4 ? 6 : 5, 5};
+    h->ngrp = h->kind == CVS_KIND_G4 ? 3 : 2;
+    const bool merged = merge_orient && inter && h->kind == CVS_KIND_G2;
+    if (merged) {
+        counts[0] = h->nb + 5;
+        h->ngrp = 1;
+    }
+    size_t off = 0;
+    int first = 0;
+    for (int g = 0; g < h->ngrp; ++g) {
+        cvs_context::PlaneGroup& G = h->grp[g];
+        G.first = first;
+        G.count = counts[g];
+        G.off = off;
+        if (inter) {
+            G.pitch = pitch * G.count;
+            G.stride = pitch;
+            off += round_up(pitch * rows * G.count, 64);   // <= stride * count: the block holds it
+        } else {
+            G.pitch = pitch;
+            G.stride = stride;
+            off += stride * G.count;
+        }
+        first += G.count;
+    }
+    h->frame_stride = off;
+    h->last.state_layout = !inter ? 0 : merged ? 2 : 1;
+}
+
 // row-interleaved state planes (CVS_OPT_STATE_LAYOUT = 1, the default) while a whole group of planes stays below 2 GiB, i.e.
 // within the 32-bit buffer offsets of one launch (larger states -- 8192^2 G4, 16384^2 G2 -- stay planar and are banded)
 bool state_interleaved(cvs_handle h, int rows, size_t dense_pitch)
@@ -461,31 +503,8 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes)
     // groups, basis and orientation, so that a basis-only setup writes a dense stream too.  On plain blocks, same handles
     // side by side: basis 0.76 -> 0.80, fused steer 0.70 -> 0.80, full setup 0.65 -> 0.82, pipeline 0.66 -> 0.73 of the HBM
     // roofline, fresh images +4-5 points.  Per-plane windows (the opt-in placement search) keep the planar form.
-    const bool inter = state_interleaved(h, rows, pitch) && !h->sb.vmm;
-    // groups: G2 = 7 basis planes | 5 orientation planes; G4 = the 5 G planes | the 6 H planes | 5 orientation planes (the
-    // half banks of the G4 pair launch write one group each, so each of them streams a dense sweep as well)
-    const int counts[3] = {h->kind == CVS_KIND_G4 ? 5 : h->nb, h->kind == CVS_KIND_G4 ? 6 : 5, 5};
-    h->ngrp = h->kind == CVS_KIND_G4 ? 3 : 2;
-    size_t off = 0;
-    int first = 0;
-    for (int g = 0; g < h->ngrp; ++g) {
-        cvs_context::PlaneGroup& G = h->grp[g];
-        G.first = first;
-        G.count = counts[g];
-        G.off = off;
-        if (inter) {
-            G.pitch = pitch * G.count;
-            G.stride = pitch;
-            off += round_up(pitch * rows * G.count, 64);   // <= stride * count: the block holds it
-        } else {
-            G.pitch = pitch;
-            G.stride = stride;
-            off += stride * G.count;
-        }
-        first += G.count;
-    }
-    h->frame_stride = off;
-    h->last.state_layout = inter ? 1 : 0;
+    h->layout_stride = stride;
+    layout_state(h, false);
     h->num_frames = nframes;
     if (h->cur_frame >= nframes) h->cur_frame = 0;
     return CVS_OK;

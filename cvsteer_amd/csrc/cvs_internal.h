@@ -55,6 +55,7 @@ struct BasisArgs {
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
+    int merge_orient;     // host only (cvs_tune.cpp -> do_setup): lay the G2 orientation planes out in one group with the basis planes
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
     int out_row_lo, out_row_hi;    // caller: compute output rows [out_row_lo, out_row_hi) only (0, 0 = the whole image);
                                    // the band-split of one large image over several GPUs (cvs_setup_rows)

@@ -77,7 +77,8 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // ---------------------------------------------------------------------------------------------------------------------
 struct Cand {
     int order, xw, strip, split;
-    bool operator==(const Cand& o) const { return order == o.order && xw == o.xw && strip == o.strip && split == o.split; }
+    int merge = 0;   // G2 launches that write orientation planes: one 12-plane group instead of basis | orientation (cvs_handle.cpp layout_state)
+    bool operator==(const Cand& o) const { return order == o.order && xw == o.xw && strip == o.strip && split == o.split && merge == o.merge; }
 };
 
 struct TuneEntry {
@@ -114,6 +115,7 @@ static void apply(BasisArgs& a, const Cand& c, bool xw_pinned)
     }
     a.strip_rows = c.strip;
     a.g4_split = c.split;
+    a.merge_orient = c.merge;
 }
 
 // read back every sample whose launch has finished (never waits); decide entries that are complete.  g_tune_mutex held.
@@ -149,7 +151,7 @@ static void harvest()
             if (std::getenv("CVS_TUNE_VERBOSE")) {
                 std::fprintf(stderr, "[cvsteer] tuned on the caller's launches:");
                 for (size_t c = 0; c < e.cand.size(); ++c)
-                    std::fprintf(stderr, " (order %d, xcd %d, strip %d, split %d) %.4f ms x%d", e.cand[c].order, e.cand[c].xw, e.cand[c].strip, e.cand[c].split,
+                    std::fprintf(stderr, " (order %d, xcd %d, strip %d, split %d, merged %d) %.4f ms x%d", e.cand[c].order, e.cand[c].xw, e.cand[c].strip, e.cand[c].split, e.cand[c].merge,
                                  e.nsamp[c] ? e.best[c] : 0.f, e.nsamp[c]);
                 std::fprintf(stderr, " -> candidate %d\n", best);
             }
@@ -235,7 +237,7 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
             add({0, xw0, sr_short, def.split});
         } else {
             const bool strips = (size_t)a.rows * a.cols < ((size_t)32 << 20);
-            add({kOrderDynamic, xw0, sr_short, def.split});     // persistent launch, tiles taken from per-XCD queues: balances itself
+            add({kOrderDynamic, xw0, sr_short, def.split});     // the tail handed out from per-XCD queues: an XCD that is ahead helps the others
             add({1, 504, sr_short, def.split});                 // more tiles for the faster XCDs: wins where the XCDs differ
             add({kOrderXcdColumns, 101, sr_short, def.split});  // every XCD its own column range: best for the basis pass on some boxes
             add({0, xw0, sr_short, def.split});
@@ -247,6 +249,17 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
         add({1, xw0, def.strip, def.split});
         add({def.order, xw0, def.strip, 0});               // one 11-plane kernel instead of the two half banks
         add({def.order, xw0, 5 * nt - halo, def.split});   // the taller strip (53 rows at width 6): ahead by 1.5 % in some processes, behind in others
+    }
+    // G2 launches that write the orientation planes too (full setup, pipeline), row-interleaved state, single image: the same
+    // three leading configurations with ALL twelve planes in one group -- steadier (0.81-0.82 for the full setup in every
+    // process) where two groups are either faster (0.85) or slower (0.755) depending on where the block lies
+    if (h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0 && h->last.state_layout != 0 && h->layout == 1) {
+        const size_t n0 = std::min<size_t>(e.cand.size(), 3);
+        for (size_t i = 0; i < n0 && e.cand.size() < 9; ++i) {
+            Cand m = e.cand[i];
+            m.merge = 1;
+            e.cand.push_back(m);
+        }
     }
     e.best.assign(e.cand.size(), std::numeric_limits<float>::max());
     e.nsamp.assign(e.cand.size(), 0);

@@ -199,7 +199,8 @@ typedef struct cvs_launch_info {
     int32_t strip_rows;       /* ... output rows per wave strip */
     int32_t nt_stores;        /* ... 1 = streaming (nontemporal) stores */
     int32_t g4_split;         /* ... CVS_OPT_G4_SPLIT value in effect */
-    int32_t state_layout;     /* layout of the current state block: 0 = planar, 1 = row-interleaved (CVS_OPT_STATE_LAYOUT) */
+    int32_t state_layout;     /* layout of the current state block: 0 = planar, 1 = row-interleaved groups (CVS_OPT_STATE_LAYOUT),
+                                 2 = row-interleaved with the G2 orientation planes in the basis planes' group (the tuner's choice) */
     int32_t tuning_launches;  /* launches the engine has issued on this handle's stream beyond the caller's own calls
                                  (always 0 since round 4: configurations are compared on the caller's launches) */
 } cvs_launch_info;
