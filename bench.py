@@ -102,6 +102,7 @@ def _spawn_ranks(n):
 def _time_steps(torch, fn, steps, warmup, barrier, repeats=1):
     """W untimed warm-ups, then R regions of exactly K steps, each between barrier + synchronize on both sides;
     returns ([wall seconds per region], [HIP-event milliseconds per region, on the launch stream])."""
+    import gc
     for _ in range(warmup):
         fn()
     walls, evs = [], []
@@ -109,6 +110,10 @@ def _time_steps(torch, fn, steps, warmup, barrier, repeats=1):
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        # a generation-2 collection of the interpreter (tens of milliseconds with torch + numpy loaded) inside a region of
+        # 0.1-1 ms steps starves the GPU and shows up as a 10x outlier of that repeat: collect now, not in there
+        gc.collect()
+        gc.disable()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
@@ -118,6 +123,7 @@ def _time_steps(torch, fn, steps, warmup, barrier, repeats=1):
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
+        gc.enable()
         walls.append(t1 - t0)
         evs.append(ev0.elapsed_time(ev1))
     return walls, evs

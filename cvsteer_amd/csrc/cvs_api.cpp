@@ -296,7 +296,7 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
     // example/steer.cpp:86, and a hipMalloc + hipFree pair per object costs ~20 us of the ~150 us such an object lives;
     // the 8 bytes of min / max scratch are allocated by the first 8-bit conversion that needs them)
     if (const char* e = std::getenv("CVS_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
-    if (const char* e = std::getenv("CVS_STATE_LAYOUT")) h->layout = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CVS_STATE_LAYOUT")) h->layout = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("CVS_PYR_STRIP")) h->pyr_strip = std::atoi(e) != 0;
     if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::max(0, std::min(2, std::atoi(e)));  // opt-in for new handles
     *out = h;
@@ -406,7 +406,7 @@ int cvs_set_option(cvs_handle h, int option, int value)
             h->host_overlap = value;
             return CVS_OK;
         case CVS_OPT_STATE_LAYOUT:
-            if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "state layout");
+            if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "state layout");
             h->layout = value;
             return CVS_OK;
     }

@@ -151,6 +151,7 @@ void pool_release_all();
 void release_state(cvs_handle h);
 bool state_interleaved(cvs_handle h, int rows, size_t dense_pitch);
 int ensure_state(cvs_handle h, int rows, int cols, int nframes = 1);
+bool state_merge_fits(cvs_handle h, int rows, size_t dense_pitch);
 void layout_state(cvs_handle h, bool merge_orient);   // (re)lays the planes out inside the block; ensure_state leaves the two-group form
 
 // ---- cvs_tune.cpp ----

@@ -395,6 +395,12 @@ void release_state(cvs_handle h)
 // groups run the 12-plane launch at 0.755 or at 0.854 of the HBM roofline depending on where the allocator put the block,
 // one group at 0.81-0.82 either way (profiles/r04_groups_probe.txt), so the launch tuner compares them on the spot for the
 // launches that write orientation planes (cvs_tune.cpp); a basis-only launch always uses the two-group form (dense stream).
+// twelve planes in one group must still lie within the 32-bit buffer offsets of one launch
+bool state_merge_fits(cvs_handle h, int rows, size_t dense_pitch)
+{
+    return h->kind == CVS_KIND_G2 && (size_t)rows * dense_pitch * sizeof(float) * (size_t)(h->nb + 5) <= (size_t)0x7ffffff0;
+}
+
 void layout_state(cvs_handle h, bool merge_orient)
 {
     const size_t pitch = h->dense_pitch, stride = h->layout_stride;
@@ -404,7 +410,7 @@ void layout_state(cvs_handle h, bool merge_orient)
     // half banks of the G4 pair launch write one group each, so each of them streams a dense sweep as well)
     int counts[3] = {h->kind == CVS_KIND_G4 ? 5 : h->nb, h->kind == CVS_KIND_G4 ? 6 : 5, 5};
     h->ngrp = h->kind == CVS_KIND_G4 ? 3 : 2;
-    const bool merged = merge_orient && inter && h->kind == CVS_KIND_G2;
+    const bool merged = merge_orient && inter && h->kind == CVS_KIND_G2 && state_merge_fits(h, rows, pitch);
     if (merged) {
         counts[0] = h->nb + 5;
         h->ngrp = 1;
@@ -435,7 +441,7 @@ void layout_state(cvs_handle h, bool merge_orient)
 // within the 32-bit buffer offsets of one launch (larger states -- 8192^2 G4, 16384^2 G2 -- stay planar and are banded)
 bool state_interleaved(cvs_handle h, int rows, size_t dense_pitch)
 {
-    return h->layout == 1 && (size_t)rows * dense_pitch * sizeof(float) * (size_t)(h->kind == CVS_KIND_G4 ? 6 : 7) <= (size_t)0x7ffffff0;
+    return h->layout >= 1 && (size_t)rows * dense_pitch * sizeof(float) * (size_t)(h->kind == CVS_KIND_G4 ? 6 : 7) <= (size_t)0x7ffffff0;
 }
 
 int ensure_state(cvs_handle h, int rows, int cols, int nframes)

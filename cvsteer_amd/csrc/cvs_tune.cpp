@@ -182,6 +182,8 @@ static bool default_config(cvs_handle h, BasisArgs& a, int variant, bool fresh_i
     a.xcd_even = xw_pinned ? xw_pinned / 100 : 5;
     a.xcd_odd = xw_pinned ? xw_pinned % 100 : 4;
     a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
+    // CVS_OPT_STATE_LAYOUT = 2 pins the grouping: launches that write orientation planes use ONE group of twelve planes
+    a.merge_orient = (h->layout == 2 && h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0) ? 1 : 0;
     const bool fast = basis_fast_path(h->kind, h->width, h->taps);
     const bool big = (size_t)a.rows * a.cols >= ((size_t)1 << 20);
     // the plain row-major order: with the row-interleaved state it is within a few per cent of the best order on every box
@@ -210,7 +212,7 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     const bool free_strip = h->strip_rows <= 0 && (a.batch == 0 || !a.no_state);
     const bool free_split = h->kind == CVS_KIND_G4 && h->g4_split < 0;
     const int xw0 = a.xcd_even * 100 + a.xcd_odd;
-    const Cand def{a.block_order, xw0, a.strip_rows, a.g4_split};
+    const Cand def{a.block_order, xw0, a.strip_rows, a.g4_split, a.merge_orient};
     e.cand.assign(1, def);
     auto add = [&](Cand c) {
         const bool deals = c.order == 1 || c.order == kOrderXcdColumns;   // orders in which the even : odd shares matter
@@ -220,6 +222,7 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
         if (c.split != def.split && !free_split) return;
         if (deals && xw_pinned) c.xw = xw0;
         if (!deals) c.xw = xw0;
+        c.merge = def.merge;
         const int grid_x = ((a.cols + 63) / 64 + 3) / 4;
         if (c.order == kOrderXcdColumns && (grid_x % 8 != 0 || a.batch != 0)) return;
         for (const Cand& k : e.cand)
@@ -253,7 +256,8 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     // G2 launches that write the orientation planes too (full setup, pipeline), row-interleaved state, single image: the same
     // three leading configurations with ALL twelve planes in one group -- steadier (0.81-0.82 for the full setup in every
     // process) where two groups are either faster (0.85) or slower (0.755) depending on where the block lies
-    if (h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0 && h->last.state_layout != 0 && h->layout == 1) {
+    if (h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0 && h->last.state_layout != 0 && h->layout == 1 &&
+        state_merge_fits(h, a.rows, h->dense_pitch)) {
         const size_t n0 = std::min<size_t>(e.cand.size(), 3);
         for (size_t i = 0; i < n0 && e.cand.size() < 9; ++i) {
             Cand m = e.cand[i];
@@ -273,7 +277,7 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     const bool free_any = h->block_order < 0 || h->strip_rows <= 0 || (h->kind == CVS_KIND_G4 && h->g4_split < 0);
     if (!free_any) return CVS_OK;
     const int xw_pinned = h->xcd_weights;
-    const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->g4_split >= 0 ? 1 : 0) + (h->last.state_layout ? 4 : 0);
+    const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->g4_split >= 0 ? 1 : 0) + (h->last.state_layout ? 4 : 0) + (h->layout << 3);
     const TuneKey key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->sb.vmm ? 1024 : 0) | (h->kind << 12) | (pins << 16) | (a.in_u8 << 20),
                                         a.rows, a.cols, xw_pinned, h->block_order, a.batch);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

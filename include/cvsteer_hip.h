@@ -125,7 +125,11 @@ enum {
                                   one stream per plane 64 MiB apart, and runs 5-25 % faster on a plain block; every
                                   plane is still an ordinary strided image (cvs_state_plane: step = planes x row length).  0 =
                                   planar, plane after plane (rounds 1-3; also what per-plane placement windows and groups of
-                                  2 GiB and more use).  Takes effect at the next cvs_setup*; results do not depend on it.  Also
+                                  2 GiB and more use).  With 1 the engine also decides, by comparing both on the caller's launches,
+                                  whether a G2 launch that writes the orientation planes keeps them in a group of their own or
+                                  puts all twelve planes into one group (steadier across allocations; cvs_launch_info.state_layout
+                                  = 2 when it does); 2 = always one group of twelve for those launches.
+                                  Takes effect at the next cvs_setup*; results do not depend on it.  Also
                                   CVS_STATE_LAYOUT in the environment (new handles). */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
                                 launch (blockIdx.z picks the half); -1 (default) = 2, or 0 where the autotuner finds it faster */

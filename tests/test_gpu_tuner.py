@@ -131,12 +131,25 @@ def test_state_layouts_give_identical_planes(cv):
         img = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
         for cls, nb in ((cv.SteerableFiltersG2, 7), (cv.SteerableFiltersG4, 11)):
             hs = []
-            for lay in (0, 1):
+            for lay in (0, 1, 2):
                 f = cls(None)
                 f.set_option(L.OPT_STATE_LAYOUT, lay)
                 f.setup(img)
-                assert f.launch_info()["state_layout"] == lay
+                # 2 = all twelve G2 planes in one group (what the tuner may also choose by itself); G4 has no such form
+                assert f.launch_info()["state_layout"] == (lay if nb == 7 else min(lay, 1))
                 hs.append(f)
+            for p in range(nb):
+                assert torch.equal(hs[0].basis(p), hs[2].basis(p)), (shape, p, "merged")
+            if nb == 7:
+                assert torch.equal(hs[0].getDominantOrientationAngle(), hs[2].getDominantOrientationAngle())
+                for a_, b_ in zip(hs[0].steer(None, full=True), hs[2].steer(None, full=True)):
+                    assert torch.equal(a_, b_)
+                for a_, b_ in zip(hs[0].pipeline(img), hs[2].pipeline(img)):
+                    assert torch.equal(a_, b_)
+                x, y = shape[1] // 2, shape[0] // 3
+                assert tuple(hs[0].steer_point((x, y), -0.2, full=True)) == tuple(hs[2].steer_point((x, y), -0.2, full=True))
+                hs[2].setup(img, flags=cv.SETUP_BASIS)          # a basis-only launch goes back to the two-group form
+                assert hs[2].launch_info()["state_layout"] == 1
             for p in range(nb):
                 assert torch.equal(hs[0].basis(p), hs[1].basis(p)), (shape, p)
             s0, s1 = hs[0].basis_view(1)[3], hs[1].basis_view(1)[3]
