@@ -565,7 +565,19 @@ int cvs_read_state(cvs_handle h, int which, const cvs_plane* dst)
     if (rc) return rc;
     if ((rc = check_plane(h, dst, "dst")) || (rc = check_same(h, dst, h->rows, h->cols))) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, copy_rows(dst->data, dst->step, src.data, src.step, (size_t)h->cols * sizeof(float), h->rows,
+    const size_t width = (size_t)h->cols * sizeof(float);
+    if (dst->mem == CVS_MEM_HOST && src.step != width && dst->step == width) {
+        // a plane of a row-interleaved group on its way to a dense host plane: over the host link a pitched 2-D copy is served
+        // row by row at a fraction of the rate of a linear one (cvs_context.h copy_rows), so the rows are gathered on the
+        // device first (a device-to-device 2-D copy runs at memory speed) and cross the link as one linear copy
+        const size_t elems = (size_t)h->rows * h->cols;
+        if ((rc = arena_reserve(h, round_up(elems, 64)))) return rc;
+        HIP_TRY(h, hipMemcpy2DAsync(h->arena, width, src.data, src.step, width, h->rows, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(dst->data, h->arena, width * h->rows, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return CVS_OK;
+    }
+    HIP_TRY(h, copy_rows(dst->data, dst->step, src.data, src.step, width, h->rows,
                                 dst->mem == CVS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
     if (dst->mem == CVS_MEM_HOST) HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CVS_OK;
