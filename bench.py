@@ -377,7 +377,7 @@ def main():
 
     def launch_of(handle):
         li = handle.launch_info()
-        return {k: li[k] for k in ("block_order", "xcd_weights", "strip_rows", "nt_stores", "state_layout", "tuning_launches")}
+        return {k: li[k] for k in ("block_order", "xcd_weights", "strip_rows", "nt_stores", "state_layout", "read_ahead", "tuning_launches")}
 
     def settle(fn, n=SETTLE_CALLS):
         """calls before a timed region on a new (handle, entry point, shape): the online tuner compares its candidates on them"""

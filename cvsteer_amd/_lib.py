@@ -37,7 +37,7 @@ class LaunchInfo(C.Structure):
     """struct cvs_launch_info"""
     _fields_ = [("placement_mode", C.c_int32), ("state_per_plane", C.c_int32), ("window_found", C.c_int32), ("probes_run", C.c_int32),
                 ("probe_ms", C.c_double), ("block_order", C.c_int32), ("xcd_weights", C.c_int32), ("strip_rows", C.c_int32),
-                ("nt_stores", C.c_int32), ("g4_split", C.c_int32), ("state_layout", C.c_int32), ("tuning_launches", C.c_int32)]
+                ("nt_stores", C.c_int32), ("g4_split", C.c_int32), ("state_layout", C.c_int32), ("read_ahead", C.c_int32), ("tuning_launches", C.c_int32)]
 
 
 _PP = C.POINTER(Plane)

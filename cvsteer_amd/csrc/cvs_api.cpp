@@ -156,7 +156,10 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
             fill_state_args(h, a, orient_k);
         }
         note_launch(h, a);
-        const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, scr, h->stream);
+        hipError_t le = hipSuccess;
+        if (a.read_ahead)   // the image in one pure-read burst first (a tuner candidate for launches on new images)
+            le = launch_read_ahead(a.in, a.in_pitch * (a.in_u8 ? 1 : sizeof(float)), a.rows, (size_t)a.cols * (a.in_u8 ? 1 : sizeof(float)), h->stream);
+        if (le == hipSuccess) le = launch_basis(h->kind, h->width, h->taps, a, scr, h->stream);
         tune_end(h, tok);
         HIP_TRY(h, le);
     }

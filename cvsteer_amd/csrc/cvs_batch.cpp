@@ -407,7 +407,7 @@ bool host_plane(const cvs_plane* p, int rows, int cols, bool u8 = false)
 // Host planes (the reference's callers hold cv::Mat: example/steer.cpp:73-104).  Nothing goes through the root's GPU:
 // every rank pulls ITS frames from the caller's host planes over its own PCIe link and pushes its outputs back the
 // same way, all ranks at once.  Inside a rank the shard is cut into chunks of frames and three things overlap, as
-// in the single-image host path of cvs_api.cpp: the upload of chunk c+1 (stream `up`, this rank's worker thread),
+// in the single-image host path (cvs_host.cpp): the upload of chunk c+1 (stream `up`, this rank's worker thread),
 // the launch for chunk c (the rank's stream) and the download of chunk c-1 (stream `down`, a second thread --
 // copies from / to pageable memory hold the calling thread).  Needs every rank in this process.
 struct HostRun {

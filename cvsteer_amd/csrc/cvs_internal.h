@@ -43,7 +43,7 @@ struct BasisArgs {
     float* orient;        // c1,c2,c3,theta,strength at orient + i*orient_stride (row pitch orient_pitch), or nullptr
     size_t orient_pitch;  // the state is laid out as two groups of planes, basis and orientation, each either planar
     size_t orient_stride; // (pitch = row length, stride = plane size) or ROW-INTERLEAVED (stride = row length, pitch = planes x row
-                          // length: row r of all planes of the group lies side by side) -- see cvs_api.cpp ensure_state
+                          // length: row r of all planes of the group lies side by side) -- see cvs_handle.cpp layout_state
     size_t state_bytes;   // bytes of one frame's state block from `basis` on (basis group, then orientation group)
     float* steer_g;       // fused scalar-steer outputs, or nullptr
     size_t steer_g_pitch;
@@ -55,6 +55,7 @@ struct BasisArgs {
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
+    int read_ahead;       // host only (cvs_tune.cpp -> do_setup): a pure-read pass over the image in front of the launch
     int merge_orient;     // host only (cvs_tune.cpp -> do_setup): lay the G2 orientation planes out in one group with the basis planes
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
     int out_row_lo, out_row_hi;    // caller: compute output rows [out_row_lo, out_row_hi) only (0, 0 = the whole image);
@@ -170,6 +171,8 @@ hipError_t launch_quantize_u8(const float* src, size_t pitch, int rows, int cols
 
 hipError_t launch_convert_u8(const float* src, size_t pitch, int rows, int cols, float alpha, float beta, uint8_t* dst,
                              size_t dst_step, hipStream_t s);
+// pure-read pass over an image (rows x row_bytes, step_bytes apart): pulls it into the Infinity Cache ahead of a filter launch
+hipError_t launch_read_ahead(const void* src, size_t step_bytes, int rows, size_t row_bytes, hipStream_t s);
 hipError_t launch_u8_to_f32(const uint8_t* src, size_t sstep, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 // the same as a strip march of the basis kernel's machinery (cvs_kernels_basis.hip); false = geometry not covered, use launch_pyr_down

@@ -225,7 +225,7 @@ __device__ __forceinline__ bool static_tile(const BasisArgs& a, int& bx, int& by
     // T >= 2: 1-D grid, groups of T bands walked column by column, so T vertically adjacent bands are in
     // flight together (T >= grid_y: column-major).  Which order the memory system prefers depends on the
     // kernel variant (how many planes it writes) and on the box; the API layer picks it by timing the
-    // candidates once per (variant, shape) -- see autotune in cvs_api.cpp.
+    // candidates on the caller's own launches, once per (variant, shape) -- cvs_tune.cpp.
     bx = blockIdx.x;
     by = blockIdx.y;
     if (a.block_order == 1) {
@@ -409,7 +409,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     [[maybe_unused]] const unsigned pstride2_b = (unsigned)(a.plane_stride2 * sizeof(float));
     [[maybe_unused]] const unsigned off2_b = ANY_B ? (unsigned)((size_t)(basis2_p - basis_p) * sizeof(float)) : 0u;   // single-resource form only
     [[maybe_unused]] const size_t plane2_bytes = (size_t)(a.rows - rbase) * a.pitch2 * sizeof(float);
-    // the orientation planes are a group of their own (own row pitch, own plane stride: ensure_state in cvs_api.cpp)
+    // the orientation planes are a group of their own (own row pitch, own plane stride: layout_state in cvs_handle.cpp)
     [[maybe_unused]] const unsigned opitch_b = (unsigned)(a.orient_pitch * sizeof(float));
     [[maybe_unused]] const unsigned ostride_b = (unsigned)(a.orient_stride * sizeof(float));
     [[maybe_unused]] const unsigned ooff_b = (unsigned)((size_t)(orient_p - basis_p) * sizeof(float));   // single-resource form only (block < 2 GiB)

@@ -77,8 +77,9 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // ---------------------------------------------------------------------------------------------------------------------
 struct Cand {
     int order, xw, strip, split;
+    int ahead = 0;   // launches on new images: a pure-read pass over the image first (cvs_kernels_point.hip k_read_ahead)
     int merge = 0;   // G2 launches that write orientation planes: one 12-plane group instead of basis | orientation (cvs_handle.cpp layout_state)
-    bool operator==(const Cand& o) const { return order == o.order && xw == o.xw && strip == o.strip && split == o.split && merge == o.merge; }
+    bool operator==(const Cand& o) const { return order == o.order && xw == o.xw && strip == o.strip && split == o.split && merge == o.merge && ahead == o.ahead; }
 };
 
 struct TuneEntry {
@@ -116,6 +117,7 @@ static void apply(BasisArgs& a, const Cand& c, bool xw_pinned)
     a.strip_rows = c.strip;
     a.g4_split = c.split;
     a.merge_orient = c.merge;
+    a.read_ahead = c.ahead;
 }
 
 // read back every sample whose launch has finished (never waits); decide entries that are complete.  g_tune_mutex held.
@@ -151,7 +153,7 @@ static void harvest()
             if (std::getenv("CVS_TUNE_VERBOSE")) {
                 std::fprintf(stderr, "[cvsteer] tuned on the caller's launches:");
                 for (size_t c = 0; c < e.cand.size(); ++c)
-                    std::fprintf(stderr, " (order %d, xcd %d, strip %d, split %d, merged %d) %.4f ms x%d", e.cand[c].order, e.cand[c].xw, e.cand[c].strip, e.cand[c].split, e.cand[c].merge,
+                    std::fprintf(stderr, " (order %d, xcd %d, strip %d, split %d, merged %d, read-ahead %d) %.4f ms x%d", e.cand[c].order, e.cand[c].xw, e.cand[c].strip, e.cand[c].split, e.cand[c].merge, e.cand[c].ahead,
                                  e.nsamp[c] ? e.best[c] : 0.f, e.nsamp[c]);
                 std::fprintf(stderr, " -> candidate %d\n", best);
             }
@@ -212,7 +214,8 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     const bool free_strip = h->strip_rows <= 0 && (a.batch == 0 || !a.no_state);
     const bool free_split = h->kind == CVS_KIND_G4 && h->g4_split < 0;
     const int xw0 = a.xcd_even * 100 + a.xcd_odd;
-    const Cand def{a.block_order, xw0, a.strip_rows, a.g4_split, a.merge_orient};
+    Cand def{a.block_order, xw0, a.strip_rows, a.g4_split};
+    def.merge = a.merge_orient;
     e.cand.assign(1, def);
     auto add = [&](Cand c) {
         const bool deals = c.order == 1 || c.order == kOrderXcdColumns;   // orders in which the even : odd shares matter
@@ -252,6 +255,19 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
         add({1, xw0, def.strip, def.split});
         add({def.order, xw0, def.strip, 0});               // one 11-plane kernel instead of the two half banks
         add({def.order, xw0, 5 * nt - halo, def.split});   // the taller strip (53 rows at width 6): ahead by 1.5 % in some processes, behind in others
+    }
+    // Launches on NEW images (a handle's first call, or another image than last time) of a size the Infinity Cache holds beside
+    // the launch's own traffic: the two leading configurations again with a pure-read pass over the image in front.  Where the
+    // image really comes from HBM that wins 3-6 %; where it is in the cache already (the previous kernel made it) it loses
+    // its 5-12 us and is dropped.
+    const size_t in_bytes = (size_t)a.rows * a.cols * (a.in_u8 ? 1 : sizeof(float));
+    if (fresh_input && a.batch == 0 && in_bytes >= ((size_t)4 << 20) && in_bytes <= ((size_t)(std::getenv("CVS_READ_AHEAD_MAX_MB") ? std::atoi(std::getenv("CVS_READ_AHEAD_MAX_MB")) : 128) << 20) && !std::getenv("CVS_NO_READ_AHEAD")) {
+        const size_t n0 = std::min<size_t>(e.cand.size(), 2);
+        for (size_t i = 0; i < n0; ++i) {
+            Cand m = e.cand[i];
+            m.ahead = 1;
+            e.cand.push_back(m);
+        }
     }
     // G2 launches that write the orientation planes too (full setup, pipeline), row-interleaved state, single image: the same
     // three leading configurations with ALL twelve planes in one group -- steadier (0.81-0.82 for the full setup in every
@@ -351,6 +367,7 @@ void note_launch(cvs_handle h, const BasisArgs& a)
     h->last.strip_rows = a.strip_rows;
     h->last.nt_stores = a.nt_stores;
     h->last.g4_split = a.g4_split;
+    h->last.read_ahead = a.read_ahead;
     h->last.tuning_launches = h->tuning_launches;
 }
 

@@ -94,7 +94,8 @@ enum {
                                 Results do not depend on it. */
     CVS_OPT_XCD_WEIGHTS = 10, /* block orders 1 and 1000000: 100 * e + o = shares of the even / odd XCDs (1..16 each; 101 =
                                  equal); 0 (default) = the engine's choice, or what the autotuner found (tuning) */
-    CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the second launch of a shape times a few launch configurations and caches the
+    CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the first ~40 calls of a shape each run one of a few launch configurations between two
+                                events on the caller's stream (no extra launches, no waiting); the engine then keeps the
                                 winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
     CVS_OPT_PLACEMENT_SEARCH = 11, /* where the state planes of a large image (state >= 256 MiB) live.  0 (DEFAULT since round 3):
                                       a plain hipMalloc block, no probe, no side effects.  1 (opt-in tuning knob; also
@@ -205,6 +206,8 @@ typedef struct cvs_launch_info {
     int32_t g4_split;         /* ... CVS_OPT_G4_SPLIT value in effect */
     int32_t state_layout;     /* layout of the current state block: 0 = planar, 1 = row-interleaved groups (CVS_OPT_STATE_LAYOUT),
                                  2 = row-interleaved with the G2 orientation planes in the basis planes' group (the tuner's choice) */
+    int32_t read_ahead;       /* last basis launch: 1 = a pure-read pass over the image ran in front of it (a tuner candidate for
+                                 launches on new images: the image then comes out of the Infinity Cache) */
     int32_t tuning_launches;  /* launches the engine has issued on this handle's stream beyond the caller's own calls
                                  (always 0 since round 4: configurations are compared on the caller's launches) */
 } cvs_launch_info;

@@ -80,7 +80,7 @@ def test_config4_batched_pipeline_32x1080p_state_kept_and_outputs_only(cv, ora):
     frames[15] = 0.5 * frames[15] + torch.from_numpy(smooth_image(1080, 1920)).cuda()
     eng = cv.SteerableFiltersG2(None)
     out = torch.empty((nfr, 8, 1080, 1920), device="cuda")
-    for _ in range(3):   # first call, the launch-order tuner's call, a tuned call: all must agree
+    for _ in range(3):   # first call and calls on which the online tuner tries other configurations: all must agree
         out.zero_()
         eng.pipeline_batch(frames, out=out)
         torch.cuda.synchronize()
@@ -386,7 +386,7 @@ def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora):
 
 
 def test_overlapped_host_path_against_the_oracle(cv, ora):
-    """the band-wise upload / filter / download path (host_pipeline in cvs_api.cpp; a 1-Mpix-and-more host image with host
+    """the band-wise upload / filter / download path (host_pipeline in cvs_host.cpp; a 1-Mpix-and-more host image with host
     outputs: cvs::k_basis<BankG2, 2 / 3, STREAM, 0, false, 4> per band) directly against the oracle, not only against the
     device path: g, h and basis planes on a band that straddles two upload bands, and on the image borders."""
     rng = np.random.default_rng(32)

@@ -1120,7 +1120,7 @@ def test_block_order_never_changes_results(cv):
         f = cv.SteerableFiltersG2(None)
         f.set_option(L.OPT_BLOCK_ORDER, order)
         outs = []
-        for _ in range(3):                              # the autotuner kicks in on the second call
+        for _ in range(3):                              # the online tuner tries its candidates on these calls
             outs = f.pipeline(img)
         g, h = f.setup_steer(img, 0.3)
         cur = [o.clone() for o in outs] + [g, h] + [f.basis(p) for p in range(7)]
@@ -1515,7 +1515,7 @@ def test_placement_retry_on_a_second_pool(cv, monkeypatch):
 
 def test_batch_block_search_keeps_results(cv):
     """CVS_OPT_PLACEMENT_SEARCH = 1 on a frame batch with state kept: the first call times the REAL launch on up to six candidate
-    state blocks and keeps the fastest (cvs_api.cpp batch_block_search).  Outputs, every frame's state and later calls must not
+    state blocks and keeps the fastest (cvs_tune.cpp batch_block_search).  Outputs, every frame's state and later calls must not
     notice; the search runs once per block size; stateless batches and the default (0) never search."""
     import torch
     from cvsteer_amd import _lib as L

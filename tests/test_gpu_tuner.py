@@ -75,6 +75,35 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     del last
 
 
+def test_tuner_candidates_on_new_images_never_change_results(cv):
+    """launches on NEW images (another image every call): the online tuner's candidates there include a pure-read pass over the
+    image in front of the filter launch (cvs_launch_info.read_ahead); whatever runs, every image's outputs are the bits of the
+    tuner-less handle, f32 and 8-bit images"""
+    import torch
+    from cvsteer_amd import _lib as L
+    n = 2560
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    imgs = [torch.rand((n, n), device="cuda", generator=gen) for _ in range(4)]
+    imgs += [(im * 255).to(torch.uint8) for im in imgs[:2]]
+    plain = cv.SteerableFiltersG2(None)
+    plain.set_option(L.OPT_AUTOTUNE, 0)
+    refs = []
+    for im in imgs:
+        g, h = plain.setup_steer(im, 0.3, flags=cv.SETUP_BASIS)
+        refs.append((g.clone(), h.clone(), plain.basis(5).clone()))
+    f = cv.SteerableFiltersG2(None)
+    seen_ahead = set()
+    for it in range(90):
+        k = it % len(imgs)
+        g, h = f.setup_steer(imgs[k], 0.3, flags=cv.SETUP_BASIS)
+        li = f.launch_info()
+        seen_ahead.add(li["read_ahead"])
+        assert li["tuning_launches"] == 0
+        if it % 3 == 0 or li["read_ahead"]:
+            assert torch.equal(g, refs[k][0]) and torch.equal(h, refs[k][1]) and torch.equal(f.basis(5), refs[k][2]), (it, k, li)
+    assert seen_ahead == {0, 1}, seen_ahead      # the read-ahead candidates did take their turns
+
+
 def test_objects_come_and_go_without_draining_the_device(cv):
     """one object per image (example/steer.cpp:86 inside the parallel_for_ body), no host synchronisation anywhere in the
     loop: cvs_destroy parks the state block with an event and the next object's launch waits for it on the device.  Every
