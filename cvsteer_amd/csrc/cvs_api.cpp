@@ -502,8 +502,10 @@ int cvs_setup_pyr(cvs_handle h, const cvs_plane* image, unsigned flags, const cv
 // of level k writes level k + 1 (cvs_setup_pyr: every level image is read once), all on the handles' stream.
 // (Measured and NOT done, round 4: filtering the three small levels of a 5-level pyramid of 8192^2 concurrently on side streams
 // behind the 4096^2 level -- 57 us of launch-latency-bound launches that could shrink to the longest of them.  The events
-// that fork and join the streams cost more than the overlap saves: 0.603 ms against 0.525 ms for the plain chain,
-// gpurun_out r4_pyr, same box and process.)
+// that fork and join the streams cost more than the overlap saves: 0.603 ms against 0.525 ms for the plain chain, same box
+// and process.  Nor: ONE launch for the three small levels (grid.z = level, per-level geometry) behind two stand-alone pyrDown
+// launches that make their images first: 0.560 ms against 0.545 ms -- what the merged launch saves, the two extra launches
+// and the loss of the fused level emission cost again.)
 int cvs_pyramid_setup(cvs_handle* hs, int levels, const cvs_plane* image, unsigned flags, const cvs_plane* level_images)
 {
     if (!hs || levels < 1 || !hs[0]) return CVS_E_BADARG;
