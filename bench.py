@@ -25,6 +25,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -99,21 +100,42 @@ def _spawn_ranks(n):
     return rc
 
 
-def _time_steps(torch, fn, steps, warmup, barrier, repeats=1):
+LEAD_IN_MS = 20.0
+
+
+def _time_steps(torch, fn, steps, warmup, barrier, repeats=1, idle_s=0.0):
     """W untimed warm-ups, then R regions of exactly K steps, each between barrier + synchronize on both sides;
-    returns ([wall seconds per region], [HIP-event milliseconds per region, on the launch stream])."""
+    returns ([wall seconds per region], [HIP-event milliseconds per region, on the launch stream]).
+
+    Every region is led into by untimed steps of the same call (at least W, enough for about LEAD_IN_MS of GPU time) with
+    nothing but the synchronize + barrier between them and the first timed step: a card that has sat idle for some tens of
+    milliseconds (a generation-2 collection of the interpreter is enough) starts the next launches at a lower shader clock, and
+    a region of 2-5 ms is over before the clock is back -- the launches within reach of the VALU then read 10-20 % slow
+    (`tools/burst_probe.py`, profiles/r04_burst_probe.txt).  `idle_s` > 0 puts exactly such a pause in front of the region:
+    the `*_after_idle` legs."""
     import gc
-    for _ in range(warmup):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(max(1, warmup)):
         fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    per_ms = max(ev0.elapsed_time(ev1) / max(1, warmup), 1e-3)
+    lead = max(warmup, min(400, int(LEAD_IN_MS / per_ms)))
     walls, evs = [], []
     for _ in range(repeats):
+        # a collection inside a region of 0.1-1 ms steps starves the GPU and shows up as a 10x outlier of that repeat:
+        # collect before the lead-in, not in there
+        gc.collect()
+        gc.disable()
+        for _ in range(lead):
+            fn()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        # a generation-2 collection of the interpreter (tens of milliseconds with torch + numpy loaded) inside a region of
-        # 0.1-1 ms steps starves the GPU and shows up as a 10x outlier of that repeat: collect now, not in there
-        gc.collect()
-        gc.disable()
+        if idle_s > 0:
+            time.sleep(idle_s)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
@@ -127,6 +149,60 @@ def _time_steps(torch, fn, steps, warmup, barrier, repeats=1):
         walls.append(t1 - t0)
         evs.append(ev0.elapsed_time(ev1))
     return walls, evs
+
+
+def _telemetry_files(torch, dev_index):
+    """sysfs files of THIS rank's card (a box shows all cards of its host): shader clock, package power, power cap"""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        cards = [c for c in glob.glob("/sys/class/drm/card*/device") if want in os.path.realpath(c)]
+        if len(cards) != 1:
+            return None
+        pick = lambda pat: (sorted(glob.glob(os.path.join(cards[0], pat))) or [None])[0]
+        fs = {"sclk": pick("hwmon/hwmon*/freq1_input"), "power": pick("hwmon/hwmon*/power1_input") or pick("hwmon/hwmon*/power1_average"),
+              "cap": pick("hwmon/hwmon*/power1_cap")}
+        return fs if fs["sclk"] and fs["power"] else None
+    except Exception:
+        return None
+
+
+def _sustained(torch, fs, fn, seconds=1.0):
+    """`fn` back to back for `seconds` (one host synchronisation per 50 calls) while a thread reads the card's shader clock
+    and package power every 20 ms: what the launch runs at when the power management has settled -- the timed regions above
+    are bursts of a few milliseconds.  Explains box-to-box differences; not used for `value` or any roofline figure."""
+    def rd(p):
+        try:
+            return int(open(p).read().split()[0])
+        except Exception:
+            return None
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            samples.append((rd(fs["sclk"]), rd(fs["power"])))
+            time.sleep(0.02)
+    for _ in range(50):
+        fn()
+    torch.cuda.synchronize()
+    th = threading.Thread(target=sampler)
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        n += 50
+    dt = time.perf_counter() - t0
+    stop[0] = True
+    th.join()
+    half = samples[len(samples) // 2:] or samples    # the second half: after the power management has reacted
+    clk = [a for a, _ in half if a]
+    pw = [b for _, b in half if b]
+    cap = rd(fs["cap"]) if fs.get("cap") else None
+    return {"ms_per_call": round(1e3 * dt / n, 5), "calls": n, "sclk_mhz": round(_median(clk) / 1e6) if clk else None,
+            "power_w": round(_median(pw) / 1e6) if pw else None, "power_cap_w": round(cap / 1e6) if cap else None}
 
 
 def _median(v):
@@ -419,7 +495,9 @@ def main():
         "config": {"workload": "G2+H2 7-basis separable pass + scalar steer (theta=0.3), one 4096x4096 f32 image "
                                "per GPU per step, image resident in HBM, bases persisted (BASELINE configs[1])",
                    "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective",
-                   "init_calls": INIT_CALLS, "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process"),
+                   "init_calls": INIT_CALLS, "lead_in": "every timed region follows >= W untimed steps of the same call (about %g ms of GPU time) "
+                                                        "with only the synchronize + barrier in between; extra.*_after_idle = with a 30 ms pause instead" % LEAD_IN_MS,
+                   "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process"),
                    "library_defaults": not args.placement and not args.strip_rows,
                    "output_planes": "g, h = cv.alloc_planes(2, rows, cols): rows of one block, what setup_steer() allocates by itself",
                    "placement": {"mode": info["placement_mode"], "window_found": bool(info["window_found"]), "probe_ms": round(info["probe_ms"], 3),
@@ -671,11 +749,32 @@ def main():
             f.setup(img, flags=cv.SETUP_FULL)
             leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36, settle_calls=4)
             leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), 64, settle_calls=4)
-            del outs8
             f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)
             leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"], handle=f4)
             leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"], handle=f4)
-            del f4
+            # what a lead-in without a pause is worth: the same two launches with 30 ms of idleness in front of every region
+            for nm, fn_, bpp_ in (("M5_pipeline_after_idle", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"]),
+                                  ("M6_g4_basis_after_idle", lambda: f4.setup(img), BYTES_PER_PIX["M6"])):
+                _w, e_ = _time_steps(torch, fn_, ksteps, kwarm, barrier, repeats=LR, idle_s=0.03)
+                per = sorted(v / ksteps for v in max_over_ranks(*e_))
+                extra[nm] = dict(rate(_median(per), bpp_, npix), ms_min=round(per[0], 5), ms_max=round(per[-1], 5), repeats=LR,
+                                 note="the card idle for 30 ms before every timed region of %d steps: the first launches run at the shader "
+                                      "clock the power management had dropped to (every other leg is led into without a pause)" % ksteps)
+            # clock and power of this card while three of the launches above run back to back for a second each
+            fs = _telemetry_files(torch, local_rank) if rank == 0 else None
+            if fs:
+                sus = {"M2_filter_steer": (step, BYTES_PER_PIX["M2"]), "M5_pipeline": (lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"]),
+                       "M6_g4_basis": (lambda: f4.setup(img), BYTES_PER_PIX["M6"])}
+                tel = {}
+                for name, (fn, bpp) in sus.items():
+                    tel[name] = _sustained(torch, fs, fn)
+                    tel[name]["frac_hbm"] = round(bpp * npix / (tel[name]["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                tel["note"] = ("each launch back to back for 1 s, host synchronisation every 50 calls; median shader clock and package power of "
+                               "the second half, from the card's hwmon files.  The card sits at its power cap under these launches and the "
+                               "shader clock is what the cap leaves: a lower clock on another box shows first in the VALU-heavier launches")
+                out["device_telemetry"] = tel
+                step()
+            del outs8, f4
             # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed
             # start-up cost of a launch (every wave primes its 8-row window before its first store) amortises
             big2 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
