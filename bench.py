@@ -303,6 +303,7 @@ def _cpu_baseline(theta):
 
 
 def main():
+    global LEAD_IN_MS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -315,8 +316,10 @@ def main():
                     help="CVS_OPT_PLACEMENT_SEARCH of the headline handle: 0 (default) = the library default, a plain hipMalloc block; "
                          "1 = the library's opt-in allocation-time placement search (A/B aid: extra.M2_placement_window reports it in any case)")
     ap.add_argument("--repeats", type=int, default=11, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
+    ap.add_argument("--lead-ms", type=float, default=LEAD_IN_MS, help="GPU time of the untimed lead-in in front of every timed region (at least --warmup steps)")
     ap.add_argument("--leg-repeats", type=int, default=5, help="repeats of every secondary leg's timed region (median reported)")
     args = ap.parse_args()
+    LEAD_IN_MS = max(0.0, args.lead_ms)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

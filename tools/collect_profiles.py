@@ -34,16 +34,28 @@ if stats:
     line = [l for l in open(os.path.join(G, "prof_stats.log")) if l.startswith("{")]
     if trace and line:
         jl = json.loads(line[-1])
-        steps = jl["steps"] * int(jl.get("repeats", {}).get("repeats", 1))   # every repeat of the timed region
-        durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace[0]))
-                if "k_basis<cvs::BankG2, 2" in r["Kernel_Name"] or "k_basisINS_6BankG2ELi2" in r["Kernel_Name"]]
-        durs = [d for _, d in sorted(durs)][-steps:]
+        # the timed regions are the bursts of exactly `steps` launches: every region is led into by untimed launches of the same
+        # kernel and separated from them by the synchronize + barrier (a gap of tens of microseconds in the trace)
+        K = jl["steps"]
+        rec = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace[0]))
+                     if "k_basis<cvs::BankG2, 2" in r["Kernel_Name"] or "k_basisINS_6BankG2ELi2" in r["Kernel_Name"])
+        bursts, cur = [], []
+        for st, en in rec:
+            if cur and st - cur[-1][1] > 15000:
+                bursts.append(cur)
+                cur = []
+            cur.append((st, en))
+        if cur:
+            bursts.append(cur)
+        regions = [b_ for b_ in bursts if len(b_) == K]
+        durs = [en - st for b_ in regions for st, en in b_]
         if durs:
-            starts = sorted(int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace[0])) if "BankG2, 2" in r["Kernel_Name"])[-jl["steps"]:]
+            l2l = [(b_[-1][0] - b_[0][0]) / max(1, len(b_) - 1) for b_ in regions]
             with open(os.path.join(P, "%s_kernel_stats.csv" % rnd), "a") as f:
                 w = csv.writer(f)
-                w.writerow(["# timed region: last %d launches of the headline kernel" % len(durs), len(durs), sum(durs), "%.1f" % (sum(durs) / len(durs)),
-                            min(durs), max(durs), "launch-to-launch %.1f ns (last repeat)" % ((starts[-1] - starts[0]) / max(1, len(starts) - 1))])
+                w.writerow(["# timed regions: %d bursts of exactly %d launches of the headline kernel (lead-in bursts excluded)" % (len(regions), K), len(durs), sum(durs),
+                            "%.1f" % (sum(durs) / len(durs)), min(durs), max(durs),
+                            "launch-to-launch %.1f ns (median over the regions); bench.py avg_launch_ms %.5f" % (sorted(l2l)[len(l2l) // 2], jl["roofline"]["avg_launch_ms"])])
     if line:
         open(os.path.join(P, "%s_bench_under_rocprof.json" % rnd), "w").write(line[-1])
 # the same headline loop on a plain hipMalloc block (bench.py --placement 0): timed region only
