@@ -302,6 +302,59 @@ def _cpu_baseline(theta):
     return res
 
 
+def _traffic_child():
+    """`bench.py --traffic-child`: nothing but the headline launch on the library's default configuration, a few times -- the
+    program the parent runs under `rocprofv3 --pmc` (counters only, no tracing) to read the launch's HBM traffic"""
+    import torch
+    import cvsteer_amd as cv
+    from cvsteer_amd import _lib as L
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    img = torch.rand((ROWS, COLS), generator=gen, device="cuda", dtype=torch.float32)
+    f = cv.SteerableFiltersG2(None, 4, 0.67, device=0)
+    f.set_option(L.OPT_AUTOTUNE, 0)    # the engine's default configuration (what the tuner keeps unless a challenger wins by 2 %)
+    g, h = cv.alloc_planes(2, ROWS, COLS, device="cuda")
+    for _ in range(10):
+        f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
+    torch.cuda.synchronize()
+
+
+def _live_traffic():
+    """HBM bytes per headline launch from the PMC counters, measured by THIS run: two child processes (FETCH_SIZE, then
+    WRITE_SIZE -- separate passes, never combined with tracing, as MI355X_MICROARCH.md prescribes) of `--traffic-child`
+    under rocprofv3 (children, never an exec of this process).  gfx950 corrections as in tools/collect_profiles.py
+    (calibrated on kernels of known traffic, profiles/r04_pmc_traffic.json): counters are KiB per dispatch, FETCH_SIZE
+    reports half of the streamed read bytes, WRITE_SIZE is exact.  None (with the reason) when rocprofv3 is missing, this
+    process is itself being profiled, or a pass fails; the committed value is then replayed and labelled so."""
+    import csv, glob, shutil, subprocess, tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cvs_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            pr = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child"],
+                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
+            vals = []
+            for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(fn)):
+                    if r.get("Counter_Name") == ctr and "k_basis" in r.get("Kernel_Name", ""):
+                        vals.append(float(r["Counter_Value"]) * 1024.0)
+            if pr.returncode != 0 or len(vals) < 4:
+                return None, "%s pass failed (rc %d, %d samples): %s" % (ctr, pr.returncode, len(vals), pr.stderr.decode(errors="replace")[-200:])
+            vals = vals[2:]     # the first launches touch fresh pages
+            got[ctr] = sum(vals) / len(vals)
+        except Exception as ex:
+            return None, "%s pass: %s: %s" % (ctr, type(ex).__name__, ex)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"read_bytes": round(2.0 * got["FETCH_SIZE"]), "write_bytes": round(got["WRITE_SIZE"]),
+            "hbm_bytes_per_launch": round(2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"])}, None
+
+
 def main():
     global LEAD_IN_MS
     ap = argparse.ArgumentParser()
@@ -317,13 +370,18 @@ def main():
                          "1 = the library's opt-in allocation-time placement search (A/B aid: extra.M2_placement_window reports it in any case)")
     ap.add_argument("--repeats", type=int, default=11, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
     ap.add_argument("--lead-ms", type=float, default=LEAD_IN_MS, help="GPU time of the untimed lead-in in front of every timed region (at least --warmup steps)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not start the two rocprofv3 --pmc child runs; roofline.traffic is then replayed from profiles/traffic.json")
     ap.add_argument("--leg-repeats", type=int, default=5, help="repeats of every secondary leg's timed region (median reported)")
     args = ap.parse_args()
     LEAD_IN_MS = max(0.0, args.lead_ms)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.traffic_child:
+        return _traffic_child()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_spawn_ranks(args.gpus))   # before torch is imported: the parent never touches the GPU
+    live, live_why = None, "the counter passes had not run yet when this line was printed"
 
     # SIGTERM (a sibling rank failed and the launcher -- ours or torchrun -- stops everybody): blocked in every thread
     # of this process (set before any library starts threads; threads inherit the mask) and received by ONE watcher
@@ -481,7 +539,7 @@ def main():
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("k_basis_g2_steer_4096", {}).get("hbm_bytes_per_launch")
-            traffic_source = "profiles/traffic.json (replayed from the committed rocprofv3 --pmc passes of this kernel; not measured in this run)"
+            traffic_source = "profiles/traffic.json (replayed from the committed rocprofv3 --pmc passes of this kernel; not measured in this run: %s)" % live_why
         except Exception:
             traffic = None
 
@@ -1031,6 +1089,27 @@ def main():
             os._exit(EXIT_LEGS_FAILED)
     if timer is not None:
         timer.cancel()
+
+    # HBM traffic of the headline launch from the PMC counters, measured by this run -- AFTER everything that is timed: in
+    # front of it, two of four runs had the headline and M1 3-6 % slow (tools/ab_live_traffic.sh; the children's allocations
+    # change where this process's first state block lands).  One rank only: the counter passes use device 0.
+    if rank == 0 and out.get("roofline"):
+        if args.no_live_traffic:
+            live_why = "switched off (--no-live-traffic)"
+        elif ws != 1:
+            live_why = "runs of several ranks replay the committed value"
+        else:
+            torch.cuda.synchronize()
+            live, live_why = _live_traffic()
+        if live:
+            out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = (
+                "measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two counter-only child runs of the headline launch "
+                "(`bench.py --traffic-child`, library defaults) after the timed part; read %d B (2 x FETCH_SIZE, the gfx950 correction) + "
+                "written %d B" % (live["read_bytes"], live["write_bytes"]))
+        elif out["roofline"].get("traffic_source"):
+            out["roofline"]["traffic_source"] = out["roofline"]["traffic_source"].replace(
+                "the counter passes had not run yet when this line was printed", live_why or "counter passes failed")
 
     # the CPU baseline runs on rank 0's host cores (the other ranks wait in the final barrier)
     if rank == 0 and not args.no_cpu:

@@ -9,6 +9,6 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 500 rocprofv3 --pmc $C --output-format csv -d $O/pmcall_$C -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --leg-repeats 1 --lead-ms 2 --no-cpu > $O/pmcall_$C.log 2>&1
+  timeout 500 rocprofv3 --pmc $C --output-format csv -d $O/pmcall_$C -- python3 bench.py --no-live-traffic --steps 3 --warmup 1 --repeats 1 --leg-repeats 1 --lead-ms 2 --no-cpu > $O/pmcall_$C.log 2>&1
   echo "pmcall $C rc=$?" >> $O/pmcall_$C.log
 done
