@@ -70,7 +70,7 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // output planes were rewritten over and over.  Since round 4 NOTHING extra is launched: while a shape is being tuned, each of
 // the caller's own calls runs one candidate, bracketed by a pair of events on the caller's stream; candidates take turns in
 // blocks of kBlock consecutive calls (the first call of a block is not counted: a configuration's first launch after a
-// change runs slower than the ones that follow it), kRounds times; when every sample has been read back -- at some later
+// change runs slower than the ones that follow it), kRounds times, and the default once more at the end; when every sample has been read back -- at some later
 // call, never by waiting -- the fastest is kept, the default unless a challenger beats it by 2 %.  Until then and for shapes
 // seen once, the default runs.  Process-wide (the reference's callers build one object per image), keyed by device, kind,
 // kernel variant, shape, batch size, layout and what the caller pinned.  cvs_launch_info.tuning_launches stays 0.
@@ -336,9 +336,15 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     }
     if (++e.in_block == kBlock) {
         e.in_block = 0;
-        if (++e.cur == (int)e.cand.size()) {
+        if (e.round == kRounds) e.done_issuing = true;   // the closing block of the default has run
+        else if (++e.cur == (int)e.cand.size()) {
+            // After the last round the DEFAULT runs one more block.  A card that was idle before the first of these calls (the
+            // state allocation of a new handle is enough) takes tens of launches to come back to its clock, and the launches
+            // within reach of the VALU follow the clock: whoever is sampled later looks faster, the default -- first in every
+            // round -- worst (a G4 handle once kept an order that is 10 % slower side by side).  With the default sampled at
+            // both ends of the comparison that drift can only work against a challenger.
             e.cur = 0;
-            if (++e.round == kRounds) e.done_issuing = true;
+            ++e.round;
         }
     }
     return CVS_OK;
