@@ -89,19 +89,27 @@ for it in range(iters):
     if rng.integers(0, 2):
         opts[L.OPT_STRIP_ROWS] = int(rng.choice([1, 5, 10, 19, 28, 37, 64, 131]))
     if rng.integers(0, 2):
-        opts[L.OPT_BLOCK_ORDER] = int(rng.choice([0, 1, 2, 3, 8, 1000, 1000000, 1000000]))   # 1000000 = every XCD on its own column blocks
+        opts[L.OPT_BLOCK_ORDER] = int(rng.choice([0, 1, 2, 3, 8, 1000, 1000000, 1000000, 2000000, 2000000]))   # 1000000 = every XCD on its own column blocks, 2000000 = dynamic tail
     if rng.integers(0, 3) == 0:
         opts[L.OPT_XCD_WEIGHTS] = int(rng.choice([403, 504, 101, 302, 706, 1601, 116]))
     if rng.integers(0, 2):
         opts[L.OPT_STORE_POLICY] = int(rng.choice([0, 1, 2]))
     if kind == 4 and rng.integers(0, 2):
         opts[L.OPT_G4_SPLIT] = int(rng.integers(0, 3))
+    if rng.integers(0, 2):
+        opts[L.OPT_STATE_LAYOUT] = int(rng.integers(0, 3))    # planar / row-interleaved groups / one merged group (round 4)
+    if rng.integers(0, 4) == 0:
+        opts[L.OPT_AUTOTUNE] = 1                              # otherwise tools run with what the environment says (the tuner's candidates take turns)
     entry = str(rng.choice(["setup", "setup_steer", "pipeline", "batch", "rows", "pyr"]))
     custom = bool(rng.integers(0, 6) == 0)   # a non-default (width, spacing): the two-pass fallback at every size
     cw, cs = int(rng.integers(1, 9)), float(np.float32(rng.uniform(0.3, 1.0)))
     if custom and entry in ("pipeline", "batch", "pyr"):
         entry = "setup"
     theta = float(rng.uniform(-4, 4))
+    as_u8 = bool(rng.integers(0, 5) == 0) and not nonfinite and not custom and entry in ("setup", "setup_steer", "pipeline")
+    if as_u8:   # 8-bit image (what the reference's callers hold): read as bytes inside the filter kernel, widened unscaled
+        img = np.floor(rng.random((rows, cols)) * 256.0).clip(0, 255).astype(np.float32)
+        scale = 255.0
     desc = dict(it=it, seed=seed, nonfinite=nonfinite, kind=kind, rows=rows, cols=cols, device=device, strided=strided, opts=opts, entry=entry, theta=round(theta, 4))
     try:
         w, s = (4, 0.67) if kind == 2 else (6, 0.5)
@@ -112,7 +120,20 @@ for it in range(iters):
         f = cv.SteerableFiltersG2(None, w, s) if kind == 2 else cv.SteerableFiltersG4(None, w, s)
         for o, v in opts.items():
             f.set_option(o, v)
+        if opts.get(L.OPT_BLOCK_ORDER) == 2000000:
+            counts["dynamic tail"] = counts.get("dynamic tail", 0) + 1
+        if L.OPT_STATE_LAYOUT in opts:
+            counts["layout %d" % opts[L.OPT_STATE_LAYOUT]] = counts.get("layout %d" % opts[L.OPT_STATE_LAYOUT], 0) + 1
         x = as_plane(img, device, strided)
+        if as_u8:
+            desc["u8"] = True
+            counts["8-bit image"] = counts.get("8-bit image", 0) + 1
+            if torch.is_tensor(x):
+                xb = torch.zeros((rows, cols + 5), dtype=torch.uint8, device="cuda")[:, 2:2 + cols] if strided else torch.empty((rows, cols), dtype=torch.uint8, device="cuda")
+                xb.copy_(x.to(torch.uint8))
+                x = xb
+            else:
+                x = np.ascontiguousarray(x).astype(np.uint8)
         truth = ora.basis(kind, img, w, s, f64=True)
         fin_t = truth[np.isfinite(truth)]
         scale = max(scale, float(np.abs(fin_t).max()) if fin_t.size else 1.0)   # wide / dense tap sets have gains of 30 and more
