@@ -35,7 +35,6 @@ int host_pipeline(cvs_handle h, Call& c, BasisArgs& a, float* scr)
 {
     const int W = h->width;
     int nbands = 8;
-    if (const char* e = std::getenv("CVS_HOST_BANDS")) nbands = std::max(1, std::min(64, std::atoi(e)));  // tuning aid
     int per = (a.rows + nbands - 1) / nbands;
     per = std::max(a.strip_rows, (per + a.strip_rows - 1) / a.strip_rows * a.strip_rows);
     nbands = (a.rows + per - 1) / per;

@@ -23,8 +23,12 @@
 //  * every memory access is a buffer instruction: plane = resource (SGPRs), row = scalar offset,
 //    column = one per-lane byte offset shared by all loads and stores; masked lanes use an
 //    out-of-range offset that the hardware range check drops.
+//  * the state planes lie row-interleaved in groups ([row][plane][column]: basis | orientation, for G4 G | H | orientation;
+//    BasisArgs pitch / plane_stride per group, cvs_handle.cpp layout_state): the launch's write frontier is one linear
+//    sweep per group; 8-bit images are read as bytes (template U8) and widened in registers.
 //  * variants (templates): epilogue flags, streaming stores, batched launch (grid.z = frame),
 //    single state resource; G4 runs as two half banks side by side in one launch (k_basis_pair).
+//  * which tile a workgroup takes: pick_tile -- static orders from blockIdx, or the tail of the launch from per-XCD queues.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -844,18 +848,12 @@ static unsigned weighted_grid(BasisArgs& a)
     return (unsigned)(((tiles + period - 1) / period) * 8 * cmax);
 }
 
-// dynamic order: more workgroups than tiles (see pick_tile; CVS_DYN_SURPLUS_PCT = tuning aid, default 25 %), a multiple of 8 so
+// dynamic order: the last tenth of the tiles goes through the queues (the rest: tile = workgroup index) with a quarter more
+// workgroups than queued tiles (see pick_tile; both figures from the sweep in profiles/r04_order_probe.txt), a multiple of 8 so
 // that every XCD gets the same number
 static unsigned dynamic_blocks(size_t ntiles, int* dyn_static)
 {
-    static const int pct = [] {
-        const char* e = std::getenv("CVS_DYN_SURPLUS_PCT");
-        return e ? std::max(0, std::min(100, std::atoi(e))) : 25;
-    }();
-    static const int tail_pct = [] {   // share of the tiles handed out through the queues (the rest: tile = workgroup index)
-        const char* e = std::getenv("CVS_DYN_TAIL_PCT");
-        return e ? std::max(1, std::min(100, std::atoi(e))) : 10;
-    }();
+    constexpr int pct = 25, tail_pct = 10;
     const size_t tail = std::max<size_t>(8, ntiles * tail_pct / 100);
     const size_t stat = ntiles > tail ? (ntiles - tail) / 8 * 8 : 0;
     *dyn_static = (int)stat;
@@ -1165,7 +1163,6 @@ bool launch_pyr_strip(const float* src, size_t spitch, int rows, int cols, float
     a.pyr_out = dst;
     a.pyr_pitch = dpitch;
     a.strip_rows = 6 * (2 * W + 1) - 2 * W;   // 46 rows: 17 % more rows staged than written, ~11 k waves at 8192^2
-    if (const char* e = std::getenv("CVS_PYR_STRIP_ROWS")) a.strip_rows = std::max(1, std::atoi(e));  // tuning aid
     a.row_lo = 0;
     a.row_hi = rows;
     a.row_base = 0;

@@ -261,7 +261,8 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     // image really comes from HBM that wins 3-6 %; where it is in the cache already (the previous kernel made it) it loses
     // its 5-12 us and is dropped.
     const size_t in_bytes = (size_t)a.rows * a.cols * (a.in_u8 ? 1 : sizeof(float));
-    if (fresh_input && a.batch == 0 && in_bytes >= ((size_t)4 << 20) && in_bytes <= ((size_t)(std::getenv("CVS_READ_AHEAD_MAX_MB") ? std::atoi(std::getenv("CVS_READ_AHEAD_MAX_MB")) : 128) << 20) && !std::getenv("CVS_NO_READ_AHEAD")) {
+    static const bool no_read_ahead = std::getenv("CVS_NO_READ_AHEAD") != nullptr;   // A/B aid (tools/fresh_probe.py)
+    if (fresh_input && a.batch == 0 && in_bytes >= ((size_t)4 << 20) && in_bytes <= ((size_t)128 << 20) && !no_read_ahead) {
         const size_t n0 = std::min<size_t>(e.cand.size(), 2);
         for (size_t i = 0; i < n0; ++i) {
             Cand m = e.cand[i];
