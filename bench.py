@@ -337,7 +337,7 @@ def _live_traffic():
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             pr = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child"],
-                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
+                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=40)   # a pass takes ~3 s; a hung one must not cost the run its line
             vals = []
             for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(fn)):
