@@ -336,15 +336,26 @@ def _live_traffic():
         d = tempfile.mkdtemp(prefix="cvs_pmc_", dir="/tmp")
         try:
             env = dict(os.environ, TMPDIR="/tmp")
-            pr = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child"],
-                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=40)   # a pass takes ~3 s; a hung one must not cost the run its line
+            # its own session: on a timeout the whole group goes (rocprofv3 AND the program under it), by its exact group id
+            po = subprocess.Popen([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child"],
+                                  cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _o, err_txt = po.communicate(timeout=40)   # a pass takes ~3 s; a hung one must not cost the run its line
+            except subprocess.TimeoutExpired:
+                import signal as _sig
+                try:
+                    os.killpg(po.pid, _sig.SIGKILL)
+                except OSError:
+                    pass
+                po.communicate()
+                return None, "%s pass timed out" % ctr
             vals = []
             for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(fn)):
                     if r.get("Counter_Name") == ctr and "k_basis" in r.get("Kernel_Name", ""):
                         vals.append(float(r["Counter_Value"]) * 1024.0)
-            if pr.returncode != 0 or len(vals) < 4:
-                return None, "%s pass failed (rc %d, %d samples): %s" % (ctr, pr.returncode, len(vals), pr.stderr.decode(errors="replace")[-200:])
+            if po.returncode != 0 or len(vals) < 4:
+                return None, "%s pass failed (rc %d, %d samples): %s" % (ctr, po.returncode, len(vals), (err_txt or b"").decode(errors="replace")[-200:])
             vals = vals[2:]     # the first launches touch fresh pages
             got[ctr] = sum(vals) / len(vals)
         except Exception as ex:
