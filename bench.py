@@ -675,7 +675,13 @@ def main():
         fu.set_option(L.OPT_AUTOTUNE, 0)
         leg("M2_untuned", lambda: fu.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], handle=fu, settle_calls=4)
         extra["M2_untuned"]["note"] = "fresh handle, CVS_OPT_AUTOTUNE=0 (the engine's default configuration from the first call)"
-        del fu
+        # the same for the other G2 entry points: what the online tuner's pick is worth against the plain default, leg by leg
+        # (compare with M1 = roofline_m1, M4_full_setup, M5_pipeline; another handle means another state block, worth +-1.5 % by itself)
+        outs8u = cv.alloc_planes(8, ROWS, COLS, device=dev)
+        leg("M1_untuned", lambda: fu.setup(img, flags=cv.SETUP_BASIS), BYTES_PER_PIX["M1"], handle=fu, settle_calls=4)
+        leg("M4_untuned", lambda: fu.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"], handle=fu, settle_calls=4)
+        leg("M5_untuned", lambda: fu.pipeline(img, out=outs8u), BYTES_PER_PIX["M5"], handle=fu, settle_calls=4)
+        del fu, outs8u
 
         # the reference's usage pattern: ONE object per image (example/steer.cpp:86, test/test.cpp:85).
         # (a) `M2_one_object_per_image`: a loop of 64 objects -- create, one fused call, destroy -- on a stream of different

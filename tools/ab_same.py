@@ -2,7 +2,7 @@
 """tools/ab_same.py -- interleaved A/B of launch options on ONE handle (one state allocation), so that the
 allocation-dependent speed modes (tools/alloc_modes.py) cannot masquerade as an effect of the option.
 usage: ab_same.py "8=0" "8=32" "8=0,7=8" ...   (option=value[,option=value]; options not named are reset to
-order 0, strip rows auto, default weights).  AB_KIND=4 for the G4 bank, AB_HANDLES=n repeats on n handles."""
+order 0, strip rows auto, default weights).  AB_KIND=4 for the G4 bank, AB_HANDLES=n repeats on n handles, AB_STEPS=k launches per timed burst (default 20)."""
 import os, sys, statistics
 os.environ.setdefault("CVS_PLACEMENT_SEARCH", "0")
 os.environ.setdefault("CVS_AUTOTUNE", "0")
@@ -11,7 +11,13 @@ import torch
 import cvsteer_amd as cv
 from cvsteer_amd import _lib as L
 
-def timeit(fn, steps=20):
+STEPS = int(os.environ.get("AB_STEPS", "20"))   # AB_STEPS=300: sustained launches (the card at its power cap) instead of short bursts
+
+
+def timeit(fn, steps=None):
+    steps = steps or STEPS
+    for _ in range(steps // 3 if steps > 60 else 0):   # lead-in for the long form
+        fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(steps): fn()
