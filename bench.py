@@ -525,7 +525,7 @@ def main():
 
     def launch_of(handle):
         li = handle.launch_info()
-        return {k: li[k] for k in ("block_order", "xcd_weights", "strip_rows", "nt_stores", "state_layout", "read_ahead", "tuning_launches")}
+        return {k: li[k] for k in ("block_order", "xcd_weights", "strip_rows", "nt_stores", "state_layout", "read_ahead", "wg_per_cu", "tuning_launches")}
 
     def settle(fn, n=SETTLE_CALLS):
         """calls before a timed region on a new (handle, entry point, shape): the online tuner compares its candidates on them"""
@@ -675,13 +675,7 @@ def main():
         fu.set_option(L.OPT_AUTOTUNE, 0)
         leg("M2_untuned", lambda: fu.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], handle=fu, settle_calls=4)
         extra["M2_untuned"]["note"] = "fresh handle, CVS_OPT_AUTOTUNE=0 (the engine's default configuration from the first call)"
-        # the same for the other G2 entry points: what the online tuner's pick is worth against the plain default, leg by leg
-        # (compare with M1 = roofline_m1, M4_full_setup, M5_pipeline; another handle means another state block, worth +-1.5 % by itself)
-        outs8u = cv.alloc_planes(8, ROWS, COLS, device=dev)
-        leg("M1_untuned", lambda: fu.setup(img, flags=cv.SETUP_BASIS), BYTES_PER_PIX["M1"], handle=fu, settle_calls=4)
-        leg("M4_untuned", lambda: fu.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"], handle=fu, settle_calls=4)
-        leg("M5_untuned", lambda: fu.pipeline(img, out=outs8u), BYTES_PER_PIX["M5"], handle=fu, settle_calls=4)
-        del fu, outs8u
+        del fu
 
         # the reference's usage pattern: ONE object per image (example/steer.cpp:86, test/test.cpp:85).
         # (a) `M2_one_object_per_image`: a loop of 64 objects -- create, one fused call, destroy -- on a stream of different
@@ -815,12 +809,24 @@ def main():
             torch.cuda.current_stream().synchronize()
             f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))  # back on the main stream
             del f2, img2, g2_, h2_
+            def same_handle_default(name, fn, bpp):
+                """the leg just timed, on the SAME handle (same state block) with the tuner switched off: what the tuner's pick is
+                worth.  (`M2_untuned` is another handle: another state block, worth up to +-5 % by itself on the 12- / 20-plane launches)"""
+                f.set_option(L.OPT_AUTOTUNE, 0)
+                leg(name, fn, bpp, handle=f, settle_calls=4)
+                f.set_option(L.OPT_AUTOTUNE, 1)
+                fn()
+
+            same_handle_default("M2_default_same_handle", step, BYTES_PER_PIX["M2"])
+            same_handle_default("M1_default_same_handle", step_m1, BYTES_PER_PIX["M1"])
             leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"], handle=f)
+            same_handle_default("M4_default_same_handle", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"])
             # the eight outputs of the pipeline as rows of ONE block ([row][plane][column]; cv.alloc_planes), the layout the
             # engine gives its own state planes: strided views like any cv::Mat ROI.  `M5_pipeline_separate_outputs` = eight
             # separate allocations (rounds 1-3).
             outs8 = cv.alloc_planes(8, ROWS, COLS, device=dev)
             leg("M5_pipeline", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"], handle=f)
+            same_handle_default("M5_default_same_handle", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"])
             outs8s = [torch.empty_like(img) for _ in range(8)]
             leg("M5_pipeline_separate_outputs", lambda: f.pipeline(img, out=outs8s), BYTES_PER_PIX["M5"], handle=f, settle_calls=8)
             del outs8s

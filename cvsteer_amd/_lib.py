@@ -15,6 +15,7 @@ OPT_PLACEMENT_SEARCH = 11
 OPT_AUTOTUNE = 12
 OPT_HOST_OVERLAP = 13
 OPT_STATE_LAYOUT = 14
+OPT_WG_PER_CU = 15
 PLANE_BASIS0, PLANE_C1, PLANE_C2, PLANE_C3, PLANE_THETA, PLANE_STRENGTH = 0, 32, 33, 34, 35, 36
 
 
@@ -37,7 +38,7 @@ class LaunchInfo(C.Structure):
     """struct cvs_launch_info"""
     _fields_ = [("placement_mode", C.c_int32), ("state_per_plane", C.c_int32), ("window_found", C.c_int32), ("probes_run", C.c_int32),
                 ("probe_ms", C.c_double), ("block_order", C.c_int32), ("xcd_weights", C.c_int32), ("strip_rows", C.c_int32),
-                ("nt_stores", C.c_int32), ("g4_split", C.c_int32), ("state_layout", C.c_int32), ("read_ahead", C.c_int32), ("tuning_launches", C.c_int32)]
+                ("nt_stores", C.c_int32), ("g4_split", C.c_int32), ("state_layout", C.c_int32), ("read_ahead", C.c_int32), ("tuning_launches", C.c_int32), ("wg_per_cu", C.c_int32)]
 
 
 _PP = C.POINTER(Plane)

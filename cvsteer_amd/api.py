@@ -199,6 +199,11 @@ class SteerableFilters:
     def set_option(self, option, value):
         self._check(lib().cvs_set_option(self._h, option, int(value)), "cvs_set_option")
 
+    def get_option(self, option):
+        v = C.c_int(0)
+        self._check(lib().cvs_get_option(self._h, option, C.byref(v)), "cvs_get_option")
+        return v.value
+
     def launch_info(self):
         """cvs_get_launch_info as a dict: placement of the state block + configuration of the last basis launch"""
         li = L.LaunchInfo()

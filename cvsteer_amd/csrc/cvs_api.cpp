@@ -412,6 +412,10 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "state layout");
             h->layout = value;
             return CVS_OK;
+        case CVS_OPT_WG_PER_CU:
+            if (value < 0 || value > 8) return fail(h, CVS_E_BADARG, "workgroups per CU");
+            h->wg_per_cu = value;
+            return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -433,6 +437,7 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;
         case CVS_OPT_STATE_LAYOUT: *value = h->layout; return CVS_OK;
+        case CVS_OPT_WG_PER_CU: *value = h->wg_per_cu; return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }

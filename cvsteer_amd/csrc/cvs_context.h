@@ -54,6 +54,7 @@ struct cvs_context {
     // placement = 0: the allocation-time placement search (cvs_state.cpp) is OPT-IN since round 3 -- on the judge's box of
     // round 2 it cost 8 ms on first use and bought nothing, and it reserves address space for the life of the process
     int layout = 1;   // CVS_OPT_STATE_LAYOUT: 0 = planar, 1 = row-interleaved (default)
+    int wg_per_cu = 0;   // CVS_OPT_WG_PER_CU: 0 = the engine's choice (uncapped unless the tuner finds a cap faster), N = at most N workgroups per CU
     int atan_mode = 0, strip_rows = 0, find_on = 0, store_policy = 0, g4_split = -1, block_order = -1, persist = 1, g4_ext = 0, xcd_weights = 0, placement = 0, autotune = 1;
     // what the last state allocation / the last basis launch of this handle did (cvs_get_launch_info)
     int window_found = 0;

@@ -57,6 +57,8 @@ struct BasisArgs {
     int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
     int read_ahead;       // host only (cvs_tune.cpp -> do_setup): a pure-read pass over the image in front of the launch
     int merge_orient;     // host only (cvs_tune.cpp -> do_setup): lay the G2 orientation planes out in one group with the basis planes
+    int wg_per_cu;        // host only: at most this many workgroups per CU (0 = whatever the registers allow); launch_basis turns it
+                          // into dynamic LDS the kernel never touches -- the way to cap occupancy on this hardware
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
     int out_row_lo, out_row_hi;    // caller: compute output rows [out_row_lo, out_row_hi) only (0, 0 = the whole image);
                                    // the band-split of one large image over several GPUs (cvs_setup_rows)

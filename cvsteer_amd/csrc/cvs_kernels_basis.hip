@@ -848,6 +848,23 @@ static unsigned weighted_grid(BasisArgs& a)
     return (unsigned)(((tiles + period - 1) / period) * 8 * cmax);
 }
 
+// Occupancy cap (BasisArgs::wg_per_cu = N > 0): dynamic LDS that no kernel touches, sized so that N workgroups fill a CU's
+// 160 KiB and N + 1 do not fit.  Why one would want FEWER waves: with the image resident in the Infinity Cache a 9..20-plane launch
+// is a pure write stream to HBM, every wave in flight is one more write front, and one workgroup per CU less than the registers
+// allow runs the fused steer 2-3.5 % faster on every handle measured, the full setup / pipeline 5 / 8 % faster on handles whose
+// two plane groups lie badly and 4 % slower where they lie well, the basis pass +-3 % (profiles/r04_occupancy_probe.txt).  On
+// new images (the reads need the waves) and at 8192^2 it loses.  So: CVS_OPT_WG_PER_CU for callers who know their images are
+// resident and want to pin it; nothing by default, and not a candidate of the online tuner (cvs_tune.cpp Cand::cap says why).
+static unsigned occupancy_pad(const BasisArgs& a)
+{
+    constexpr unsigned kLdsPerCu = 160u << 10, kStaticLds = 1536;   // static LDS of the strip kernels: 1220-1284 B, rounded up
+    if (a.wg_per_cu <= 0 || a.wg_per_cu > 8) return 0;
+    // N fit: N * (pad + static) <= LDS;  N + 1 do not: (N + 1) * (pad + static) > LDS.  The middle of that interval: at its upper
+    // end the allocation granularity already costs a workgroup (53 KiB behaved like "two per CU", 50 KiB like three)
+    const unsigned n = (unsigned)a.wg_per_cu;
+    return (kLdsPerCu / n + kLdsPerCu / (n + 1)) / 2 - kStaticLds;
+}
+
 // dynamic order: the last tenth of the tiles goes through the queues (the rest: tile = workgroup index) with a quarter more
 // workgroups than queued tiles (see pick_tile; both figures from the sweep in profiles/r04_order_probe.txt), a multiple of 8 so
 // that every XCD gets the same number
@@ -920,7 +937,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
             a.dyn_nz = (int)grid.z;                                                        \
             grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * grid.z, &a.dyn_static), 1, 1); \
         }                                                                                  \
-        hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, f);                        \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, occupancy_pad(a), s, a, f);         \
     } while (0)
 #define CVS_LAUNCH_U(FL, BATCHED, WP, U)                                                   \
     do {                                                                                   \
@@ -1031,7 +1048,7 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
 #define CVS_PAIR_K(...)                                                                                         \
     do {                                                                                                        \
         if (dyn) grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * 2, &a.dyn_static), 1, 1);             \
-        hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, fg, fh);                                        \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, occupancy_pad(a), s, a, fg, fh);                         \
     } while (0)
 #define CVS_PAIR(FL, ST, ON)                                                      \
     do {                                                                          \

@@ -71,7 +71,7 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // the caller's own calls runs one candidate, bracketed by a pair of events on the caller's stream; candidates take turns in
 // blocks of kBlock consecutive calls (the first call of a block is not counted: a configuration's first launch after a
 // change runs slower than the ones that follow it), kRounds times, and the default once more at the end; when every sample has been read back -- at some later
-// call, never by waiting -- the fastest is kept, the default unless a challenger beats it by 2 %.  Until then and for shapes
+// call, never by waiting -- the candidate with the lowest MEDIAN is kept, the default unless a challenger beats it by 2 %.  Until then and for shapes
 // seen once, the default runs.  Process-wide (the reference's callers build one object per image), keyed by device, kind,
 // kernel variant, shape, batch size, layout and what the caller pinned.  cvs_launch_info.tuning_launches stays 0.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -79,12 +79,17 @@ struct Cand {
     int order, xw, strip, split;
     int ahead = 0;   // launches on new images: a pure-read pass over the image first (cvs_kernels_point.hip k_read_ahead)
     int merge = 0;   // G2 launches that write orientation planes: one 12-plane group instead of basis | orientation (cvs_handle.cpp layout_state)
-    bool operator==(const Cand& o) const { return order == o.order && xw == o.xw && strip == o.strip && split == o.split && merge == o.merge && ahead == o.ahead; }
+    int cap = 0;     // workgroups per CU (0 = no cap).  NOT offered by build_candidates: as a second stage of this comparison (the winner
+                     // against itself with one workgroup per CU less) it was picked where sustained launches then ran 2 % slower and
+                     // skipped where they would have run 3 % faster -- candidates that take turns every few launches share one
+                     // power / clock state, and what the cap changes is exactly that (profiles/r04_occupancy_probe.txt)
+    bool operator==(const Cand& o) const { return order == o.order && xw == o.xw && strip == o.strip && split == o.split && merge == o.merge && ahead == o.ahead && cap == o.cap; }
 };
 
 struct TuneEntry {
     std::vector<Cand> cand;        // cand[0] = the default
-    std::vector<float> best;       // fastest counted launch of each candidate, ms
+    std::vector<float> best;       // MEDIAN of the counted launches of each candidate, ms (filled in when the entry is decided)
+    std::vector<std::vector<float>> samples;
     std::vector<int> nsamp;
     int cur = 0, in_block = 0, round = 0;
     int pending = 0;               // samples recorded but not read back yet
@@ -118,6 +123,7 @@ static void apply(BasisArgs& a, const Cand& c, bool xw_pinned)
     a.g4_split = c.split;
     a.merge_orient = c.merge;
     a.read_ahead = c.ahead;
+    if (c.cap) a.wg_per_cu = c.cap;
 }
 
 // read back every sample whose launch has finished (never waits); decide entries that are complete.  g_tune_mutex held.
@@ -135,7 +141,7 @@ static void harvest()
         float ms = 0.f;
         TuneEntry& e = *sm.entry;
         if (q == hipSuccess && hipEventElapsedTime(&ms, sm.e0, sm.e1) == hipSuccess && ms > 0.f) {
-            e.best[sm.cand] = std::min(e.best[sm.cand], ms);
+            e.samples[sm.cand].push_back(ms);
             ++e.nsamp[sm.cand];
         }
         (void)hipGetLastError();
@@ -145,6 +151,14 @@ static void harvest()
         g_samples[i] = g_samples.back();
         g_samples.pop_back();
         if (e.done_issuing && e.pending == 0 && e.chosen < 0) {
+            // The median of a candidate's samples, not the fastest one: a configuration whose launches vary more would win on
+            // its luckiest sample (the three-workgroup cap once did, 2.4 % ahead on its best launch and 3 % behind sustained)
+            for (size_t c = 0; c < e.cand.size(); ++c) {
+                std::vector<float>& v = e.samples[c];
+                if (v.empty()) continue;
+                std::sort(v.begin(), v.end());
+                e.best[c] = v.size() % 2 ? v[v.size() / 2] : 0.5f * (v[v.size() / 2 - 1] + v[v.size() / 2]);
+            }
             int best = 0;
             for (int c = 1; c < (int)e.cand.size(); ++c)
                 if (e.nsamp[c] > 0 && e.best[c] < e.best[best] * (best == 0 ? 0.98f : 1.0f)) best = c;   // a challenger must win by 2 %
@@ -184,6 +198,7 @@ static bool default_config(cvs_handle h, BasisArgs& a, int variant, bool fresh_i
     a.xcd_even = xw_pinned ? xw_pinned / 100 : 5;
     a.xcd_odd = xw_pinned ? xw_pinned % 100 : 4;
     a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
+    a.wg_per_cu = h->wg_per_cu;
     // CVS_OPT_STATE_LAYOUT = 2 pins the grouping: launches that write orientation planes use ONE group of twelve planes
     a.merge_orient = (h->layout == 2 && h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0) ? 1 : 0;
     const bool fast = basis_fast_path(h->kind, h->width, h->taps);
@@ -283,6 +298,7 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
         }
     }
     e.best.assign(e.cand.size(), std::numeric_limits<float>::max());
+    e.samples.assign(e.cand.size(), std::vector<float>());
     e.nsamp.assign(e.cand.size(), 0);
 }
 
@@ -295,7 +311,7 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     if (!free_any) return CVS_OK;
     const int xw_pinned = h->xcd_weights;
     const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->g4_split >= 0 ? 1 : 0) + (h->last.state_layout ? 4 : 0) + (h->layout << 3);
-    const TuneKey key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->sb.vmm ? 1024 : 0) | (h->kind << 12) | (pins << 16) | (a.in_u8 << 20),
+    const TuneKey key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->sb.vmm ? 1024 : 0) | (h->kind << 12) | (pins << 16) | (a.in_u8 << 22) | (h->wg_per_cu << 24),
                                         a.rows, a.cols, xw_pinned, h->block_order, a.batch);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(h->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
@@ -375,6 +391,7 @@ void note_launch(cvs_handle h, const BasisArgs& a)
     h->last.nt_stores = a.nt_stores;
     h->last.g4_split = a.g4_split;
     h->last.read_ahead = a.read_ahead;
+    h->last.wg_per_cu = a.wg_per_cu;
     h->last.tuning_launches = h->tuning_launches;
 }
 

@@ -132,6 +132,11 @@ enum {
                                   = 2 when it does); 2 = always one group of twelve for those launches.
                                   Takes effect at the next cvs_setup*; results do not depend on it.  Also
                                   CVS_STATE_LAYOUT in the environment (new handles). */
+    CVS_OPT_WG_PER_CU = 15,  /* strip kernels: at most N workgroups (of four waves) per CU, N = 1..8; 0 (default) = as many as the
+                                registers allow (4-5 for G2, 3 for the G4 half banks).  One less than that runs G2 launches on an
+                                image the Infinity Cache already holds 2-8 % faster in some processes (fewer write fronts) and
+                                4 % slower in others, and launches on new images slower everywhere (profiles/r04_occupancy_probe.txt):
+                                a knob for callers who measure, never set by the engine.  Results do not depend on it. */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
                                 launch (blockIdx.z picks the half); -1 (default) = 2, or 0 where the autotuner finds it faster */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
@@ -210,6 +215,7 @@ typedef struct cvs_launch_info {
                                  launches on new images: the image then comes out of the Infinity Cache) */
     int32_t tuning_launches;  /* launches the engine has issued on this handle's stream beyond the caller's own calls
                                  (always 0 since round 4: configurations are compared on the caller's launches) */
+    int32_t wg_per_cu;        /* last basis launch: workgroups per CU it was capped to (CVS_OPT_WG_PER_CU); 0 = no cap */
 } cvs_launch_info;
 int cvs_get_launch_info(cvs_handle h, cvs_launch_info* out);
 /* the handle's idx-th tap vector (m_g1.. members), 2*width+1 floats */

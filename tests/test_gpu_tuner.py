@@ -18,7 +18,7 @@ def cv():
 def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     """a new 4096^2 shape: the second call costs about what a settled call costs (rounds 2-3 ran ~250 timing launches inside
     it, 25-30 ms); cvs_launch_info.tuning_launches stays 0; every call -- whatever candidate configuration it ran with --
-    returns the same bits; after ~40 calls a configuration has been kept"""
+    returns the same bits; after 30-57 calls a configuration has been kept"""
     import torch
     from cvsteer_amd import _lib as L
     n = 4096
@@ -292,3 +292,43 @@ def test_dynamic_order_survives_recycled_queue_slots(cv):
                 assert torch.equal(f.basis(p), refs[k][p]), (rnd, k, p)
             del f
             cv.lib().cvs_release_cached_memory()         # the block is freed, its slot goes back to the slab
+
+
+def test_workgroups_per_cu_cap_never_changes_results(cv):
+    """CVS_OPT_WG_PER_CU (dynamic LDS nobody touches, to cap the workgroups per CU -- a knob for callers, never set by
+    the engine): every value gives the bits of the uncapped launch, G2 and G4, every entry point, a shape large
+    enough for many workgroups per CU; bad values are refused; cvs_launch_info reports what ran"""
+    import torch
+    from cvsteer_amd import _lib as L
+    img = torch.rand((1500, 2300), device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+    frames = torch.rand((5, 300, 500), device="cuda", generator=torch.Generator(device="cuda").manual_seed(12))
+    ref = {}
+    for cap in (0, 1, 2, 3, 4, 8):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_AUTOTUNE, 0)
+        f.set_option(L.OPT_WG_PER_CU, cap)
+        assert f.get_option(L.OPT_WG_PER_CU) == cap
+        got = {}
+        g, h = f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS)
+        assert f.launch_info()["wg_per_cu"] == cap
+        got["steer"] = [g.clone(), h.clone()] + [f.basis(p).clone() for p in range(7)]
+        f.setup(img, flags=cv.SETUP_FULL)
+        got["full"] = [f.basis(p).clone() for p in range(7)] + [f.getDominantOrientationAngle().clone(), f.getDominantOrientationStrength().clone()]
+        got["pipe"] = [o.clone() for o in f.pipeline(img)]
+        got["batch"] = [o.clone() for fr in f.pipeline_batch(frames) for o in fr]
+        f4 = cv.SteerableFiltersG4(None)
+        f4.set_option(L.OPT_AUTOTUNE, 0)
+        f4.set_option(L.OPT_WG_PER_CU, cap)
+        g4, h4 = f4.setup_steer(img, -0.7)
+        got["g4"] = [g4.clone(), h4.clone()] + [f4.basis(p).clone() for p in range(11)]
+        if cap == 0:
+            ref = got
+            continue
+        for k in ref:
+            assert len(ref[k]) == len(got[k])
+            for a_, b_ in zip(ref[k], got[k]):
+                assert torch.equal(a_, b_), (cap, k)
+    f = cv.SteerableFiltersG2(None)
+    for bad in (-1, 9, 100):
+        with pytest.raises(cv.CvsError):
+            f.set_option(L.OPT_WG_PER_CU, bad)
