@@ -168,10 +168,15 @@ __device__ __forceinline__ float bld_in(rsrc_t r, unsigned lane_off, unsigned ro
     if constexpr (U8) return (float)__builtin_amdgcn_raw_buffer_load_b8(r, lane_off, row_off, 0);
     else return bld(r, lane_off, row_off);
 }
+// cache policy of the streaming stores (aux bits of the buffer store on gfx94x / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt alone is the
+// product's; `make storepolicy` builds twins with other policies for tools/store_policy_probe.sh
+#ifndef CVS_STREAM_AUX
+#define CVS_STREAM_AUX 2
+#endif
 template <bool STREAM>
 __device__ __forceinline__ void bst(rsrc_t r, unsigned lane_off, unsigned row_off, float v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_off, row_off, STREAM ? 2 : 0);  // aux 2 = nt
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_off, row_off, STREAM ? CVS_STREAM_AUX : 0);
 }
 
 // a 64-bit value that is the same in every lane, moved to SGPRs (the compiler cannot prove that a
