@@ -379,11 +379,11 @@ def main():
     ap.add_argument("--placement", type=int, default=0, choices=(0, 1),
                     help="CVS_OPT_PLACEMENT_SEARCH of the headline handle: 0 (default) = the library default, a plain hipMalloc block; "
                          "1 = the library's opt-in allocation-time placement search (A/B aid: extra.M2_placement_window reports it in any case)")
-    ap.add_argument("--repeats", type=int, default=11, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
+    ap.add_argument("--repeats", type=int, default=15, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
     ap.add_argument("--lead-ms", type=float, default=LEAD_IN_MS, help="GPU time of the untimed lead-in in front of every timed region (at least --warmup steps)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-live-traffic", action="store_true", help="do not start the two rocprofv3 --pmc child runs; roofline.traffic is then replayed from profiles/traffic.json")
-    ap.add_argument("--leg-repeats", type=int, default=5, help="repeats of every secondary leg's timed region (median reported)")
+    ap.add_argument("--leg-repeats", type=int, default=9, help="repeats of every secondary leg's timed region (median reported)")
     args = ap.parse_args()
     LEAD_IN_MS = max(0.0, args.lead_ms)
     if args.gpus < 1:
@@ -594,7 +594,8 @@ def main():
         f.setup(img, flags=cv.SETUP_BASIS)
 
     settle(step_m1)
-    R1 = max(3, R // 2)
+    R1 = R   # as many repeats as the headline: a region of 20 steps is 2 ms long, and at the power cap the card's clock control makes
+             # single regions scatter by +-3 % (min / max of the repeats are in the line); the median of 15 is good to ~1 %
     _w1, e1 = _time_steps(torch, step_m1, args.steps, args.warmup, barrier, repeats=R1)
     e1 = sorted(v / args.steps for v in max_over_ranks(*e1))
     m1_ms = _median(e1)

@@ -71,7 +71,7 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // the caller's own calls runs one candidate, bracketed by a pair of events on the caller's stream; candidates take turns in
 // blocks of kBlock consecutive calls (the first call of a block is not counted: a configuration's first launch after a
 // change runs slower than the ones that follow it), kRounds times, and the default once more at the end; when every sample has been read back -- at some later
-// call, never by waiting -- the candidate with the lowest MEDIAN is kept, the default unless a challenger beats it by 2 %.  Until then and for shapes
+// call, never by waiting -- the candidate with the lowest MEDIAN is kept, the default unless a challenger beats it by 3 %.  Until then and for shapes
 // seen once, the default runs.  Process-wide (the reference's callers build one object per image), keyed by device, kind,
 // kernel variant, shape, batch size, layout and what the caller pinned.  cvs_launch_info.tuning_launches stays 0.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -161,7 +161,7 @@ static void harvest()
             }
             int best = 0;
             for (int c = 1; c < (int)e.cand.size(); ++c)
-                if (e.nsamp[c] > 0 && e.best[c] < e.best[best] * (best == 0 ? 0.98f : 1.0f)) best = c;   // a challenger must win by 2 %
+                if (e.nsamp[c] > 0 && e.best[c] < e.best[best] * (best == 0 ? 0.97f : 1.0f)) best = c;   // a challenger must win by 3 %
             if (e.nsamp[0] == 0) best = 0;
             e.chosen = best;
             if (std::getenv("CVS_TUNE_VERBOSE")) {
@@ -257,13 +257,25 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
             add({kOrderXcdColumns, 101, sr_short, def.split});
             add({0, xw0, sr_short, def.split});
         } else {
-            const bool strips = (size_t)a.rows * a.cols < ((size_t)32 << 20);
-            add({kOrderDynamic, xw0, sr_short, def.split});     // the tail handed out from per-XCD queues: an XCD that is ahead helps the others
-            add({1, 504, sr_short, def.split});                 // more tiles for the faster XCDs: wins where the XCDs differ
-            add({kOrderXcdColumns, 101, sr_short, def.split});  // every XCD its own column range: best for the basis pass on some boxes
-            add({0, xw0, sr_short, def.split});
-            if (strips) add({1, 403, sr_tall, def.split});
-            if (strips) add({0, xw0, sr_tall, def.split});
+            // Resident image.  What has beaten the default (plain order, 10-row strips) by more than 2 % in SUSTAINED side-by-side
+            // runs on one handle (tools/ab_same.py AB_STEPS=300, tools/tuner_value_probe.py; profiles/r04_order_probe_sustained.txt):
+            // for launches that also write the orientation planes (12 / 20 planes) the weighted order (+4-6 %), the dynamic tail
+            // (+3 %) and the merged grouping (below) on handles whose plane groups lie badly; for the basis pass and the fused steer
+            // NOTHING (all orders within 1 %, taller strips behind) -- and there the comparison itself did harm: candidates that
+            // take turns every few launches share one power / clock state, and in one run in seven a configuration that is 4 %
+            // slower sustained (19-row strips, the XCD-column order) was kept.  So large single-group launches are not tuned.
+            const bool multi = a.orient != nullptr || a.pipe;
+            const bool large = (size_t)a.rows * a.cols >= ((size_t)8 << 20);
+            if (multi || !large) {
+                add({kOrderDynamic, xw0, sr_short, def.split});     // the tail handed out from per-XCD queues: an XCD that is ahead helps the others
+                add({1, 504, sr_short, def.split});                 // more tiles for the faster XCDs: wins where the XCDs differ
+                add({0, xw0, sr_short, def.split});
+            }
+            if (!large) {   // smaller images (the default there is the 19-row strip): both heights, both leading orders
+                add({kOrderXcdColumns, 101, sr_short, def.split});
+                add({1, 403, sr_tall, def.split});
+                add({0, xw0, sr_tall, def.split});
+            }
         }
     } else {
         add({kOrderDynamic, xw0, def.strip, def.split});

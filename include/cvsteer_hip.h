@@ -94,7 +94,7 @@ enum {
                                 Results do not depend on it. */
     CVS_OPT_XCD_WEIGHTS = 10, /* block orders 1 and 1000000: 100 * e + o = shares of the even / odd XCDs (1..16 each; 101 =
                                  equal); 0 (default) = the engine's choice, or what the autotuner found (tuning) */
-    CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the first 30-57 calls of a shape each run one of a few launch configurations between two
+    CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the first 20-45 calls of a shape each run one of a few launch configurations between two
                                 events on the caller's stream (no extra launches, no waiting); the engine then keeps the
                                 winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
     CVS_OPT_PLACEMENT_SEARCH = 11, /* where the state planes of a large image (state >= 256 MiB) live.  0 (DEFAULT since round 3):

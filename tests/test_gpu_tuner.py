@@ -18,7 +18,8 @@ def cv():
 def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     """a new 4096^2 shape: the second call costs about what a settled call costs (rounds 2-3 ran ~250 timing launches inside
     it, 25-30 ms); cvs_launch_info.tuning_launches stays 0; every call -- whatever candidate configuration it ran with --
-    returns the same bits; after 30-57 calls a configuration has been kept"""
+    returns the same bits; after 20-45 calls a configuration has been kept.  The launch is the full setup (12 planes): the basis pass
+    and the fused steer on a large resident image are deliberately NOT tuned (see build_candidates) -- checked at the end"""
     import torch
     from cvsteer_amd import _lib as L
     n = 4096
@@ -30,7 +31,7 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     def call():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        f.setup(img, flags=cv.SETUP_FULL)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1)
@@ -40,12 +41,12 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     for i in range(70):
         times.append(call())
         li = f.launch_info()
-        configs.add((li["block_order"], li["xcd_weights"], li["strip_rows"]))
+        configs.add((li["block_order"], li["xcd_weights"], li["strip_rows"], li["state_layout"]))
         assert li["tuning_launches"] == 0
         if first is None:
-            first = (g.clone(), h.clone(), f.basis(3).clone())
+            first = (f.getDominantOrientationAngle().clone(), f.getDominantOrientationStrength().clone(), f.basis(3).clone())
         elif i in (1, 2, 5, 9, 14, 22, 31, 45, 69):
-            assert torch.equal(g, first[0]) and torch.equal(h, first[1]) and torch.equal(f.basis(3), first[2]), i
+            assert torch.equal(f.getDominantOrientationAngle(), first[0]) and torch.equal(f.getDominantOrientationStrength(), first[1]) and torch.equal(f.basis(3), first[2]), i
     steady = statistics.median(times[-15:])
     assert times[1] <= 1.5 * steady + 0.15, (times[:4], steady)          # the second call is an ordinary call (+ host jitter; rounds 2-3: 25-30 ms)
     assert max(times[1:]) <= 3.0 * steady + 0.2, (max(times[1:]), steady)  # ... and so is every other one
@@ -55,24 +56,36 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     for _ in range(6):
         call()
         li = f.launch_info()
-        tail.add((li["block_order"], li["xcd_weights"], li["strip_rows"]))
+        tail.add((li["block_order"], li["xcd_weights"], li["strip_rows"], li["state_layout"]))
     assert len(tail) == 1, tail                                           # settled: one configuration from here on
     # a second handle of the same shape starts from what the process has learnt
     f2 = cv.SteerableFiltersG2(None)
-    f2.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
-    f2.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))   # (a handle's first call counts as a fresh image: its own key)
+    f2.setup(img, flags=cv.SETUP_FULL)
+    f2.setup(img, flags=cv.SETUP_FULL)   # (a handle's first call counts as a fresh image: its own key)
     li2 = f2.launch_info()
-    assert (li2["block_order"], li2["xcd_weights"], li2["strip_rows"]) == next(iter(tail))
+    assert (li2["block_order"], li2["xcd_weights"], li2["strip_rows"], li2["state_layout"]) == next(iter(tail))
     # tuner off: the default configuration on every call
     f3 = cv.SteerableFiltersG2(None)
     f3.set_option(L.OPT_AUTOTUNE, 0)
     seen = set()
     for _ in range(8):
-        f3.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        f3.setup(img, flags=cv.SETUP_FULL)
         li = f3.launch_info()
         seen.add((li["block_order"], li["xcd_weights"], li["strip_rows"]))
-    assert len(seen) <= 2 and torch.equal(g, first[0])   # (first call = fresh-image default, then the resident default)
+    assert len(seen) <= 2 and torch.equal(f3.getDominantOrientationAngle(), first[0])   # (first call = fresh-image default, then the resident default)
     del last
+    # the fused steer and the basis pass on this large resident image: one configuration from the second call on, tuner or not
+    f4 = cv.SteerableFiltersG2(None)
+    seen = set()
+    for k in range(30):
+        if k & 1:
+            f4.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        else:
+            f4.setup(img, flags=cv.SETUP_BASIS)
+        li = f4.launch_info()
+        if k >= 2:
+            seen.add((li["block_order"], li["xcd_weights"], li["strip_rows"], li["wg_per_cu"]))
+    assert len(seen) == 1, seen
 
 
 def test_tuner_candidates_on_new_images_never_change_results(cv):

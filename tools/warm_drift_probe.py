@@ -9,6 +9,8 @@ import cvsteer_amd as cv
 from cvsteer_amd import _lib as L
 
 n = 4096
+LEG = os.environ.get("DRIFT_LEG", "M2")   # M1 = the basis pass alone
+BPP = 32 if LEG == "M1" else 40
 img = torch.rand((n, n), device="cuda")
 g, h = cv.alloc_planes(2, n, n, device="cuda")
 f = cv.SteerableFiltersG2(None)
@@ -27,12 +29,15 @@ while time.perf_counter() - t0 < 6.0:
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(100):
-        f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        if LEG == "M1":
+            f.setup(img, flags=cv.SETUP_BASIS)
+        else:
+            f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
     b.record()
     torch.cuda.synchronize()
     rows.append((time.perf_counter() - t0, a.elapsed_time(b) / 100, rd(clk) / 1e6, rd(pw) / 1e6))
 last = 0.0
 for t, ms, c, p in rows:
     if t - last >= 0.25 or t < 0.1:
-        print("t = %5.2f s  %.4f ms  %.3f   sclk %4.0f MHz  %4.0f W" % (t, ms, 40 * n * n / (ms * 1e-3) / 8e12, c, p))
+        print("t = %5.2f s  %.4f ms  %.3f   sclk %4.0f MHz  %4.0f W" % (t, ms, BPP * n * n / (ms * 1e-3) / 8e12, c, p))
         last = t
