@@ -252,10 +252,15 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     if (h->kind == CVS_KIND_G2) {
         if (fresh_input) {
             // a stream of new images: short strips are a must (the halo rows of vertically adjacent strips only hit in cache when
-            // those strips run close in time), and the weighted order loses 4-6 points; the XCD-column order fetches less
-            add({kOrderDynamic, xw0, sr_short, def.split});
-            add({kOrderXcdColumns, 101, sr_short, def.split});
-            add({0, xw0, sr_short, def.split});
+            // those strips run close in time), the weighted order loses 4-6 points, and the plain order, the XCD-column order and
+            // the dynamic tail are within 1 % of each other in sustained runs (tools/ab_same.py AB_ROT=1 AB_STEPS=300) -- offered,
+            // the latter two only displaced the read-ahead pass below, the one candidate that is worth 3-5 % here, in two runs of six.
+            // Large images: the default against itself with the read-ahead pass, nothing else.
+            if ((size_t)a.rows * a.cols < ((size_t)8 << 20)) {
+                add({kOrderDynamic, xw0, sr_short, def.split});
+                add({kOrderXcdColumns, 101, sr_short, def.split});
+                add({0, xw0, sr_short, def.split});
+            }
         } else {
             // Resident image.  What has beaten the default (plain order, 10-row strips) by more than 2 % in SUSTAINED side-by-side
             // runs on one handle (tools/ab_same.py AB_STEPS=300, tools/tuner_value_probe.py; profiles/r04_order_probe_sustained.txt):
