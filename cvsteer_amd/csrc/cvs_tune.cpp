@@ -283,10 +283,10 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
             }
         }
     } else {
+        // G4: the dynamic tail (+6 % on one box, level on the others).  Not offered any more: the weighted order (3-4 % behind in every
+        // sustained run, yet kept once by the comparison), the single 11-plane kernel (15 % behind everywhere), 53-row strips (+-1.5 %)
+        // -- profiles/r04_g4_strips_probe.txt, r04_g4_bank_layouts.txt; CVS_OPT_G4_SPLIT / CVS_OPT_STRIP_ROWS still pin them
         add({kOrderDynamic, xw0, def.strip, def.split});
-        add({1, xw0, def.strip, def.split});
-        add({def.order, xw0, def.strip, 0});               // one 11-plane kernel instead of the two half banks
-        add({def.order, xw0, 5 * nt - halo, def.split});   // the taller strip (53 rows at width 6): ahead by 1.5 % in some processes, behind in others
     }
     // Launches on NEW images (a handle's first call, or another image than last time) of a size the Infinity Cache holds beside
     // the launch's own traffic: the two leading configurations again with a pure-read pass over the image in front.  Where the

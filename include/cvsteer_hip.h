@@ -138,7 +138,7 @@ enum {
                                 4 % slower in others, and launches on new images slower everywhere (profiles/r04_occupancy_probe.txt):
                                 a knob for callers who measure, never set by the engine.  Results do not depend on it. */
     CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
-                                launch (blockIdx.z picks the half); -1 (default) = 2, or 0 where the autotuner finds it faster */
+                                launch (blockIdx.z picks the half); -1 (default) = 2 (0 and 1 are 5-15 % slower everywhere measured and no longer tried by the tuner) */
     CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
                                 256 MiB Infinity Cache), 1 = plain, 2 = always nontemporal (tuning) */
 };
