@@ -27,8 +27,15 @@ def measure(tag):
 
 for _ in range(60):
     step()
-for k in range(6):
+for k in range(4):
     measure("headline, round %d" % k)
+host = torch.empty((n, n), dtype=torch.float32).pin_memory()
+for k in range(6):       # what a host-plane leg does: copies over the host link in both directions
+    host.copy_(img)
+    img2 = host.cuda(non_blocking=True)
+torch.cuda.synchronize()
+measure("after host <-> device copies")
+measure("once more")
 imgs = [torch.rand((n, n), generator=gen, device="cuda") for _ in range(7)]
 for k in range(200):
     f.setup_steer(imgs[k % 7], 0.3, flags=cv.SETUP_BASIS, out=(g, h))
