@@ -10,9 +10,20 @@ SteerableFiltersG2.cpp:62-68) + steer(theta=0.3) (G2.cpp:137-145), as ONE fused 
 (cvs_setup_steer).  Basis planes are persisted (7 planes) and g2/h2 written: 4 B read + 36 B
 written = 40 algorithmic bytes per pixel (SURVEY.md 8(d) "M2").
 
-Multi-GPU: the image/batch axis shards with no data-path collective -- every rank filters its
-own images (weak scaling); RCCL is used for the barrier and the max-over-ranks reduction, and in
-the `C4_e2e` leg for the scatter of frames from rank 0 and the gather of results to it.
+The ONE JSON line (round 5: <= 6 KB, so that it survives the driver's 8 KB tail):
+  * contract keys at the top level; `roofline` carries, as FLAT scalars (nested objects do not survive the driver's parse), the
+    headline kernel's figures and the fractions of the legs that matter: m1_* (north_star's own target: the basis pass alone),
+    fresh_frac (a new image every call), one_object_frac / first_call_frac (the reference's one object per image), after_idle_frac,
+    m4 / m5 / g4 / c3 / c4, and what RCCL saw (rccl_ranks, transport, scatter / compute / gather ms);
+  * `legs`: name -> [frac_hbm, ms, ms_min, ms_max, config index, frac_valu] with the launch configurations listed once in
+    `launch_configs`; frac_valu = the leg's VALU roof (vector instructions per pixel from profiles/valu_insts.json, two cycles
+    per wave64 instruction on a SIMD32, 1024 SIMDs, the sustained shader clock of this run) so that `bound` can be min(hbm, valu);
+  * probe-only legs (8-bit inputs, untuned twin, host planes, two streams, tuner-off twins, separate outputs, pyramid parts)
+    run with --all-legs.
+
+Multi-GPU: the image/batch axis shards with no data-path collective -- every rank filters its own images (weak scaling); RCCL
+is used for the barrier and the max-over-ranks reduction, for a start-up self-test (one 1080p frame per rank through
+ncclSend/ncclRecv, bytes compared) and in the `C4_e2e` leg for the scatter of frames from rank 0 and the gather of results.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
         N > 1 without WORLD_SIZE in the environment: this process starts N rank processes
@@ -32,19 +43,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+N_SIMD = 1024              # 256 CUs x 4 SIMD32
+VALU_CYCLES_PER_INST = 2.0 # a wave64 vector instruction occupies its SIMD32 for two cycles (MI355X_MICROARCH.md, tools/valu_rate.hip)
+NOMINAL_SCLK_MHZ = 2000.0  # used for the VALU roof only when the card's clock cannot be read
 ROWS = COLS = 4096
 THETA = 0.3
-BYTES_PER_PIX = {"M1": 32, "M2": 40, "M4": 52, "M5": 84, "M6": 48, "M6s": 56, "M2_u8": 37, "C4_u8_feat3": 13}
-# Everything here runs on the library's DEFAULTS (round 4): plain hipMalloc state block, row-interleaved state planes, the
-# online launch tuner.  The tuner compares a handful of launch configurations on the caller's own calls (no extra launches):
-# a new (handle kind, entry point, shape) needs 40-55 calls to settle, which every leg makes before its timed region
-# (SETTLE_CALLS).  The allocation-time placement search stays an opt-in knob of the library; `extra.M2_placement_window`
-# shows what it is worth on the box the run landed on.  `M2_untuned` = CVS_OPT_AUTOTUNE 0.
-SETTLE_CALLS = 60
-INIT_CALLS = SETTLE_CALLS
+BYTES_PER_PIX = {"M1": 32, "M2": 40, "M3": 64, "M4": 52, "M5": 84, "M6": 48, "M6s": 56, "M2_u8": 37, "C4_feat3": 16, "C4_u8_feat3": 13}
+MAX_SETTLE_CALLS = 160     # the online tuner compares its candidates on the caller's own calls; legs call until it has decided
 EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
 EXIT_LEGS_FAILED = 5  # a secondary leg raised: headline + the legs finished so far are printed first
 EXIT_TERMINATED = 4   # SIGTERM (another rank failed / the launcher gave up): whatever was measured is printed first
+LEAD_IN_MS = 20.0
 
 
 def _dist_env():
@@ -100,9 +109,6 @@ def _spawn_ranks(n):
     return rc
 
 
-LEAD_IN_MS = 20.0
-
-
 def _time_steps(torch, fn, steps, warmup, barrier, repeats=1, idle_s=0.0):
     """W untimed warm-ups, then R regions of exactly K steps, each between barrier + synchronize on both sides;
     returns ([wall seconds per region], [HIP-event milliseconds per region, on the launch stream]).
@@ -110,9 +116,8 @@ def _time_steps(torch, fn, steps, warmup, barrier, repeats=1, idle_s=0.0):
     Every region is led into by untimed steps of the same call (at least W, enough for about LEAD_IN_MS of GPU time) with
     nothing but the synchronize + barrier between them and the first timed step: a card that has sat idle for some tens of
     milliseconds (a generation-2 collection of the interpreter is enough) starts the next launches at a lower shader clock, and
-    a region of 2-5 ms is over before the clock is back -- the launches within reach of the VALU then read 10-20 % slow
-    (`tools/burst_probe.py`, profiles/r04_burst_probe.txt).  `idle_s` > 0 puts exactly such a pause in front of the region:
-    the `*_after_idle` legs."""
+    a region of 2-5 ms is over before the clock is back.  `idle_s` > 0 puts exactly such a pause in front of the region: the
+    `*_after_idle` legs."""
     import gc
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -168,10 +173,10 @@ def _telemetry_files(torch, dev_index):
         return None
 
 
-def _sustained(torch, fs, fn, seconds=1.0):
+def _sustained(torch, fs, fn, seconds=0.5):
     """`fn` back to back for `seconds` (one host synchronisation per 50 calls) while a thread reads the card's shader clock
-    and package power every 20 ms: what the launch runs at when the power management has settled -- the timed regions above
-    are bursts of a few milliseconds.  Explains box-to-box differences; not used for `value` or any roofline figure."""
+    and package power every 20 ms: what the launch runs at when the power management has settled -- the timed regions are
+    bursts of a few milliseconds.  Feeds the VALU roof and explains box-to-box differences; not used for `value`."""
     def rd(p):
         try:
             return int(open(p).read().split()[0])
@@ -201,8 +206,8 @@ def _sustained(torch, fs, fn, seconds=1.0):
     clk = [a for a, _ in half if a]
     pw = [b for _, b in half if b]
     cap = rd(fs["cap"]) if fs.get("cap") else None
-    return {"ms_per_call": round(1e3 * dt / n, 5), "calls": n, "sclk_mhz": round(_median(clk) / 1e6) if clk else None,
-            "power_w": round(_median(pw) / 1e6) if pw else None, "power_cap_w": round(cap / 1e6) if cap else None}
+    return {"ms": round(1e3 * dt / n, 5), "sclk_mhz": round(_median(clk) / 1e6) if clk else None,
+            "power_w": round(_median(pw) / 1e6) if pw else None, "cap_w": round(cap / 1e6) if cap else None}
 
 
 def _median(v):
@@ -220,13 +225,22 @@ def _cpu_model():
     return "unknown"
 
 
+def _valu_table():
+    """vector instructions per OUTPUT pixel of every timed kernel (halo rows included), measured with rocprofv3 --pmc
+    SQ_INSTS_VALU on this code (tools/collect_valu.py -> profiles/valu_insts.json); {} when the file is missing"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json"))).get("per_pixel", {})
+    except Exception:
+        return {}
+
+
 def _opencv_baseline(theta, threads_all):
     """BASELINE.md 3.3a / SURVEY 8(d): when OpenCV exists on the box, the literal reference sequence -- 7 x cv::sepFilter2D
     (SteerableFiltersG2.cpp:62-68) + the scalar steer (G2.cpp:137-145) -- on the same synthetic image, one thread and all."""
     try:
         import cv2
     except Exception:
-        return "absent"
+        return None
     import numpy as np
     import cvsteer_amd as cv
     taps = [cv.make_taps(cv.KIND_G2, i, 4, 0.67) for i in range(7)]
@@ -236,29 +250,27 @@ def _opencv_baseline(theta, threads_all):
 
     def once():
         b = [cv2.sepFilter2D(img, cv2.CV_32F, taps[kx].reshape(1, -1), taps[ky].reshape(-1, 1)) for kx, ky in pairs]
-        g = w[0] * b[0] + w[1] * b[1] + w[2] * b[2]
-        hq = w[3] * b[3] + w[4] * b[4] + w[5] * b[5] + w[6] * b[6]
-        return g, hq
+        return w[0] * b[0] + w[1] * b[1] + w[2] * b[2], w[3] * b[3] + w[4] * b[4] + w[5] * b[5] + w[6] * b[6]
 
-    out = {"version": cv2.__version__}
-    for label, nthr in (("1_thread", 1), ("all_threads", threads_all)):
+    out = {"opencv": cv2.__version__}
+    for label, nthr in (("opencv_1_thread", 1), ("opencv_all_threads", threads_all)):
         cv2.setNumThreads(nthr)
         once()
         reps, total = 0, 0.0
-        while total < 4.0 and reps < 8:
+        while total < 3.0 and reps < 6:
             t0 = time.perf_counter()
             once()
             total += time.perf_counter() - t0
             reps += 1
-        out[label] = {"value": round(reps * ROWS * COLS / total / 1e6, 3), "unit": "Mpix/s", "cores": nthr, "sample": "%d x 4096x4096" % reps}
+        out[label] = round(reps * ROWS * COLS / total / 1e6, 3)
     return out
 
 
-def _cpu_baseline(theta):
+def _cpu_baseline(theta, full):
     """The CPU restatement of the reference call sequence (oracle/, kind 'port'), one thread, on a bounded sample of the same
-    workload (full 4096x4096 images, ~10-20 s of CPU work); then the example's own model of parallelism (one image per thread,
-    example/steer.cpp:169) and one image row-parallel -- on ALL host cores the process may use, with the
-    64-thread figures of earlier rounds beside them."""
+    workload (full 4096x4096 images, about 10 s of CPU work); then, on ALL host cores the process may use, one
+    image split by rows and -- the example's own model of parallelism, example/steer.cpp:169 -- one image per thread.  Flat
+    scalars: nested objects do not survive the driver's parse."""
     import numpy as np
     import oracle  # test infrastructure used as the timed CPU baseline leg only
     img = np.random.default_rng(1234).random((ROWS, COLS), dtype=np.float32)
@@ -273,32 +285,21 @@ def _cpu_baseline(theta):
     except AttributeError:
         avail = os.cpu_count() or 1
     frame = np.random.default_rng(99).random((1080, 1920), dtype=np.float32)
-
-    def per_thread(threads, per=12):
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(threads) as pool:  # ctypes releases the GIL inside the C call
-            list(pool.map(lambda _: oracle.time_g2_filter_steer(frame, theta, per), range(threads)))
-        wall = time.perf_counter() - t0
-        return {"value": round(threads * per * 1080 * 1920 / wall / 1e6, 3), "unit": "Mpix/s", "cores": threads,
-                "sample": "%d threads x %d x (1080x1920 f32, 7 sepFilter2D + scalar steer), one frame per thread" % (threads, per)}
-
-    def banded(threads):
-        t_mt = min(oracle.time_g2_filter_steer_mt(img, theta, 1, threads) for _ in range(3))
-        return {"value": round(ROWS * COLS / t_mt / 1e6, 3), "unit": "Mpix/s", "cores": threads,
-                "sample": "best of 3 x (4096x4096 f32, 7 sepFilter2D + scalar steer), rows split over %d threads" % threads}
-
-    t64 = max(1, min(avail, 64))
-    res = {
-        "value": round(reps * ROWS * COLS / total / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
-        "sample": "%d x (4096x4096 f32, 7 sepFilter2D + scalar steer), single thread, oracle/ C restatement "
-                  "(-O3 -march=native)" % reps,
-        "one_image_per_thread": per_thread(avail), "one_image_row_parallel": banded(avail),
-        "host_cpus": os.cpu_count(), "usable_cpus": avail, "cpu_model": _cpu_model(),
-    }
-    if t64 != avail:
-        res["one_image_per_thread_64"] = per_thread(t64)
-        res["one_image_row_parallel_64"] = banded(t64)
-    res["opencv"] = _opencv_baseline(theta, avail)
+    per = 12 if full else 3
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(avail) as pool:  # ctypes releases the GIL inside the C call
+        list(pool.map(lambda _: oracle.time_g2_filter_steer(frame, theta, per), range(avail)))
+    per_thread = avail * per * 1080 * 1920 / (time.perf_counter() - t0) / 1e6
+    t_mt = min(oracle.time_g2_filter_steer_mt(img, theta, 1, avail) for _ in range(3))
+    res = {"value": round(reps * ROWS * COLS / total / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
+           "sample": "%d x (4096x4096 f32, 7 sepFilter2D + scalar steer), 1 thread, oracle/ C restatement (-O3 -march=native)" % reps,
+           "row_parallel_value": round(ROWS * COLS / t_mt / 1e6, 3), "row_parallel_cores": avail,
+           "per_thread_value": round(per_thread, 3), "per_thread_cores": avail,
+           "per_thread_sample": "%d threads x %d x 1080x1920 frames, one frame per thread (example/steer.cpp:169)" % (avail, per),
+           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(), "opencv": "absent"}
+    ocv = _opencv_baseline(theta, avail)
+    if ocv:
+        res.update(ocv)
     return res
 
 
@@ -311,7 +312,7 @@ def _traffic_child():
     gen = torch.Generator(device="cuda").manual_seed(1234)
     img = torch.rand((ROWS, COLS), generator=gen, device="cuda", dtype=torch.float32)
     f = cv.SteerableFiltersG2(None, 4, 0.67, device=0)
-    f.set_option(L.OPT_AUTOTUNE, 0)    # the engine's default configuration (what the tuner keeps unless a challenger wins by 2 %)
+    f.set_option(L.OPT_AUTOTUNE, 0)    # the engine's default configuration (what the tuner keeps unless a challenger clearly wins)
     g, h = cv.alloc_planes(2, ROWS, COLS, device="cuda")
     for _ in range(10):
         f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
@@ -321,10 +322,9 @@ def _traffic_child():
 def _live_traffic():
     """HBM bytes per headline launch from the PMC counters, measured by THIS run: two child processes (FETCH_SIZE, then
     WRITE_SIZE -- separate passes, never combined with tracing, as MI355X_MICROARCH.md prescribes) of `--traffic-child`
-    under rocprofv3 (children, never an exec of this process).  gfx950 corrections as in tools/collect_profiles.py
-    (calibrated on kernels of known traffic, profiles/r04_pmc_traffic.json): counters are KiB per dispatch, FETCH_SIZE
-    reports half of the streamed read bytes, WRITE_SIZE is exact.  None (with the reason) when rocprofv3 is missing, this
-    process is itself being profiled, or a pass fails; the committed value is then replayed and labelled so."""
+    under rocprofv3 (children, never an exec of this process).  gfx950 corrections as in tools/collect_profiles.py: counters are
+    KiB per dispatch, FETCH_SIZE reports half of the streamed read bytes, WRITE_SIZE is exact.  None (with the reason) when
+    rocprofv3 is missing, this process is itself being profiled, or a pass fails; the committed value is then replayed."""
     import csv, glob, shutil, subprocess, tempfile
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process runs under a profiler"
@@ -372,18 +372,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (M1/M4/M5/G4/C3/C4)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (M1 stays: it is north_star's own target)")
+    ap.add_argument("--all-legs", action="store_true", help="also run the probe-only legs (8-bit inputs, untuned twin, host planes, two streams, tuner-off twins, pyramid parts)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--extra-timeout", type=int, default=300, help="seconds the secondary legs may take before every rank gives up on them (0 = no watchdog)")
-    ap.add_argument("--placement", type=int, default=0, choices=(0, 1),
-                    help="CVS_OPT_PLACEMENT_SEARCH of the headline handle: 0 (default) = the library default, a plain hipMalloc block; "
-                         "1 = the library's opt-in allocation-time placement search (A/B aid: extra.M2_placement_window reports it in any case)")
     ap.add_argument("--repeats", type=int, default=15, help="the --steps region is timed this many times; `value` is the median (spread reported beside it)")
     ap.add_argument("--lead-ms", type=float, default=LEAD_IN_MS, help="GPU time of the untimed lead-in in front of every timed region (at least --warmup steps)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-live-traffic", action="store_true", help="do not start the two rocprofv3 --pmc child runs; roofline.traffic is then replayed from profiles/traffic.json")
-    ap.add_argument("--leg-repeats", type=int, default=9, help="repeats of every secondary leg's timed region (median reported)")
+    ap.add_argument("--leg-repeats", type=int, default=7, help="repeats of every secondary leg's timed region (median reported)")
     args = ap.parse_args()
     LEAD_IN_MS = max(0.0, args.lead_ms)
     if args.gpus < 1:
@@ -392,14 +390,13 @@ def main():
         return _traffic_child()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_spawn_ranks(args.gpus))   # before torch is imported: the parent never touches the GPU
-    live, live_why = None, "the counter passes had not run yet when this line was printed"
+    t_start = time.perf_counter()
 
     # SIGTERM (a sibling rank failed and the launcher -- ours or torchrun -- stops everybody): blocked in every thread
     # of this process (set before any library starts threads; threads inherit the mask) and received by ONE watcher
     # thread through sigwait, which prints what has been measured so far and leaves with a distinct status.  A Python
     # signal handler would never run here: the main thread sits inside a collective or a device synchronisation (C code).
     import signal
-    import threading
     signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
 
     # stdout carries exactly one thing, the JSON line: libraries that print banners there (RCCL does, at communicator
@@ -470,10 +467,7 @@ def main():
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)  # i.i.d. uniform [0,1)
-    f = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-    # the headline handle is a handle as the library hands it out: no option is touched (--placement 1 is an A/B aid)
-    if args.placement:
-        f.set_option(L.OPT_PLACEMENT_SEARCH, args.placement)
+    f = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)   # a handle as the library hands it out: no option is touched
     if args.strip_rows:
         f.set_strip_rows(args.strip_rows)
     # the two output planes as the Python API itself allocates them when the caller passes none: rows of one block
@@ -481,7 +475,6 @@ def main():
     g, h = cv.alloc_planes(2, ROWS, COLS, device=dev)
     npix = ROWS * COLS
 
-    # ---- headline: filter + steer (M2), one fused launch per step ----
     def step():
         f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))
 
@@ -489,7 +482,7 @@ def main():
     # whatever has been measured when they fire
     out = {"metric": "Mpix/s for G2+H2 7-basis filter+steer at 4096x4096 f32; % HBM roofline", "value": None, "unit": "Mpix/s",
            "n_gpus": ws, "steps": args.steps, "warmup": args.warmup}
-    extra = {}
+    legs, configs = {}, []
     done_flag = {"printed": False}
     lock = threading.Lock()
 
@@ -503,12 +496,16 @@ def main():
                 for _try in range(5):   # the main thread may be adding a leg at this very moment (watchdog / SIGTERM path)
                     try:
                         snap = dict(out)
-                        if not args.no_extra:
-                            snap["extra"] = dict(extra)
+                        if legs:
+                            snap["legs_fmt"] = "[frac_hbm, ms, ms_min, ms_max, launch_configs index, frac_valu]"
+                            snap["legs"] = dict(legs)
+                            snap["launch_configs_fmt"] = "[block_order, strip_rows, nt_stores, state_layout, read_ahead, tuned]"
+                            snap["launch_configs"] = list(configs)
                         if not final:
                             snap["extra_error"] = why or "incomplete"
                             snap.setdefault("cpu_baseline", None)
-                        line = json.dumps(snap)
+                        snap["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
+                        line = json.dumps(snap, separators=(",", ":"))
                         break
                     except RuntimeError:
                         time.sleep(0.01)
@@ -523,17 +520,57 @@ def main():
 
     threading.Thread(target=sigterm_watcher, daemon=True).start()
 
-    def launch_of(handle):
+    def cfg_index(handle):
         li = handle.launch_info()
-        return {k: li[k] for k in ("block_order", "xcd_weights", "strip_rows", "nt_stores", "state_layout", "read_ahead", "wg_per_cu", "tuning_launches")}
+        c = [li["block_order"], li["strip_rows"], li["nt_stores"], li["state_layout"], li["read_ahead"], li["tuned"]]
+        if c not in configs:
+            configs.append(c)
+        return configs.index(c)
 
-    def settle(fn, n=SETTLE_CALLS):
-        """calls before a timed region on a new (handle, entry point, shape): the online tuner compares its candidates on them"""
-        for _ in range(n):
+    def settle(fn, handle=None, n=None):
+        """calls before a timed region on a new (handle, entry point, shape): the online tuner compares its candidates on the
+        caller's own calls and says when it has decided (cvs_launch_info.tune_state)"""
+        if n is None:
+            n = MAX_SETTLE_CALLS if handle is not None else 8
+        for i in range(n):
             fn()
+            if handle is not None and i >= 3 and i % 4 == 3 and handle.launch_info()["tune_state"] != 1:
+                break
         torch.cuda.synchronize()
 
-    settle(step, INIT_CALLS)
+    # ---- start-up self-test of the transport (runs of several ranks on distinct GPUs): one 1080p frame per rank through the
+    # native batch layer's ncclSend / ncclRecv, results compared bit for bit with rank 0's own single-GPU run ----
+    mg = {"rccl_ranks": ws if (ws > 1 and not test_backend) else 0, "transport": "none", "selftest": "n/a"}
+    if ws > 1 and not test_backend:
+        try:
+            nb0 = batch.NativeBatch.from_torch_distributed(local_rank)
+            mg["transport"] = nb0.transport
+            if distinct and nb0.transport != "rccl":
+                raise RuntimeError("ranks on distinct GPUs but transport %r" % nb0.transport)
+            nb0.set_persist(False)
+            frames = torch.rand((ws, 1080, 1920), generator=torch.Generator(device=dev).manual_seed(77), device=dev) if rank == 0 else None
+            res = torch.empty((ws, 3, 1080, 1920), device=dev) if rank == 0 else None
+            nb0.run(frames, ws, (1080, 1920), outputs=(5, 6, 7), out=res)
+            ok = 1.0
+            if rank == 0:
+                fr_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+                fr_.set_persist(False)
+                want = fr_.pipeline_batch(frames, outputs=(5, 6, 7))
+                torch.cuda.synchronize()
+                ok = 1.0 if torch.equal(want, res) else 0.0
+                del fr_, want
+            (bad,) = max_over_ranks(1.0 - ok)
+            mg["selftest"] = "ok" if bad == 0.0 else "MISMATCH"
+            nb0.close()
+            del frames, res
+            if bad != 0.0:
+                raise SystemExit("bench.py: frames sent through ncclSend/ncclRecv came back different from the single-GPU run")
+        except SystemExit:
+            raise
+        except Exception as ex:
+            mg["selftest"] = "error: %s: %s" % (type(ex).__name__, str(ex)[:80])
+
+    settle(step, f)
     R = max(1, args.repeats)
     walls, evs = _time_steps(torch, step, args.steps, args.warmup, barrier, repeats=R)
     # per repeat: the slowest rank; then the median over the repeats
@@ -550,69 +587,60 @@ def main():
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("k_basis_g2_steer_4096", {}).get("hbm_bytes_per_launch")
-            traffic_source = "profiles/traffic.json (replayed from the committed rocprofv3 --pmc passes of this kernel; not measured in this run: %s)" % live_why
+            traffic_source = "replayed from profiles/traffic.json (committed rocprofv3 --pmc passes)"
         except Exception:
             traffic = None
 
-    info = f.launch_info()
+    valu_tab = _valu_table()
+    clock = {"mhz": None}
+
+    def frac_valu(key, pix, ms):
+        """fraction of the VALU roof: vector instructions of the launch x 2 cycles / (1024 SIMDs x shader clock) / measured time"""
+        per = valu_tab.get(key)
+        if not per:
+            return None
+        mhz = clock["mhz"] or NOMINAL_SCLK_MHZ
+        return round(per * pix * VALU_CYCLES_PER_INST / N_SIMD / (mhz * 1e6) / (ms * 1e-3), 4)
+
     out.update({
         "value": round(value, 1), "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "repeats": {"repeats": R, "of": "the %d-step timed region (barrier + synchronize on both sides, slowest rank per repeat)" % args.steps,
-                    "ms_per_step": {"min": round(min(walls) / args.steps * 1e3, 5), "median": round(wall / args.steps * 1e3, 5),
-                                    "max": round(max(walls) / args.steps * 1e3, 5)},
-                    "Mpix/s": {"min": round(ws * args.steps * npix / max(walls) / 1e6, 1), "median": round(value, 1),
-                               "max": round(ws * args.steps * npix / min(walls) / 1e6, 1)},
-                    "event_ms_per_launch": {"min": round(min(evs) / args.steps, 5), "median": round(k_ms, 5), "max": round(max(evs) / args.steps, 5)}},
-        "config": {"workload": "G2+H2 7-basis separable pass + scalar steer (theta=0.3), one 4096x4096 f32 image "
-                               "per GPU per step, image resident in HBM, bases persisted (BASELINE configs[1])",
-                   "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "sharding": "images per rank, no collective",
-                   "init_calls": INIT_CALLS, "lead_in": "every timed region follows >= W untimed steps of the same call (about %g ms of GPU time) "
-                                                        "with only the synchronize + barrier in between; extra.*_after_idle = with a 30 ms pause instead" % LEAD_IN_MS,
+        "config": {"workload": "G2+H2 7-basis separable pass + scalar steer, one 4096x4096 f32 image per GPU per step, resident in HBM (BASELINE configs[1])",
+                   "rows": ROWS, "cols": COLS, "width": 4, "spacing": 0.67, "theta": THETA, "sharding": "images per rank, no collective",
                    "backend": backend, "ranks_started_by": "bench.py" if os.environ.get("CVS_BENCH_SPAWNED") else ("launcher" if ws > 1 else "single process"),
-                   "library_defaults": not args.placement and not args.strip_rows,
-                   "output_planes": "g, h = cv.alloc_planes(2, rows, cols): rows of one block, what setup_steer() allocates by itself",
-                   "placement": {"mode": info["placement_mode"], "window_found": bool(info["window_found"]), "probe_ms": round(info["probe_ms"], 3),
-                                 "note": "CVS_OPT_PLACEMENT_SEARCH of the headline handle; 0 = plain hipMalloc block, the library default "
-                                         "(the opt-in search is reported as extra.M2_placement_window)"},
-                   "launch": dict(launch_of(f), note="configuration of the timed launches: the engine's default or what its online tuner kept; "
-                                                     "tuning_launches = launches issued beyond the caller's own calls")},
-        "clocks": {"value": "host wall clock around the timed region, median of the repeats",
-                   "roofline": "HIP events on the launch stream around the same region, median of the repeats; roofline.frac_wall = the same from the wall clock"},
+                   "library_defaults": not args.strip_rows, "repeats": R, "lead_in_ms": LEAD_IN_MS,
+                   "Mpix_s_min": round(ws * args.steps * npix / max(walls) / 1e6, 1), "Mpix_s_max": round(ws * args.steps * npix / min(walls) / 1e6, 1),
+                   "distinct_devices": distinct, "launch_config": cfg_index(f)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_wall": round(achieved_wall / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "cvs::k_basis<BankG2, F_STEER>", "algorithmic_bytes_per_launch": BYTES_PER_PIX["M2"] * npix,
-                     "avg_launch_ms": round(k_ms, 5)},
-        "multi_gpu": {"rccl_ranks": ws if (ws > 1 and not test_backend) else 0, "ranks": ws, "device_uuids": uuids, "distinct_devices": distinct,
-                      "transport": None, "note": "filled in by the C4_e2e / C3 band-split legs when ranks > 1"},
+                     "avg_launch_ms": round(k_ms, 5), "ms_min": round(min(evs) / args.steps, 5), "ms_max": round(max(evs) / args.steps, 5),
+                     "rccl_ranks": mg["rccl_ranks"], "transport": mg["transport"], "rccl_selftest": mg["selftest"]},
     })
+    rf = out["roofline"]
 
-    # ---- north_star's own target, at the top level: the G2+H2 7-basis separable pass ALONE (M1, 32 B/pix), same handle,
-    # same image, library defaults, timed like the headline (median of the repeats, slowest rank) ----
+    # ---- north_star's own target: the G2+H2 7-basis separable pass ALONE (M1, 32 B/pix), same handle, same image, library
+    # defaults, timed like the headline (median of the repeats, slowest rank) ----
     def step_m1():
         f.setup(img, flags=cv.SETUP_BASIS)
 
-    settle(step_m1)
-    R1 = R   # as many repeats as the headline: a region of 20 steps is 2 ms long, and at the power cap the card's clock control makes
-             # single regions scatter by +-3 % (min / max of the repeats are in the line); the median of 15 is good to ~1 %
-    _w1, e1 = _time_steps(torch, step_m1, args.steps, args.warmup, barrier, repeats=R1)
+    settle(step_m1, f)
+    _w1, e1 = _time_steps(torch, step_m1, args.steps, args.warmup, barrier, repeats=R)
     e1 = sorted(v / args.steps for v in max_over_ranks(*e1))
     m1_ms = _median(e1)
-    out["roofline_m1"] = {"bound": "hbm", "kernel": "cvs::k_basis<BankG2, 0>", "frac": round(BYTES_PER_PIX["M1"] * npix / (m1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                          "achieved": round(BYTES_PER_PIX["M1"] * npix / (m1_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "avg_launch_ms": round(m1_ms, 5), "ms_min": round(e1[0], 5), "ms_max": round(e1[-1], 5), "repeats": R1,
-                          "Mpix/s": round(npix / (m1_ms * 1e-3) / 1e6, 1), "algorithmic_bytes_per_launch": BYTES_PER_PIX["M1"] * npix,
-                          "target": "north_star: >= 0.70 of the HBM roofline on this pass", "launch": launch_of(f)}
-    settle(step, 4)   # back to the headline entry point
+    rf.update({"m1_frac": round(BYTES_PER_PIX["M1"] * npix / (m1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "m1_ms": round(m1_ms, 5),
+               "m1_ms_min": round(e1[0], 5), "m1_ms_max": round(e1[-1], 5), "m1_Mpix_s": round(npix / (m1_ms * 1e-3) / 1e6, 1),
+               "m1_target": ">= 0.70 (north_star)"})
+    legs["M1_basis"] = [rf["m1_frac"], rf["m1_ms"], rf["m1_ms_min"], rf["m1_ms_max"], cfg_index(f), None]
+    settle(step, None, 4)   # back to the headline entry point
 
     # ---- secondary legs (reported, not the headline) ----
     # Insurance for runs with several ranks: the secondary legs contain collectives (barriers, the RCCL scatter / gather
-    # of `C4_e2e`) that have only ever run on one GPU here.  If a rank fails inside a leg, the others would wait in a
-    # collective for ever and the headline measured above would be lost with them.  A watchdog armed for the secondary
-    # legs makes every rank leave after `--extra-timeout` seconds: rank 0 prints the JSON line with the headline, the
-    # legs finished so far and an `extra_error` note, and all ranks exit with status EXIT_WATCHDOG (non-zero).  A rank
-    # that CRASHES is covered by the SIGTERM watcher above (the launcher stops the siblings; rank 0 prints first).
+    # of `C4_e2e`).  If a rank fails inside a leg, the others would wait in a collective for ever and the headline measured
+    # above would be lost with them.  A watchdog armed for the secondary legs makes every rank leave after `--extra-timeout`
+    # seconds: rank 0 prints the JSON line with the headline, the legs finished so far and an `extra_error` note, and all
+    # ranks exit with status EXIT_WATCHDOG (non-zero).  A rank that CRASHES is covered by the SIGTERM watcher above.
     def watchdog():
         emit(False, "secondary legs did not finish within %d s (watchdog); headline unaffected" % args.extra_timeout)
         os._exit(EXIT_WATCHDOG)   # non-zero: a hung or failed set of secondary legs must not look like a clean run
@@ -627,26 +655,33 @@ def main():
         if os.environ.get("CVS_BENCH_TEST_CRASH_RANK") == str(rank):   # tests only: a rank that dies inside the secondary legs
             os._exit(17)
         ksteps, kwarm = args.steps, max(5, args.warmup)
-
-        def rate(ms, bpp, pix):
-            return {"Mpix/s": round(pix / (ms * 1e-3) / 1e6, 1), "ms": round(ms, 5), "GB/s": round(bpp * pix / (ms * 1e-3) / 1e9, 1),
-                    "frac_hbm": round(bpp * pix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "B/pix": bpp}
-
         LR = max(1, args.leg_repeats)
 
-        def timed(fn, steps, warm):
+        def timed(fn, steps, warm, idle_s=0.0):
             """median / min / max over LR repeats of the HIP-event time per step (slowest rank per repeat)"""
-            _w, e_ = _time_steps(torch, fn, steps, warm, barrier, repeats=LR)
+            _w, e_ = _time_steps(torch, fn, steps, warm, barrier, repeats=LR, idle_s=idle_s)
             per = sorted(v / steps for v in max_over_ranks(*e_))
             return _median(per), per[0], per[-1]
 
-        def leg(name, fn, bpp, pix=npix, steps=None, warm=None, handle=None, settle_calls=SETTLE_CALLS):
-            if settle_calls:
-                settle(fn, settle_calls)
-            ms, lo, hi = timed(fn, steps or ksteps, kwarm if warm is None else warm)
-            extra[name] = dict(rate(ms, bpp, pix), ms_min=round(lo, 5), ms_max=round(hi, 5), repeats=LR)
-            if handle is not None:
-                extra[name]["launch"] = launch_of(handle)
+        def record(name, ms, lo, hi, bpp, pix, handle=None, valu_key=None):
+            fr = round(bpp * pix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            legs[name] = [fr, round(ms, 5), round(lo, 5), round(hi, 5), cfg_index(handle) if handle is not None else None,
+                          frac_valu(valu_key, pix, ms) if valu_key else None]
+            return fr
+
+        def leg(name, fn, bpp, pix=npix, steps=None, warm=None, handle=None, settle_calls=None, valu_key=None, idle_s=0.0):
+            settle(fn, handle if settle_calls is None else None, settle_calls)
+            ms, lo, hi = timed(fn, steps or ksteps, kwarm if warm is None else warm, idle_s)
+            return record(name, ms, lo, hi, bpp, pix, handle, valu_key)
+
+        # clock and power of this card while the headline runs back to back (the VALU roofs below use this clock)
+        fs = _telemetry_files(torch, local_rank) if rank == 0 else None
+        if fs:
+            sus = _sustained(torch, fs, step)
+            clock["mhz"] = sus["sclk_mhz"]
+            rf.update({"sclk_mhz": sus["sclk_mhz"], "power_w": sus["power_w"], "power_cap_w": sus["cap_w"], "sustained_ms": sus["ms"]})
+        rf["valu_frac"] = frac_valu("M2", npix, k_ms)
+        rf["m1_valu_frac"] = legs["M1_basis"][5] = frac_valu("M1", npix, m1_ms)
 
         # the headline loop re-filters ONE 64 MiB image, which can stay resident in the 256 MiB Infinity Cache
         # between steps; this leg rotates 8 distinct images (512 MiB) so every input read comes from HBM
@@ -657,220 +692,126 @@ def main():
             rot["i"] = (rot["i"] + 1) & 7
             f.setup_steer(imgs8[rot["i"]], THETA, flags=cv.SETUP_BASIS, out=(g, h))
 
-        leg("M2_rotating_8_inputs", step_rot, BYTES_PER_PIX["M2"], handle=f)
-
-        # 8-bit images, what the reference's callers hold (test/test.cpp:73,85; example/steer.cpp:73-86): read as bytes by the
-        # kernel itself, 1 B/pix of input -> 1 + 36 = 37 algorithmic bytes per pixel; 8 images take turns
-        imgs8_u8 = [(im * 255.0).to(torch.uint8) for im in imgs8]
-
-        def step_rot_u8():
-            rot["i"] = (rot["i"] + 1) & 7
-            f.setup_steer(imgs8_u8[rot["i"]], THETA, flags=cv.SETUP_BASIS, out=(g, h))
-
-        leg("M2_u8_input_rotating", step_rot_u8, BYTES_PER_PIX["M2_u8"], handle=f)
-        extra["M2_u8_input_rotating"]["note"] = "8 rotating 8-bit images, bytes read inside the filter kernel (no widening pass): 1 B in + 36 B out per pixel"
-        del imgs8_u8
-
-        # the engine's defaults without the online tuner, same image, same outputs
-        fu = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-        fu.set_option(L.OPT_AUTOTUNE, 0)
-        leg("M2_untuned", lambda: fu.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], handle=fu, settle_calls=4)
-        extra["M2_untuned"]["note"] = "fresh handle, CVS_OPT_AUTOTUNE=0 (the engine's default configuration from the first call)"
-        del fu
+        rf["fresh_frac"] = leg("M2_fresh_8_rotating", step_rot, BYTES_PER_PIX["M2"], handle=f, valu_key="M2")
 
         # the reference's usage pattern: ONE object per image (example/steer.cpp:86, test/test.cpp:85).
-        # (a) `M2_one_object_per_image`: a loop of 64 objects -- create, one fused call, destroy -- on a stream of different
-        #     images WITHOUT any host synchronisation between them (cvs_destroy parks the state block with an event, the next
-        #     object's launch is queued behind it): HIP events around the whole loop / 64.
-        # (b) `M2_first_call`: the same object by object with a synchronisation after each (latency view): `ms` = events
-        #     around the single call, `ms_object` = wall time of create + call + sync + destroy; cold = the process-wide
-        #     state-block cache emptied first (hipMalloc of 0.8 GB inside the call).
+        # (a) a loop of 64 objects -- create, one fused call, destroy -- on a stream of different images WITHOUT any host
+        #     synchronisation between them (cvs_destroy parks the state block with an event): HIP events around the loop / 64.
+        # (b) the same object by object with a synchronisation after each (latency view): events around the single call.
         def object_loop(nobj):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for i in range(nobj):
                 fo = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
                 fo.setup_steer(imgs8[i & 7], THETA, flags=cv.SETUP_BASIS, out=(g, h))
                 del fo
-            e1.record()
+            e1_.record()
             torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / nobj
+            return e0.elapsed_time(e1_) / nobj
 
-        object_loop(SETTLE_CALLS)
+        object_loop(MAX_SETTLE_CALLS)
         per_obj = sorted(max_over_ranks(*[object_loop(64) for _ in range(LR)]))
-        extra["M2_one_object_per_image"] = dict(rate(_median(per_obj), BYTES_PER_PIX["M2"], npix), ms_min=round(per_obj[0], 5), ms_max=round(per_obj[-1], 5),
-                                                repeats=LR, objects_per_repeat=64,
-                                                note="64 x (create, one fused filter+steer call on a different image, destroy), no host synchronisation "
-                                                     "inside the loop; events around the loop / 64")
+        rf["one_object_frac"] = record("M2_one_object_per_image", _median(per_obj), per_obj[0], per_obj[-1], BYTES_PER_PIX["M2"], npix, valu_key="M2")
 
         def one_object(image):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
+            e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fo = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
             e0.record()
             fo.setup_steer(image, THETA, flags=cv.SETUP_BASIS, out=(g, h))
-            e1.record()
+            e1_.record()
             torch.cuda.synchronize()
             del fo
-            return (time.perf_counter() - t0) * 1e3, e0.elapsed_time(e1)
+            return e0.elapsed_time(e1_)
 
-        torch.cuda.synchronize()
-        cv.lib().cvs_release_cached_memory()
-        cold = one_object(imgs8[1])
-        runs = [one_object(imgs8[(2 + i) & 7]) for i in range(10)]
-        ms_call = sorted(r[1] for r in runs)[len(runs) // 2]
-        ms_obj = sorted(r[0] for r in runs)[len(runs) // 2]
-        extra["M2_first_call"] = dict(rate(ms_call, BYTES_PER_PIX["M2"], npix), ms_object=round(ms_obj, 4),
-                                      ms_call_cold=round(cold[1], 4), ms_object_cold=round(cold[0], 4),
-                                      note="one new handle per image with a host synchronisation after each; median of 10; "
-                                           "ms = events around the single call (includes the host's launch latency on an idle GPU), "
-                                           "ms_object = create+call+sync+destroy wall; cold = block cache emptied first")
+        runs = sorted(one_object(imgs8[(2 + i) & 7]) for i in range(10))
+        rf["first_call_frac"] = record("M2_first_call_synchronised", _median(runs), runs[0], runs[-1], BYTES_PER_PIX["M2"], npix)
+        # a caller that does host work between images (example/steer.cpp:73-122) meets an idle card: 30 ms of pause before every region
+        rf["after_idle_frac"] = leg("M2_after_idle", step, BYTES_PER_PIX["M2"], handle=f, settle_calls=4, valu_key="M2", idle_s=0.03)
+
+        if args.all_legs:
+            # 8-bit images, what the reference's callers hold (test/test.cpp:73,85): read as bytes by the kernel itself
+            imgs8_u8 = [(im * 255.0).to(torch.uint8) for im in imgs8]
+
+            def step_rot_u8():
+                rot["i"] = (rot["i"] + 1) & 7
+                f.setup_steer(imgs8_u8[rot["i"]], THETA, flags=cv.SETUP_BASIS, out=(g, h))
+
+            leg("M2_u8_fresh_8_rotating", step_rot_u8, BYTES_PER_PIX["M2_u8"], handle=f)
+            del imgs8_u8
+            fu = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)   # the engine's defaults without the online tuner
+            fu.set_option(L.OPT_AUTOTUNE, 0)
+            leg("M2_untuned_handle", lambda: fu.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], handle=fu, settle_calls=4)
+            del fu
         del imgs8
 
-        # the library's OPT-IN placement search (CVS_OPT_PLACEMENT_SEARCH = 1, planar per-plane windows): the headline loop on a
-        # handle with the knob on -- what it finds and costs on THIS box
-        try:
-            fp_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-            fp_.set_option(L.OPT_PLACEMENT_SEARCH, 1)
-            leg("M2_placement_window", lambda: fp_.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h)), BYTES_PER_PIX["M2"], handle=fp_)
-            pi_ = fp_.launch_info()
-            extra["M2_placement_window"].update({"window_found": bool(pi_["window_found"]), "probe_ms": round(pi_["probe_ms"], 3),
-                                                 "note": "CVS_OPT_PLACEMENT_SEARCH = 1 (opt-in tuning knob, off by default), otherwise the headline loop"})
-            del fp_
-        except Exception as ex:
-            extra["M2_placement_window"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-
-        if ws == 1:
-            # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in and out -- a
-            # stream of 8 different host images, 64 MiB up and 2 x 64 MiB down per image, pageable host memory.  The call
-            # overlaps upload, filtering and download band by band (cvs_host.cpp); `sequential` is the same
-            # with CVS_OPT_HOST_OVERLAP = 0.  Floor of the link: 128 MiB down at ~56 GB/s = 2.4 ms per image.
-            # (for a second or two after gigabytes of device memory have been released host-link copies of the process run
-            # at about half rate, tools/d2h_probe.hip; the handles below are created and warmed first, then the leg waits)
+        if ws == 1 and args.all_legs:
+            # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in and out
             import numpy as np
             himgs = [np.random.default_rng(500 + i).random((ROWS, COLS), dtype=np.float32) for i in range(8)]
             hg, hh = np.empty_like(himgs[0]), np.empty_like(himgs[0])
-            fhs = {}
-            for overlap in (0, 1):
-                fhs[overlap] = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-                fhs[overlap].set_option(L.OPT_HOST_OVERLAP, overlap)
-                fhs[overlap].setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
+            fh_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+            fh_.setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
             torch.cuda.synchronize()
-            time.sleep(2.5)
+            time.sleep(2.5)   # host-link copies run at half rate for a moment after large device frees
 
-            def host_stream(overlap):
+            def host_stream():
                 t0 = time.perf_counter()
                 for im in himgs:
-                    fhs[overlap].setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
+                    fh_.setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
                 return (time.perf_counter() - t0) / len(himgs)
 
-            # two interleaved passes, the better one of each mode (the first pass also pages the host arrays in)
-            dt_seq, dt_ovl = min(host_stream(0), host_stream(0)), min(host_stream(1), host_stream(1))
-            dt_seq, dt_ovl = min(dt_seq, host_stream(0)), min(dt_ovl, host_stream(1))
-            del fhs
-            extra["M2_host_planes_pcie_inclusive"] = {"Mpix/s": round(npix / dt_ovl / 1e6, 1), "ms": round(dt_ovl * 1e3, 3),
-                                                      "sequential_Mpix/s": round(npix / dt_seq / 1e6, 1), "sequential_ms": round(dt_seq * 1e3, 3),
-                                                      "note": "stream of 8 host f32 images in, g2/h2 out to host, bases stay on device; "
-                                                              "link floor = 128 MiB down per image"}
-            del himgs
+            dt = min(host_stream(), host_stream(), host_stream())
+            legs["M2_host_planes_pcie_inclusive"] = [None, round(dt * 1e3, 3), None, None, None, None]
+            out["pcie_inclusive_Mpix_s"] = round(npix / dt / 1e6, 1)
+            del himgs, fh_
 
-        if ws == 1:
-            # throughput mode: consecutive images go to two handles on two HIP streams, so the tail of one launch
-            # overlaps the start-up of the next (tools/two_streams.py)
-            f2 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-            img2 = torch.rand((ROWS, COLS), generator=gen, device=dev, dtype=torch.float32)
-            g2_, h2_ = torch.empty_like(img), torch.empty_like(img)
-            side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-            pair = [(f, img, (g, h)), (f2, img2, (g2_, h2_))]
-            flip = {"i": 0}
-
-            def step_two():
-                flip["i"] ^= 1
-                fi, im, oo = pair[flip["i"]]
-                with torch.cuda.stream(side[flip["i"]]):
-                    fi.setup_steer(im, THETA, flags=cv.SETUP_BASIS, out=oo)
-
-            def timed_two(k):
-                main = torch.cuda.current_stream()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(main)
-                for st in side:
-                    st.wait_event(e0)
-                for _ in range(k):
-                    step_two()
-                for st in side:
-                    main.wait_stream(st)
-                e1.record(main)
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / k
-
-            timed_two(2 * SETTLE_CALLS)
-            ms2 = timed_two(ksteps)
-            extra["M2_two_streams_two_images"] = dict(rate(ms2, 40, npix), note="alternating images on two handles / two streams; not the headline configuration")
-            torch.cuda.current_stream().synchronize()
-            f.setup_steer(img, THETA, flags=cv.SETUP_BASIS, out=(g, h))  # back on the main stream
-            del f2, img2, g2_, h2_
             def same_handle_default(name, fn, bpp):
-                """the leg just timed, on the SAME handle (same state block) with the tuner switched off: what the tuner's pick is
-                worth.  (`M2_untuned` is another handle: another state block, worth up to +-5 % by itself on the 12- / 20-plane launches)"""
+                """the leg just timed, on the SAME handle (same state block) with the tuner switched off: what the tuner's pick is worth"""
                 f.set_option(L.OPT_AUTOTUNE, 0)
                 leg(name, fn, bpp, handle=f, settle_calls=4)
                 f.set_option(L.OPT_AUTOTUNE, 1)
                 fn()
+        else:
+            same_handle_default = None
 
-            same_handle_default("M2_default_same_handle", step, BYTES_PER_PIX["M2"])
-            same_handle_default("M1_default_same_handle", step_m1, BYTES_PER_PIX["M1"])
-            leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"], handle=f)
-            same_handle_default("M4_default_same_handle", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"])
+        if ws == 1:
+            rf["m4_frac"] = leg("M4_full_setup", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"], handle=f, valu_key="M4")
+            if same_handle_default:
+                same_handle_default("M4_tuner_off_same_handle", lambda: f.setup(img, flags=cv.SETUP_FULL), BYTES_PER_PIX["M4"])
             # the eight outputs of the pipeline as rows of ONE block ([row][plane][column]; cv.alloc_planes), the layout the
-            # engine gives its own state planes: strided views like any cv::Mat ROI.  `M5_pipeline_separate_outputs` = eight
-            # separate allocations (rounds 1-3).
+            # engine gives its own state planes: strided views like any cv::Mat ROI
             outs8 = cv.alloc_planes(8, ROWS, COLS, device=dev)
-            leg("M5_pipeline", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"], handle=f)
-            same_handle_default("M5_default_same_handle", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"])
-            outs8s = [torch.empty_like(img) for _ in range(8)]
-            leg("M5_pipeline_separate_outputs", lambda: f.pipeline(img, out=outs8s), BYTES_PER_PIX["M5"], handle=f, settle_calls=8)
-            del outs8s
+            rf["m5_frac"] = leg("M5_pipeline", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"], handle=f, valu_key="M5")
+            rf["m5_after_idle_frac"] = leg("M5_pipeline_after_idle", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"], handle=f, settle_calls=4, valu_key="M5", idle_s=0.03)
+            if same_handle_default:
+                same_handle_default("M5_tuner_off_same_handle", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"])
+                outs8s = [torch.empty_like(img) for _ in range(8)]
+                leg("M5_pipeline_separate_outputs", lambda: f.pipeline(img, out=outs8s), BYTES_PER_PIX["M5"], handle=f, settle_calls=8)
+                del outs8s
             f.setup(img, flags=cv.SETUP_FULL)
-            leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36, settle_calls=4)
-            leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), 64, settle_calls=4)
+            leg("M3_steer_map_full", lambda: f.steer(None, full=True, out=outs8[:5]), BYTES_PER_PIX["M3"], settle_calls=4)
+            if args.all_legs:
+                leg("M3_steer_scalar", lambda: f.steer(THETA, out=(g, h)), 36, settle_calls=4)
             f4 = cv.SteerableFiltersG4(None, 6, 0.5, device=local_rank)
-            leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"], handle=f4)
-            leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"], handle=f4)
-            # what a lead-in without a pause is worth: the same two launches with 30 ms of idleness in front of every region
-            for nm, fn_, bpp_ in (("M5_pipeline_after_idle", lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"]),
-                                  ("M6_g4_basis_after_idle", lambda: f4.setup(img), BYTES_PER_PIX["M6"])):
-                _w, e_ = _time_steps(torch, fn_, ksteps, kwarm, barrier, repeats=LR, idle_s=0.03)
-                per = sorted(v / ksteps for v in max_over_ranks(*e_))
-                extra[nm] = dict(rate(_median(per), bpp_, npix), ms_min=round(per[0], 5), ms_max=round(per[-1], 5), repeats=LR,
-                                 note="the card idle for 30 ms before every timed region of %d steps: the first launches run at the shader "
-                                      "clock the power management had dropped to (every other leg is led into without a pause)" % ksteps)
-            # clock and power of this card while three of the launches above run back to back for a second each
-            fs = _telemetry_files(torch, local_rank) if rank == 0 else None
-            if fs:
-                sus = {"M2_filter_steer": (step, BYTES_PER_PIX["M2"]), "M5_pipeline": (lambda: f.pipeline(img, out=outs8), BYTES_PER_PIX["M5"]),
-                       "M6_g4_basis": (lambda: f4.setup(img), BYTES_PER_PIX["M6"])}
-                tel = {}
-                for name, (fn, bpp) in sus.items():
-                    tel[name] = _sustained(torch, fs, fn)
-                    tel[name]["frac_hbm"] = round(bpp * npix / (tel[name]["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                tel["note"] = ("each launch back to back for 1 s, host synchronisation every 50 calls; median shader clock and package power of "
-                               "the second half, from the card's hwmon files.  The card sits at its power cap under these launches and the "
-                               "shader clock is what the cap leaves: a lower clock on another box shows first in the VALU-heavier launches")
-                out["device_telemetry"] = tel
+            rf["g4_frac"] = leg("M6_g4_basis", lambda: f4.setup(img), BYTES_PER_PIX["M6"], handle=f4, valu_key="M6")
+            rf["g4_steer_frac"] = leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"], handle=f4, valu_key="M6s")
+            rf["g4_after_idle_frac"] = leg("M6_g4_basis_after_idle", lambda: f4.setup(img), BYTES_PER_PIX["M6"], handle=f4, settle_calls=4, valu_key="M6", idle_s=0.03)
+            rf["g4_valu_frac"] = legs["M6_g4_basis"][5]
+            rf["g4_bound"] = "valu" if (rf["g4_valu_frac"] or 0) > rf["g4_frac"] else "hbm"
+            if fs:   # what these two run at when sustained (they follow the shader clock)
+                for nm, fn_ in (("m5", lambda: f.pipeline(img, out=outs8)), ("g4", lambda: f4.setup(img))):
+                    s_ = _sustained(torch, fs, fn_, 0.4)
+                    rf[nm + "_sclk_mhz"] = s_["sclk_mhz"]
                 step()
             del outs8, f4
-            # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed
-            # start-up cost of a launch (every wave primes its 8-row window before its first store) amortises
+            # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed start-up cost of
+            # a launch (every wave primes its 8-row window before its first store) amortises -- and with two images taking turns
             big2 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
             fb = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
             gb, hb = torch.empty_like(big2), torch.empty_like(big2)
             bsteps = max(5, args.steps // 4)
-            leg("M1_basis_only_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32, pix=4 * npix, steps=bsteps, warm=2, handle=fb)
-            leg("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40, pix=4 * npix, steps=bsteps, warm=2, handle=fb)
-            # ... and with two images taking turns: the two legs above re-filter ONE 256 MiB image, most of which is still in
-            # the 256 MiB Infinity Cache when the next step starts (the streaming stores do not displace it); any launch in
-            # between that touches 64 MiB ends that (round 2, profiles/r02_issue_and_c3_probes.txt), and so does a second image
+            leg("M1_basis_8192", lambda: fb.setup(big2, flags=cv.SETUP_BASIS), 32, pix=4 * npix, steps=bsteps, warm=2, handle=fb, valu_key="M1")
+            leg("M2_filter_steer_8192", lambda: fb.setup_steer(big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb)), 40, pix=4 * npix, steps=bsteps, warm=2, handle=fb, valu_key="M2")
             big3 = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32)
             flipb = {"i": 0}
 
@@ -878,29 +819,25 @@ def main():
                 flipb["i"] ^= 1
                 fb.setup_steer(big3 if flipb["i"] else big2, THETA, flags=cv.SETUP_BASIS, out=(gb, hb))
 
-            leg("M2_filter_steer_8192_rotating_2_inputs", step_big_rot, 40, pix=4 * npix, steps=bsteps, warm=2, handle=fb)
+            rf["fresh_8192_frac"] = leg("M2_filter_steer_8192_fresh_2_rotating", step_big_rot, 40, pix=4 * npix, steps=bsteps, warm=2, handle=fb, valu_key="M2")
             del big2, big3, fb, gb, hb
 
         # ---- BASELINE config 4: 1080 x 1920 frames, the callers' whole pipeline per frame, 32 frames per GPU ----
-        # Two frame sets alternate so that every launch reads frames the previous launch did not touch (2 x 265 MB
-        # of inputs + 2.1 GB of outputs per launch pass through the 256 MiB Infinity Cache in between); >= 10 timed steps.
+        # Two frame sets alternate so that every launch reads frames the previous launch did not touch; >= 10 timed steps.
         nfr = 32
         fsets = [torch.rand((nfr, 1080, 1920), generator=gen, device=dev, dtype=torch.float32) for _ in range(2)]
         fout = torch.empty((nfr, 8, 1080, 1920), device=dev)
         ff = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
         csteps = max(10, args.steps // 10)
         alt = {"i": 0}
+        fp = nfr * 1080 * 1920
 
         def step_c4():
             alt["i"] ^= 1
             ff.pipeline_batch(fsets[alt["i"]], out=fout)
 
-        settle(step_c4)
-        ms, ms_lo, ms_hi = timed(step_c4, csteps, 2)
-        fp = nfr * 1080 * 1920
-        extra["C4_32x1080p_pipeline_batch"] = dict(rate(ms, 84, ws * fp), ms_per_frame=round(ms / nfr, 5), launches_per_batch=1,
-                                                   frames_per_gpu=nfr, timed_steps=csteps, frame_sets=2, ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR,
-                                                   launch=launch_of(ff))
+        rf["c4_frac"] = leg("C4_32x1080p_pipeline_state_kept", step_c4, 84, pix=fp, steps=csteps, warm=2, handle=ff, valu_key="M5")
+        out["c4_Mpix_s"] = round(ws * fp / (legs["C4_32x1080p_pipeline_state_kept"][1] * 1e-3) / 1e6, 1)
         ff.set_persist(False)
         fo3 = torch.empty((nfr, 3, 1080, 1920), device=dev)
 
@@ -908,24 +845,19 @@ def main():
             alt["i"] ^= 1
             ff.pipeline_batch(fsets[alt["i"]], out=fo3, outputs=(5, 6, 7))
 
-        settle(step_c4f)
-        ms, ms_lo, ms_hi = timed(step_c4f, csteps, 2)
-        extra["C4_32x1080p_feature_maps_only"] = dict(rate(ms, 16, ws * fp), ms_per_frame=round(ms / nfr, 5), timed_steps=csteps,
-                                                      ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR, launch=launch_of(ff),
-                                                      note="edges + dark + bright only, no state persisted (what example/steer.cpp keeps)")
-        # ... and from 8-bit frames, the example's sources (steer.cpp:73-80): bytes read inside the kernel, 1 + 12 = 13 B/pix
-        fsets_u8 = [(fs * 255.0).to(torch.uint8) for fs in fsets]
+        leg("C4_32x1080p_three_maps_only", step_c4f, BYTES_PER_PIX["C4_feat3"], pix=fp, steps=csteps, warm=2, handle=ff, valu_key="C4_feat3")
+        rf["c4_maps_Gpix_s"] = round(ws * fp / (legs["C4_32x1080p_three_maps_only"][1] * 1e-3) / 1e9, 1)
+        rf["c4_maps_valu_frac"] = legs["C4_32x1080p_three_maps_only"][5]
+        if args.all_legs:
+            fsets_u8 = [(fs_ * 255.0).to(torch.uint8) for fs_ in fsets]
 
-        def step_c4f_u8():
-            alt["i"] ^= 1
-            ff.pipeline_batch(fsets_u8[alt["i"]], out=fo3, outputs=(5, 6, 7))
+            def step_c4f_u8():
+                alt["i"] ^= 1
+                ff.pipeline_batch(fsets_u8[alt["i"]], out=fo3, outputs=(5, 6, 7))
 
-        settle(step_c4f_u8)
-        ms, ms_lo, ms_hi = timed(step_c4f_u8, csteps, 2)
-        extra["C4_32x1080p_u8_feature_maps"] = dict(rate(ms, BYTES_PER_PIX["C4_u8_feat3"], ws * fp), ms_per_frame=round(ms / nfr, 5), timed_steps=csteps,
-                                                    ms_min=round(ms_lo, 5), ms_max=round(ms_hi, 5), repeats=LR, launch=launch_of(ff),
-                                                    note="8-bit frames in (read as bytes by the kernel), edges + dark + bright out, no state persisted")
-        del fout, fo3, fsets_u8
+            leg("C4_32x1080p_u8_three_maps", step_c4f_u8, BYTES_PER_PIX["C4_u8_feat3"], pix=fp, steps=csteps, warm=2, handle=ff)
+            del fsets_u8
+        del fout, fo3
 
         # ---- config 4 end to end through the NATIVE batch entry (cvs_batch_run, cvs_batch.cpp): frames on rank 0 ->
         # scatter (grouped ncclSend/ncclRecv) -> one fused launch per rank -> gather of the three feature maps on rank 0.
@@ -941,7 +873,7 @@ def main():
                 if ws > 1 and distinct and nbat.transport != "rccl":
                     raise RuntimeError("%d ranks on distinct GPUs but the batch layer chose transport %r -- a rehearsal transport must "
                                        "never carry a real multi-GPU run" % (ws, nbat.transport))
-                out["multi_gpu"]["transport"] = nbat.transport
+                rf["transport"] = nbat.transport
                 nbat.set_persist(False)
                 e2e_out = torch.empty((n_all, 3) + shape, device=dev) if rank == 0 else None
                 reps, acc, wall_e2e = 5, {"scatter": 0.0, "compute": 0.0, "gather": 0.0}, 0.0
@@ -955,68 +887,43 @@ def main():
                             acc[k] += tm[k] / reps
                 acc = dict(zip(acc.keys(), max_over_ranks(*acc.values())))
                 (wall_e2e,) = max_over_ranks(wall_e2e)
-                extra["C4_e2e"] = {"frames": n_all, "ms": {k: round(v, 3) for k, v in acc.items()}, "ms_wall": round(wall_e2e * 1e3, 3),
-                                   "compute_only_Mpix/s": round(n_all * 1080 * 1920 / (acc["compute"] * 1e-3) / 1e6, 1),
-                                   "end_to_end_Mpix/s": round(n_all * 1080 * 1920 / wall_e2e / 1e6, 1),
-                                   "gathered": "3 feature maps per frame on rank 0", "entry": "cvs_batch_run", "transport": nbat.transport,
-                                   "world": "one process" if ws == 1 else "one process per GPU (ncclCommInitRank, id carried by torch.distributed)"}
-                out["multi_gpu"]["C4_e2e"] = {"frames": n_all, "phase_ms": extra["C4_e2e"]["ms"], "ms_wall": extra["C4_e2e"]["ms_wall"],
-                                              "end_to_end_Mpix/s": extra["C4_e2e"]["end_to_end_Mpix/s"], "transport": nbat.transport}
+                rf.update({"scatter_ms": round(acc["scatter"], 3), "compute_ms": round(acc["compute"], 3), "gather_ms": round(acc["gather"], 3),
+                           "e2e_ms_wall": round(wall_e2e * 1e3, 3), "e2e_frames": n_all,
+                           "e2e_compute_Mpix_s": round(n_all * 1080 * 1920 / (acc["compute"] * 1e-3) / 1e6, 1),
+                           "e2e_Mpix_s": round(n_all * 1080 * 1920 / wall_e2e / 1e6, 1)})
                 nbat.close()
                 del e2e_out
             except Exception as ex:   # a failing end-to-end leg must not take the headline down with it
-                extra["C4_e2e"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-                out["multi_gpu"]["C4_e2e"] = extra["C4_e2e"]
-            # ---- the same from HOST planes (what example/steer.cpp holds): each rank uploads its own frames from host memory,
-            # launches, downloads its three maps -- chunked and overlapped inside the rank (cvs_batch_run, host planes).
-            # PCIe-inclusive; never `value`.
-            try:
-                import numpy as _np
-                hb = batch.NativeBatch.local((local_rank,))
-                hb.set_persist(False)
-                host_in = fsets[0].cpu().numpy()
-                host_out = _np.empty((nfr, 3) + shape, _np.float32)
-                time.sleep(2.0)   # host-link copies run at half rate for a moment after large device frees
-                best, tm_best = None, None
-                for rep in range(4):
-                    t0 = time.perf_counter()
-                    _, tm = hb.run(host_in, nfr, shape, outputs=(5, 6, 7), out=host_out)
-                    dt = time.perf_counter() - t0
-                    if rep and (best is None or dt < best):
-                        best, tm_best = dt, tm
-                (best,) = max_over_ranks(best)
-                extra["C4_e2e_host_planes"] = {"frames_per_gpu": nfr, "ms_wall": round(best * 1e3, 2), "ms": {"upload": round(tm_best["scatter"], 2), "download": round(tm_best["gather"], 2), "span": round(tm_best["compute"], 2)},
-                                               "end_to_end_Mpix/s": round(ws * nfr * 1080 * 1920 / best / 1e6, 1),
-                                               "link_floor_ms": round(nfr * 1080 * 1920 * 4 * 3 / 56e9 * 1e3, 2),
-                                               "note": "host f32 frames in, 3 host f32 maps out per frame; every rank moves its own shard over its own link; floor = the download at 56 GB/s"}
-                # ... and the example's real flow: 8-bit images in, three 8-bit maps per image out (steer.cpp:73-122).  Bytes up,
-                # maps kept on the GPU, normalize(0, 255, MINMAX) there (one launch pair per block), bytes down.
-                host_u8 = (fsets[0] * 255.0).to(torch.uint8).cpu().numpy()
-                bbest = None
-                q8 = _np.zeros((nfr, 3) + shape, _np.uint8)
-                for rep in range(4):
-                    t0 = time.perf_counter()
-                    hb.run_to_u8(host_u8, out=q8)
-                    dt = time.perf_counter() - t0
-                    if rep and (bbest is None or dt < bbest):
-                        bbest = dt
-                (bbest,) = max_over_ranks(bbest)
-                extra["C4_e2e_bytes"] = {"frames_per_gpu": nfr, "ms_wall": round(bbest * 1e3, 2), "end_to_end_Mpix/s": round(ws * nfr * 1080 * 1920 / bbest / 1e6, 1),
-                                         "link_floor_ms": round(nfr * 1080 * 1920 * 3 / 56e9 * 1e3, 2),
-                                         "note": "8-bit frames in, 3 normalised 8-bit maps per frame out (example/steer.cpp flow); floor = the download at 56 GB/s"}
-                hb.close()
-                del host_in, host_out, host_u8, q8
-            except Exception as ex:
-                extra["C4_e2e_host_planes"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                rf["e2e_error"] = ("%s: %s" % (type(ex).__name__, ex))[:120]
+            if args.all_legs:
+                # the same from HOST planes (what example/steer.cpp holds): PCIe-inclusive; never `value`
+                try:
+                    import numpy as _np
+                    hb_ = batch.NativeBatch.local((local_rank,))
+                    hb_.set_persist(False)
+                    host_u8 = (fsets[0] * 255.0).to(torch.uint8).cpu().numpy()
+                    q8 = _np.zeros((nfr, 3) + shape, _np.uint8)
+                    time.sleep(2.0)
+                    bbest = None
+                    for rep in range(4):
+                        t0 = time.perf_counter()
+                        hb_.run_to_u8(host_u8, out=q8)
+                        dt = time.perf_counter() - t0
+                        if rep and (bbest is None or dt < bbest):
+                            bbest = dt
+                    (bbest,) = max_over_ranks(bbest)
+                    out["c4_bytes_in_bytes_out_pcie_Mpix_s"] = round(ws * nfr * 1080 * 1920 / bbest / 1e6, 1)
+                    hb_.close()
+                    del host_u8, q8
+                except Exception as ex:
+                    out["c4_bytes_error"] = ("%s: %s" % (type(ex).__name__, ex))[:120]
         del fsets, ff, all_frames
 
         if ws == 1:
-            # BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image (pyrDown is this
-            # build's own component -- the reference has no pyramid code).  `whole_*` = the configuration as a user
-            # runs it: build the pyramid AND filter every level, with the filter launch of level k writing level k+1
-            # (cvs_setup_pyr: the image is read once per level); two 8192^2 images alternate, so that no input is a
-            # leftover of the previous step in the Infinity Cache.  `filter_*` = the five filter launches alone on a
-            # pyramid built beforehand (round 1's figure), `pyramid_build_ms` = the four stand-alone pyrDown launches.
+            # BASELINE config 3: G2+H2 over a 5-level Gaussian pyramid of one 8192x8192 image (pyrDown is this build's own
+            # component -- the reference has no pyramid code): build the pyramid AND filter every level in one native call
+            # (cvs_pyramid_setup: the filter launch of level k writes level k+1, every level image is read once); two 8192^2
+            # images alternate, so that no input is a leftover of the previous step in the Infinity Cache.
             bigs = [torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32) for _ in range(2)]
             fp3 = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
             lv = fp3.pyramid(bigs[0], 5)
@@ -1024,59 +931,30 @@ def main():
             hp = [cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank) for _ in lv]
             flip3 = {"i": 0}
 
-            def pyr_filter():
-                for hnd, l in zip(hp, lv):
-                    hnd.setup(l, flags=cv.SETUP_BASIS)
-
-            def pyr_whole():
-                flip3["i"] ^= 1
-                cur = bigs[flip3["i"]]
-                for k, hnd in enumerate(hp):
-                    if k + 1 < len(hp):
-                        hnd.setup_pyr(cur, flags=cv.SETUP_BASIS, out=lv[k + 1])
-                        cur = lv[k + 1]
-                    else:
-                        hnd.setup(cur, flags=cv.SETUP_BASIS)
-
             def pyr_one_call():
                 flip3["i"] ^= 1
                 cv.pyramid_setup(hp, bigs[flip3["i"]], level_images=lv[1:], flags=cv.SETUP_BASIS)
 
             c3 = max(10, args.steps // 10)
-            settle(pyr_filter)
-            e_, _lo, _hi = timed(pyr_filter, c3, 2)
-            e2_, _lo, _hi = timed(lambda: fp3.pyramid(bigs[0], 5), c3, 2)
-            settle(pyr_whole)
-            e4_, e4_lo, e4_hi = timed(pyr_whole, c3, 2)
-            settle(pyr_one_call)
-            e3_, e3_lo, e3_hi = timed(pyr_one_call, c3, 2)
-            e_, e2_, e3_ = e_ * c3, e2_ * c3, e3_ * c3
-            # algorithmic bytes of the whole configuration: 4 B read + 28 B written per pixel of every level, plus the
-            # 4 B written per pixel of every level that is made here (levels 1..4)
+            # algorithmic bytes: 4 B read + 28 B written per pixel of every level, plus the 4 B written per pixel of every level made here
             whole_bytes = 32 * ppix + 4 * (ppix - lv[0].shape[0] * lv[0].shape[1])
-            extra["C3_pyramid_8192_5_levels"] = {"whole_ms": round(e3_ / c3, 4), "whole_Mpix/s": round(ppix / (e3_ / c3 * 1e-3) / 1e6, 1),
-                                                "whole_frac_hbm": round(whole_bytes / (e3_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                "whole_algorithmic_bytes": whole_bytes, "launches": len(hp),
-                                                "filter_Mpix/s": round(ppix / (e_ / c3 * 1e-3) / 1e6, 1), "filter_ms": round(e_ / c3, 4),
-                                                "filter_frac_hbm": round(32 * ppix / (e_ / c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                "pyramid_build_ms": round(e2_ / c3, 4), "total_pixels": ppix, "timed_steps": c3,
-                                                "whole_ms_min": round(e3_lo, 4), "whole_ms_max": round(e3_hi, 4), "repeats": LR,
-                                                "whole_entry": "cvs_pyramid_setup (the chain in one native call)",
-                                                "chain_of_five_calls_ms": round(e4_, 4),
-                                                "chain_of_five_calls_frac_hbm": round(whole_bytes / (e4_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                "launch_per_level": [launch_of(hnd) for hnd in hp],
-                                                "note": "whole = build + filter in one cvs_pyramid_setup call (level k+1 written by the filter launch of level k), two alternating images; chain_of_five_calls = the same as five cvs_setup_pyr / cvs_setup calls from Python; "
-                                                        "filter = five filter launches on a prebuilt pyramid; separate build + filter = filter_ms + pyramid_build_ms"}
+            settle(pyr_one_call, hp[0], 64)
+            ms, lo, hi = timed(pyr_one_call, c3, 2)
+            rf["c3_frac"] = record("C3_pyramid_8192_5_levels_whole", ms, lo, hi, whole_bytes / ppix, ppix, hp[0], None)
+            out["c3_Mpix_s"] = round(ppix / (ms * 1e-3) / 1e6, 1)
+            if args.all_legs:
+                def pyr_filter():
+                    for hnd, l in zip(hp, lv):
+                        hnd.setup(l, flags=cv.SETUP_BASIS)
+                leg("C3_filter_only_prebuilt_pyramid", pyr_filter, 32, pix=ppix, steps=c3, warm=2, settle_calls=8)
+                leg("C3_pyramid_build_only", lambda: fp3.pyramid(bigs[0], 5), 5.0 * (ppix - lv[0].shape[0] * lv[0].shape[1]) / ppix, pix=ppix, steps=c3, warm=2, settle_calls=4)
             del bigs, lv, hp, fp3
         if ws > 1 and not test_backend:
             # BASELINE config 3 over the ranks (one large image, every level split into row bands): the native
             # entry cvs_batch_pyramid_setup -- ncclBroadcast of the 8192^2 image from rank 0, every rank builds the (cheap)
-            # pyramid and filters its band of every level, the bands are gathered into rank 0's state planes.  Phase times
-            # are HIP events on the ranks' streams (slowest rank).  Never run on more than one GPU before the driver's node.
+            # pyramid and filters its band of every level, the bands are gathered into rank 0's state planes.
             try:
                 pb = batch.NativeBatch.from_torch_distributed(local_rank)
-                if distinct and pb.transport != "rccl":
-                    raise RuntimeError("%d ranks on distinct GPUs but transport %r" % (ws, pb.transport))
                 big = torch.rand((8192, 8192), generator=gen, device=dev, dtype=torch.float32) if rank == 0 else None
                 reps, acc, wall3 = 3, {"broadcast": 0.0, "compute": 0.0, "gather": 0.0}, 0.0
                 for rep in range(reps + 1):
@@ -1090,18 +968,12 @@ def main():
                 acc = dict(zip(acc.keys(), max_over_ranks(*acc.values())))
                 (wall3,) = max_over_ranks(wall3)
                 ppix3 = sum((8192 >> l) ** 2 for l in range(5))
-                extra["C3_pyramid_8192_5_levels_band_split"] = {
-                    "ranks": ws, "ms": {k: round(v, 3) for k, v in acc.items()}, "ms_wall": round(wall3 * 1e3, 3),
-                    "compute_only_Mpix/s": round(ppix3 / (acc["compute"] * 1e-3) / 1e6, 1), "end_to_end_Mpix/s": round(ppix3 / wall3 / 1e6, 1),
-                    "entry": "cvs_batch_pyramid_setup", "transport": pb.transport,
-                    "note": "image on rank 0 -> ncclBroadcast -> every rank: pyramid + its row band of every level -> bands gathered into rank 0's state"}
-                out["multi_gpu"]["C3_band_split"] = {"phase_ms": extra["C3_pyramid_8192_5_levels_band_split"]["ms"], "ms_wall": round(wall3 * 1e3, 3),
-                                                     "end_to_end_Mpix/s": round(ppix3 / wall3 / 1e6, 1), "transport": pb.transport}
+                rf.update({"c3_band_split_ranks": ws, "c3_broadcast_ms": round(acc["broadcast"], 3), "c3_band_compute_ms": round(acc["compute"], 3),
+                           "c3_band_gather_ms": round(acc["gather"], 3), "c3_band_e2e_Mpix_s": round(ppix3 / wall3 / 1e6, 1)})
                 pb.close()
                 del big
             except Exception as ex:
-                extra["C3_pyramid_8192_5_levels_band_split"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-                out["multi_gpu"]["C3_band_split"] = extra["C3_pyramid_8192_5_levels_band_split"]
+                rf["c3_band_split_error"] = ("%s: %s" % (type(ex).__name__, ex))[:120]
 
     if not args.no_extra:
         try:
@@ -1114,32 +986,30 @@ def main():
     if timer is not None:
         timer.cancel()
 
-    # HBM traffic of the headline launch from the PMC counters, measured by this run -- AFTER everything that is timed: in
-    # front of it, two of four runs had the headline and M1 3-6 % slow (tools/ab_live_traffic.sh; the children's allocations
-    # change where this process's first state block lands).  One rank only: the counter passes use device 0.
-    if rank == 0 and out.get("roofline"):
-        if args.no_live_traffic:
-            live_why = "switched off (--no-live-traffic)"
-        elif ws != 1:
-            live_why = "runs of several ranks replay the committed value"
-        else:
-            torch.cuda.synchronize()
-            live, live_why = _live_traffic()
-        if live:
-            out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = (
-                "measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two counter-only child runs of the headline launch "
-                "(`bench.py --traffic-child`, library defaults) after the timed part; read %d B (2 x FETCH_SIZE, the gfx950 correction) + "
-                "written %d B" % (live["read_bytes"], live["write_bytes"]))
-        elif out["roofline"].get("traffic_source"):
-            out["roofline"]["traffic_source"] = out["roofline"]["traffic_source"].replace(
-                "the counter passes had not run yet when this line was printed", live_why or "counter passes failed")
+    # HBM traffic of the headline launch from the PMC counters, measured by this run -- AFTER everything that is timed (the
+    # children's allocations change where this process's first state block lands), in a thread beside the CPU baseline (host
+    # work only).  One rank only: the counter passes use device 0.
+    live_box = {}
+    th_live = None
+    if rank == 0 and out.get("roofline") and not args.no_live_traffic and ws == 1:
+        torch.cuda.synchronize()
+        th_live = threading.Thread(target=lambda: live_box.update(zip(("live", "why"), _live_traffic())))
+        th_live.start()
 
     # the CPU baseline runs on rank 0's host cores (the other ranks wait in the final barrier)
     if rank == 0 and not args.no_cpu:
-        out["cpu_baseline"] = _cpu_baseline(THETA)
+        out["cpu_baseline"] = _cpu_baseline(THETA, args.all_legs)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if th_live is not None:
+        th_live.join()
+        live = live_box.get("live")
+        if live:
+            rf["traffic"] = live["hbm_bytes_per_launch"]
+            rf["traffic_read_bytes"], rf["traffic_write_bytes"] = live["read_bytes"], live["write_bytes"]
+            rf["traffic_source"] = "measured by this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, two counter-only child runs"
+        elif rf.get("traffic_source"):
+            rf["traffic_source"] = (rf["traffic_source"] + "; live passes: " + str(live_box.get("why")))[:128]
 
     emit(True)
     if dist is not None:

@@ -9,13 +9,12 @@ OK, E_BADARG, E_SIZE, E_HIP, E_NOMEM, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4
 KIND_G2, KIND_G4 = 2, 4
 MEM_HOST, MEM_DEVICE = 0, 1
 DEPTH_U8 = 0x100
-OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON, OPT_STORE_POLICY, OPT_G4_SPLIT, OPT_G4_EXTENSIONS, OPT_BLOCK_ORDER, OPT_PERSIST_STATE = 1, 2, 3, 4, 5, 6, 8, 9
-OPT_XCD_WEIGHTS = 10
-OPT_PLACEMENT_SEARCH = 11
+ABI_VERSION = 2
+OPT_ATAN_MODE, OPT_STRIP_ROWS, OPT_FIND_ON, OPT_G4_EXTENSIONS, OPT_BLOCK_ORDER, OPT_PERSIST_STATE = 1, 2, 3, 6, 8, 9
 OPT_AUTOTUNE = 12
 OPT_HOST_OVERLAP = 13
 OPT_STATE_LAYOUT = 14
-OPT_WG_PER_CU = 15
+ORDER_PLAIN, ORDER_XCD_COLUMNS, ORDER_DYNAMIC_TAIL = 0, 1000000, 2000000
 PLANE_BASIS0, PLANE_C1, PLANE_C2, PLANE_C3, PLANE_THETA, PLANE_STRENGTH = 0, 32, 33, 34, 35, 36
 
 
@@ -36,9 +35,8 @@ class CvsError(RuntimeError):
 
 class LaunchInfo(C.Structure):
     """struct cvs_launch_info"""
-    _fields_ = [("placement_mode", C.c_int32), ("state_per_plane", C.c_int32), ("window_found", C.c_int32), ("probes_run", C.c_int32),
-                ("probe_ms", C.c_double), ("block_order", C.c_int32), ("xcd_weights", C.c_int32), ("strip_rows", C.c_int32),
-                ("nt_stores", C.c_int32), ("g4_split", C.c_int32), ("state_layout", C.c_int32), ("read_ahead", C.c_int32), ("tuning_launches", C.c_int32), ("wg_per_cu", C.c_int32)]
+    _fields_ = [("struct_size", C.c_uint32), ("block_order", C.c_int32), ("strip_rows", C.c_int32), ("nt_stores", C.c_int32), ("g4_split", C.c_int32),
+                ("state_layout", C.c_int32), ("read_ahead", C.c_int32), ("tuning_launches", C.c_int32), ("tuned", C.c_int32), ("tune_state", C.c_int32)]
 
 
 _PP = C.POINTER(Plane)
@@ -141,8 +139,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
-        if L.cvs_abi_version() != 1:
-            raise ImportError("cvsteer_amd: ABI version mismatch")
+        if L.cvs_abi_version() != ABI_VERSION:
+            raise ImportError("cvsteer_amd: ABI version mismatch: the library says %d, this binding was written for %d" % (L.cvs_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

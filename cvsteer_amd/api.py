@@ -205,8 +205,9 @@ class SteerableFilters:
         return v.value
 
     def launch_info(self):
-        """cvs_get_launch_info as a dict: placement of the state block + configuration of the last basis launch"""
+        """cvs_get_launch_info as a dict: configuration of the last basis launch (the engine's default or its tuner's decision)"""
         li = L.LaunchInfo()
+        li.struct_size = C.sizeof(L.LaunchInfo)
         self._check(lib().cvs_get_launch_info(self._h, C.byref(li)), "cvs_get_launch_info")
         return {k: getattr(li, k) for k, _ in L.LaunchInfo._fields_}
 

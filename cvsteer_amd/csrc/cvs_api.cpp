@@ -113,7 +113,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     h->last_image = image->data;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols, fresh);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
-    a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
+    a.g4_split = h->g4_split;
     a.diag = h->diag;
     a.out_row_lo = out_row_lo;
     a.out_row_hi = out_row_hi;
@@ -298,10 +298,11 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
     // (nothing is allocated on the device here: the reference's callers build one short-lived object per image,
     // example/steer.cpp:86, and a hipMalloc + hipFree pair per object costs ~20 us of the ~150 us such an object lives;
     // the 8 bytes of min / max scratch are allocated by the first 8-bit conversion that needs them)
-    if (const char* e = std::getenv("CVS_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
-    if (const char* e = std::getenv("CVS_STATE_LAYOUT")) h->layout = std::max(0, std::min(2, std::atoi(e)));
-    if (const char* e = std::getenv("CVS_PYR_STRIP")) h->pyr_strip = std::atoi(e) != 0;
-    if (const char* e = std::getenv("CVS_PLACEMENT_SEARCH")) h->placement = std::max(0, std::min(2, std::atoi(e)));  // opt-in for new handles
+    const EnvOpts eo = env_opts();   // CVS_OPTS: process-wide A/B overrides for new handles
+    if (eo.autotune >= 0) h->autotune = eo.autotune;
+    if (eo.layout >= 0) h->layout = eo.layout;
+    if (eo.pyr_strip >= 0) h->pyr_strip = eo.pyr_strip;
+    if (eo.g4_split >= 0) h->g4_split = eo.g4_split;
     *out = h;
     return CVS_OK;
 }
@@ -316,8 +317,6 @@ int cvs_destroy(cvs_handle h)
     if (h->arena) (void)hipFree(h->arena);
     if (h->frame_tab) (void)hipFree(h->frame_tab);
     if (h->point_out) (void)hipFree(h->point_out);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_order) (void)hipEventDestroy(h->ev_order);
     for (hipEvent_t e : h->band_ev) (void)hipEventDestroy(e);
     if (h->s_up) (void)hipStreamDestroy(h->s_up);
@@ -372,14 +371,6 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "find_on");
             h->find_on = value;
             return CVS_OK;
-        case CVS_OPT_STORE_POLICY:
-            if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "store policy");
-            h->store_policy = value;
-            return CVS_OK;
-        case CVS_OPT_G4_SPLIT:
-            if (value < -1 || value > 2) return fail(h, CVS_E_BADARG, "g4 split");
-            h->g4_split = value;
-            return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS:
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "g4 extensions");
             h->g4_ext = value;
@@ -392,16 +383,8 @@ int cvs_set_option(cvs_handle h, int option, int value)
             if (value != 0 && value != 1) return fail(h, CVS_E_BADARG, "autotune");
             h->autotune = value;
             return CVS_OK;
-        case CVS_OPT_PLACEMENT_SEARCH:
-            if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "placement search");
-            h->placement = value;
-            return CVS_OK;
-        case CVS_OPT_XCD_WEIGHTS:
-            if (value != 0 && (value / 100 < 1 || value / 100 > 16 || value % 100 < 1 || value % 100 > 16)) return fail(h, CVS_E_BADARG, "xcd weights");
-            h->xcd_weights = value;
-            return CVS_OK;
         case CVS_OPT_BLOCK_ORDER:
-            if (value < -1 || (value > 1000000 && value != kOrderDynamic)) return fail(h, CVS_E_BADARG, "block order");
+            if (value != -1 && value != 0 && value != kOrderXcdColumns && value != kOrderDynamic) return fail(h, CVS_E_BADARG, "block order");
             h->block_order = value;
             return CVS_OK;
         case CVS_OPT_HOST_OVERLAP:
@@ -411,10 +394,6 @@ int cvs_set_option(cvs_handle h, int option, int value)
         case CVS_OPT_STATE_LAYOUT:
             if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "state layout");
             h->layout = value;
-            return CVS_OK;
-        case CVS_OPT_WG_PER_CU:
-            if (value < 0 || value > 8) return fail(h, CVS_E_BADARG, "workgroups per CU");
-            h->wg_per_cu = value;
             return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
@@ -427,17 +406,12 @@ int cvs_get_option(cvs_handle h, int option, int* value)
         case CVS_OPT_ATAN_MODE: *value = h->atan_mode; return CVS_OK;
         case CVS_OPT_STRIP_ROWS: *value = h->strip_rows; return CVS_OK;
         case CVS_OPT_FIND_ON: *value = h->find_on; return CVS_OK;
-        case CVS_OPT_STORE_POLICY: *value = h->store_policy; return CVS_OK;
-        case CVS_OPT_G4_SPLIT: *value = h->g4_split; return CVS_OK;
         case CVS_OPT_BLOCK_ORDER: *value = h->block_order; return CVS_OK;
         case CVS_OPT_HOST_OVERLAP: *value = h->host_overlap; return CVS_OK;
-        case CVS_OPT_XCD_WEIGHTS: *value = h->xcd_weights; return CVS_OK;
-        case CVS_OPT_PLACEMENT_SEARCH: *value = h->placement; return CVS_OK;
         case CVS_OPT_AUTOTUNE: *value = h->autotune; return CVS_OK;
         case CVS_OPT_PERSIST_STATE: *value = h->persist; return CVS_OK;
         case CVS_OPT_G4_EXTENSIONS: *value = h->g4_ext; return CVS_OK;
         case CVS_OPT_STATE_LAYOUT: *value = h->layout; return CVS_OK;
-        case CVS_OPT_WG_PER_CU: *value = h->wg_per_cu; return CVS_OK;
     }
     return fail(h, CVS_E_BADARG, "unknown option");
 }
@@ -445,12 +419,11 @@ int cvs_get_option(cvs_handle h, int option, int* value)
 int cvs_get_launch_info(cvs_handle h, cvs_launch_info* out)
 {
     if (!h || !out) return CVS_E_BADARG;
-    *out = h->last;
-    out->placement_mode = h->placement;
-    out->state_per_plane = h->sb.vmm ? 1 : 0;
-    out->window_found = h->window_found;
-    out->probes_run = state_probes_run();
-    out->probe_ms = h->probe_ms;
+    const uint32_t n = out->struct_size;   // the caller's sizeof(cvs_launch_info): never write beyond it
+    if (n < sizeof(uint32_t)) return fail(h, CVS_E_BADARG, "cvs_launch_info.struct_size not set");
+    cvs_launch_info li = h->last;
+    li.struct_size = (uint32_t)std::min<size_t>(n, sizeof(li));
+    std::memcpy(out, &li, li.struct_size);
     return CVS_OK;
 }
 
@@ -883,19 +856,18 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.no_state = h->persist ? 0 : 1;
     a.find_on_e = h->find_on;
     a.frames = regular ? nullptr : h->frame_tab;
-    a.g4_split = h->g4_split >= 0 ? h->g4_split : 2;
+    a.g4_split = h->g4_split;
     a.batch = n;
     // state kept: frames from the two halves of the batch in flight together (see k_basis); the stateless launch is bound by
-    // the SIMDs and does not care.  CVS_BATCH_WAYS=<n> is a tuning aid (1 = frames in order).
+    // the SIMDs and does not care.  CVS_OPTS batch_ways=<n> is a tuning aid (1 = frames in order).
     a.z_ways = (!a.no_state && n >= 4) ? 2 : 1;
     // ... and on 10-row strips: round 3 sweep (profiles/r03_c4_strip_probe.txt), 32 x 1080p, five state blocks of the allocation lottery, one handle
     // each: against 19 rows in the plain order 0.634 / 0.70 / 0.70 / 0.796 / 0.795 for 0.644 / 0.70 / 0.70 / 0.762 / 0.764 --
     // level on the slow and middle blocks, +4.5 % on the fast ones; the launch tuner then times the 19-row family and the
     // weighted order (which wins another 3 % on the slow blocks)
     if (!a.no_state && n >= 4 && h->strip_rows <= 0) a.strip_rows = 2 * (2 * h->width + 1) - 2 * h->width;
-    if (const char* e = std::getenv("CVS_BATCH_WAYS")) a.z_ways = std::max(1, std::min(n, std::atoi(e)));
+    if (const int ways = env_opts().batch_ways; ways > 0) a.z_ways = std::max(1, std::min(n, ways));
     a.frame_stride = h->frame_stride;
-    if ((rc = batch_block_search(h, a))) return rc;   // opt-in (CVS_OPT_PLACEMENT_SEARCH = 1), once per block size
     TuneToken tok;
     if ((rc = tune_begin(h, a, 16 | 1 | 4 | (a.no_state ? 8 : 0), false, tok))) return rc;
     note_launch(h, a);

@@ -25,6 +25,46 @@
 
 namespace cvs {
 
+// CVS_OPTS="autotune=0,layout=1,pyr_strip=1,batch_ways=2,read_ahead=1,g4_split=2,nt_stores=1,verbose=1,pool_mb=4096": the one documented
+// environment hook (A/B aids for new handles; unknown names are reported once on stderr and ignored)
+EnvOpts env_opts()
+{
+    static std::mutex mu;
+    static std::string cached_text;
+    static EnvOpts cached;
+    static bool have = false;
+    const char* e = std::getenv("CVS_OPTS");
+    const std::string text = e ? e : "";
+    std::lock_guard<std::mutex> lock(mu);
+    if (have && text == cached_text) return cached;   // parsed again only when the variable has changed (tests do that)
+    EnvOpts v;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t end = text.find(',', pos);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(pos, end - pos);
+        pos = end + 1;
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos) continue;
+        const std::string name = item.substr(0, eq);
+        const long val = std::atol(item.c_str() + eq + 1);
+        if (name == "autotune") v.autotune = val != 0;
+        else if (name == "layout") v.layout = (int)std::max(0L, std::min(2L, val));
+        else if (name == "pyr_strip") v.pyr_strip = val != 0;
+        else if (name == "batch_ways") v.batch_ways = (int)std::max(1L, val);
+        else if (name == "read_ahead") v.read_ahead = val != 0;
+        else if (name == "g4_split") v.g4_split = (int)std::max(0L, std::min(2L, val));
+        else if (name == "nt_stores") v.nt_stores = val != 0;
+        else if (name == "verbose") v.verbose = val != 0;
+        else if (name == "pool_mb") v.pool_mb = val;
+        else std::fprintf(stderr, "[cvsteer] CVS_OPTS: unknown name '%s' ignored\n", name.c_str());
+    }
+    cached = v;
+    cached_text = text;
+    have = true;
+    return v;
+}
+
 int fail(cvs_handle h, int code, const char* what)
 {
     if (h) h->err = what;
@@ -288,33 +328,26 @@ void fill_state_args(cvs_handle h, BasisArgs& a, bool orient)
 // (example/steer.cpp:86 inside the parallel_for_ body; test/test.cpp:85): a hipMalloc + hipFree of the 0.8 GiB state
 // block per image costs more than the filtering itself, so cvs_destroy parks the block here (after its stream has
 // drained) and the next handle on the same device that needs a block of about that size takes it over.  Bounded:
-// CVS_STATE_POOL_MB megabytes in all (default 4096, 0 = off), blocks at most twice the size asked for;
+// CVS_OPTS pool_mb megabytes in all (default 4096, 0 = off), blocks at most twice the size asked for;
 // cvs_release_cached_memory() empties it.
 static std::mutex g_pool_mutex;
 static std::vector<StateBlock> g_pool;
-static std::set<std::tuple<int, int, int, size_t>> g_no_window;  // (device, planes, rows, pitch) whose placement probe found nothing
 
 size_t pool_limit_bytes()
 {
-    static const size_t lim = [] {
-        const char* e = std::getenv("CVS_STATE_POOL_MB");
-        const long mb = e ? std::atol(e) : 4096;
-        return mb > 0 ? (size_t)mb << 20 : (size_t)0;
-    }();
-    return lim;
+    const long mb = env_opts().pool_mb;
+    return mb > 0 ? (size_t)mb << 20 : (size_t)0;
 }
 
-// a plain block of about the size asked for, or a per-plane block of exactly the geometry asked for
-bool pool_take(int device, size_t elems, bool vmm, size_t piece_bytes_min, int nplanes, StateBlock& out)
+// a block of about the size asked for
+bool pool_take(int device, size_t elems, StateBlock& out)
 {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     int best = -1;
     for (int i = 0; i < (int)g_pool.size(); ++i) {
         const StateBlock& b = g_pool[i];
-        if (b.device != device || b.vmm != vmm) continue;
-        const bool fits = vmm ? ((int)b.pieces.size() == nplanes && b.piece_bytes >= piece_bytes_min && b.piece_bytes <= piece_bytes_min + piece_bytes_min / 4 + ((size_t)2 << 20))
-                              : (b.elems >= elems && b.elems <= 2 * elems);
-        if (fits && (best < 0 || b.elems < g_pool[best].elems)) best = i;
+        if (b.device != device) continue;
+        if (b.elems >= elems && b.elems <= 2 * elems && (best < 0 || b.elems < g_pool[best].elems)) best = i;
     }
     if (best < 0) return false;
     out = g_pool[best];
@@ -345,14 +378,13 @@ void pool_give(StateBlock& blk)
     for (StateBlock& d : drop) state_block_free(d);
 }
 
-// every parked block goes back to the allocator (cvs_release_cached_memory); the next handle of a large geometry probes again
+// every parked block goes back to the allocator (cvs_release_cached_memory)
 void pool_release_all()
 {
     std::vector<StateBlock> blocks;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         blocks.swap(g_pool);
-        g_no_window.clear();
     }
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
@@ -405,7 +437,7 @@ void layout_state(cvs_handle h, bool merge_orient)
 {
     const size_t pitch = h->dense_pitch, stride = h->layout_stride;
     const int rows = h->rows;
-    const bool inter = state_interleaved(h, rows, pitch) && !h->sb.vmm;
+    const bool inter = state_interleaved(h, rows, pitch);
     // groups: G2 = 7 basis planes | 5 orientation planes; G4 = the 5 G planes | the 6 H planes | 5 orientation planes (the
     // half banks of the G4 pair launch write one group each, so each of them streams a dense sweep as well)
     int counts[3] = {h->kind == CVS_KIND_G4 ? 5 : h->nb, h->kind == CVS_KIND_G4 ? 6 : 5, 5};
@@ -447,30 +479,12 @@ bool state_interleaved(cvs_handle h, int rows, size_t dense_pitch)
 int ensure_state(cvs_handle h, int rows, int cols, int nframes)
 {
     const size_t pitch = round_up((size_t)cols, 64);
-    size_t stride = round_up(pitch * rows, 64);
+    const size_t stride = round_up(pitch * rows, 64);
     const int nplanes = h->nb + 5;
-    // Large single-image states get one physical allocation per plane, placed by a bounded search (cvs_state.cpp);
-    // small ones (they live in the Infinity Cache anyway) and frame batches take a plain block.
-    bool want_planes = h->placement != 0 && nframes == 1 && stride * sizeof(float) >= ((size_t)8 << 20) &&
-                       stride * sizeof(float) * nplanes >= ((size_t)256 << 20);
-    // a geometry whose probe found no window on this device takes plain blocks from now on (cvs_release_cached_memory()
-    // forgets that): the reference's callers build one object per image, and every new handle would search again
-    const auto geo = std::make_tuple(h->device, nplanes, rows, pitch);
-    if (want_planes) {
-        std::lock_guard<std::mutex> lock(g_pool_mutex);
-        if (g_no_window.count(geo)) want_planes = false;
-    }
-    bool reuse = h->state != nullptr;
-    if (reuse) {
-        if (want_planes && h->sb.vmm) reuse = (int)h->sb.pieces.size() == nplanes && h->sb.piece_bytes >= stride * sizeof(float) &&
-                                              h->sb.piece_bytes <= stride * sizeof(float) + stride + ((size_t)2 << 20);
-        else if (want_planes) reuse = h->placed_stride == stride && stride * nplanes <= h->state_elems;  // searched: a plain block it is
-        else reuse = !h->sb.vmm && stride * nplanes * (size_t)nframes <= h->state_elems;
-    }
-    if (!reuse) {
+    const size_t elems = stride * nplanes * (size_t)nframes;
+    if (!(h->state != nullptr && elems <= h->state_elems)) {
         release_state(h);   // parked, not freed: a handle that alternates between two geometries gets its blocks back
-        const size_t elems = stride * nplanes * (size_t)nframes;
-        const bool from_pool = pool_take(h->device, elems, want_planes, stride * sizeof(float), nplanes, h->sb);
+        const bool from_pool = pool_take(h->device, elems, h->sb);
         if (from_pool && h->sb.ready) {   // the previous owner's work on this block comes first
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(h->stream, &cap);
@@ -480,23 +494,10 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes)
             h->sb.ready = nullptr;
             if (we != hipSuccess) return fail_hip(h, we, "waiting for a parked state block");
         }
-        if (!from_pool) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(h->stream, &cap);
-            if (want_planes && cap == hipStreamCaptureStatusNone) HIP_TRY(h, state_block_alloc_planes(h->device, nplanes, rows, pitch, h->stream, h->placement, h->sb));
-            else HIP_TRY(h, state_block_alloc_plain(h->device, elems, h->sb));
-        }
-        if (want_planes && h->sb.searched) {
-            std::lock_guard<std::mutex> lock(g_pool_mutex);
-            g_no_window.insert(geo);
-        }
-        h->window_found = h->sb.vmm ? 1 : 0;
-        h->probe_ms = (!from_pool && h->sb.probed) ? h->sb.probe_ms : 0.f;  // a parked block was paid for by an earlier handle
+        if (!from_pool) HIP_TRY(h, state_block_alloc(h->device, elems, h->sb));
         h->state = h->sb.base;
         h->state_elems = h->sb.elems;
-        h->placed_stride = want_planes ? stride : 0;
     }
-    if (h->sb.vmm) stride = h->sb.piece_bytes / sizeof(float);  // planes start at piece boundaries
     h->rows = rows;
     h->cols = cols;
     h->dense_pitch = pitch;
@@ -508,7 +509,7 @@ int ensure_state(cvs_handle h, int rows, int cols, int nframes)
     // (step = planes x row length), which is all the per-pixel kernels, cvs_state_plane and the facade ever ask for.  Two
     // groups, basis and orientation, so that a basis-only setup writes a dense stream too.  On plain blocks, same handles
     // side by side: basis 0.76 -> 0.80, fused steer 0.70 -> 0.80, full setup 0.65 -> 0.82, pipeline 0.66 -> 0.73 of the HBM
-    // roofline, fresh images +4-5 points.  Per-plane windows (the opt-in placement search) keep the planar form.
+    // roofline, fresh images +4-5 points.
     h->layout_stride = stride;
     layout_state(h, false);
     h->num_frames = nframes;

@@ -54,10 +54,8 @@ int host_pipeline(cvs_handle h, Call& c, BasisArgs& a, float* scr)
     HIP_TRY(h, hipEventRecord(start, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->s_up, start, 0));
     HIP_TRY(h, hipStreamWaitEvent(h->s_down, start, 0));
-    // plain order, default weights: the launch-order tuner works on whole resident images, not on bands
+    // plain order: the launch tuner works on whole images, not on bands
     a.block_order = 0;
-    a.xcd_even = 4;
-    a.xcd_odd = 3;
     note_launch(h, a);
 
     // download thread: band b's outputs leave as soon as its kernel has finished

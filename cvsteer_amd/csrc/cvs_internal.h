@@ -13,7 +13,7 @@ constexpr int kMaxWidth = 32;           // generic path: up to 65 taps
 constexpr int kMaxTaps = 2 * kMaxWidth + 1;
 constexpr int kMaxBasis = 11;
 constexpr int kOrderXcdColumns = 1000000;  // BasisArgs::block_order: every XCD owns a contiguous range of column blocks
-constexpr int kOrderDynamic = 2000000;     // BasisArgs::block_order: persistent launch, tiles taken from per-XCD queues (tile_ctr)
+constexpr int kOrderDynamic = 2000000;     // BasisArgs::block_order: the tail of the launch is taken from per-XCD queues (tile_ctr)
 
 struct PlaneRef {
     float* p;       // nullptr = not requested
@@ -51,19 +51,15 @@ struct BasisArgs {
     size_t steer_h_pitch;
     float steer_w[kMaxBasis];  // scalar steering weights (host-computed)
     int strip_rows;       // output rows per wave strip
-    int xcd_steal;        // XCD-column order: tiles every odd XCD leaves (the last of its range) to its even neighbour; 0 = equal shares
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
     int read_ahead;       // host only (cvs_tune.cpp -> do_setup): a pure-read pass over the image in front of the launch
     int merge_orient;     // host only (cvs_tune.cpp -> do_setup): lay the G2 orientation planes out in one group with the basis planes
-    int wg_per_cu;        // host only: at most this many workgroups per CU (0 = whatever the registers allow); launch_basis turns it
-                          // into dynamic LDS the kernel never touches -- the way to cap occupancy on this hardware
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
     int out_row_lo, out_row_hi;    // caller: compute output rows [out_row_lo, out_row_hi) only (0, 0 = the whole image);
                                    // the band-split of one large image over several GPUs (cvs_setup_rows)
-    int block_order;      // 0 = row-major grid, 1 = row-major weighted per XCD, T >= 2 = groups of T bands walked column by column
-    int xcd_even, xcd_odd; // block_order 1: tiles per period for the even / odd XCDs (see basis_body)
+    int block_order;      // 0 = row-major grid (default), kOrderXcdColumns, kOrderDynamic
     int grid_x, grid_y;   // filled by the launcher
     int dyn_static;       // dynamic order: the first dyn_static tiles are dealt statically (tile = workgroup index); filled by the launcher
     int dyn_nz;           // dynamic order: planes of tiles (frames of a batch / half banks of the G4 pair); filled by the launcher
@@ -180,19 +176,11 @@ hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, 
 // the same as a strip march of the basis kernel's machinery (cvs_kernels_basis.hip); false = geometry not covered, use launch_pyr_down
 bool launch_pyr_strip(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s, hipError_t* err);
 
-// ---- state blocks (cvs_state.cpp): a plain hipMalloc block, or one physical allocation per plane mapped back to back ----
+// ---- state blocks (cvs_state.cpp): one plain hipMalloc block per handle, parked in a process-wide cache between handles ----
 struct StateBlock {
     float* base = nullptr;
     size_t elems = 0;          // usable floats from base
     int device = 0;
-    bool vmm = false;          // built with the virtual-memory API: piece_bytes per plane, pieces.size() planes
-    bool searched = false;     // a plain block handed out by state_block_alloc_planes after a COMPLETE probe found no window
-    bool probed = false;       // this allocation ran the placement probe (to the end or not)
-    float probe_ms = 0.f;      // host wall time the probe took (pool creation, launches, release of the spare pieces)
-    size_t piece_bytes = 0;
-    std::vector<hipMemGenericAllocationHandle_t> pieces;
-    void* va_base = nullptr;   // the reserved virtual range the planes are a window of (freed with the block)
-    size_t va_bytes = 0;
     // a PARKED block (cvs_destroy / a handle that changed geometry): recorded on the stream that last used the block; whoever
     // takes the block over makes its own stream wait for it -- the device is never drained for a destroy.  nullptr = idle.
     hipEvent_t ready = nullptr;
@@ -201,14 +189,8 @@ struct StateBlock {
     unsigned* tile_ctr = nullptr;
     int ctr_parity = 0;        // the set the next dynamic launch uses (that launch zeroes the other one)
 };
-hipError_t state_block_alloc_plain(int device, size_t elems, StateBlock& b);
-hipError_t state_block_alloc_planes(int device, int nplanes, int rows, size_t pitch, hipStream_t stream, int mode, StateBlock& b);
+hipError_t state_block_alloc(int device, size_t elems, StateBlock& b);
 void state_block_free(StateBlock& b);
-// placement probes this process has run so far (tests and bench.py read it through cvs_get_launch_info)
-int state_probes_run();
-// streaming-store probe used by the placement search: writes `n` planes (<= 12) of rows x pitch floats in the basis
-// kernel's access shape (wave = 64-column strip of 19 rows, nontemporal dword stores)
-hipError_t launch_place_probe(float* const* planes, int n, int rows, size_t pitch, hipStream_t s);
 
 // host-side tap math (cvs_taps.cpp, no HIP)
 int host_num_basis(int kind);

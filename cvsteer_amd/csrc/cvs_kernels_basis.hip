@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "cvs_device_math.h"
 #include "cvs_internal.h"
@@ -179,6 +180,76 @@ __device__ __forceinline__ void bst(rsrc_t r, unsigned lane_off, unsigned row_of
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_off, row_off, STREAM ? CVS_STREAM_AUX : 0);
 }
 
+// ---------------------------------------------------------------------------------------
+// Input rows straight into LDS (round 5): `buffer_load_dword ... lds` writes lane i's dword to LDS address M0 + 4 i without
+// passing through a VGPR.  Every wave owns a ring of 2W+1 lines of kRingLine floats; line j holds input row (i mod 2W+1 = j):
+// words [0, 64) = columns x0-W .. x0-W+63 (one load, all lanes), words [64, 64+2W) = the next 2W columns (a second load whose
+// other lanes carry an out-of-range offset: the hardware returns 0 for them, which lands in the line's padding).  Lane l then
+// reads its 2W+1 neighbours as line[l .. l+2W] -- the same values the staged line of rounds 1-4 held, without the 2 x (2W+1)
+// prefetch VGPRs and the two ds_write per row.  The compiler knows nothing about these LDS writes (its own LDS-DMA intrinsic
+// makes every later LDS read wait for the LAST such load -- no prefetching), so the loads are inline assembly and the waits are
+// counted by hand: vector-memory operations retire in issue order and `s_waitcnt vmcnt(N)` waits until at most N are
+// outstanding, so a row has landed once N = number of loads and stores issued after its halo load (see the row loop).
+// ---------------------------------------------------------------------------------------
+#ifndef CVS_INPUT_DMA
+#define CVS_INPUT_DMA 1   // 0: every variant stages through VGPRs as in rounds 1-4 (A/B twin, `make nodma`)
+#endif
+constexpr int kRingLine = 128;   // floats per ring line (512 B): 64 + 2W used, the rest takes the zeros of the halo load's idle lanes
+typedef int i4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float;
+
+__device__ __forceinline__ i4_t raw_rsrc(const void* base, size_t bytes)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    i4_t r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((a >> 32) & 0xffffu);
+    r.z = (int)(bytes > kMaxPlaneBytes ? kMaxPlaneBytes : bytes);
+    r.w = 0x00020000;
+    return r;
+}
+// both loads of one input row into the ring line at LDS byte address `lds_line` (s_nop: one wait state between an SALU write of
+// M0 and the LDS-DMA that reads it, which the assembler does not insert inside inline assembly).  8-bit images: the byte load
+// writes the zero-extended sample as a dword, and the lanes convert what they read back (cv::Mat1f(const Mat&), unscaled).
+template <bool U8>
+__device__ __forceinline__ void dma_row(i4_t rsrc, unsigned vmain, unsigned vhalo, unsigned soff, unsigned lds_line)
+{
+    if constexpr (U8)
+        asm volatile("s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_ubyte %0, %2, %4 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_ubyte %1, %2, %4 offen lds"
+                     :
+                     : "v"(vmain), "v"(vhalo), "s"(rsrc), "s"(lds_line), "s"(soff)
+                     : "memory", "scc");
+    else
+        asm volatile("s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dword %0, %2, %4 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dword %1, %2, %4 offen lds"
+                     :
+                     : "v"(vmain), "v"(vhalo), "s"(rsrc), "s"(lds_line), "s"(soff)
+                     : "memory", "scc");
+}
+// s_waitcnt vmcnt(n) for an n that is a constant once the row loop is unrolled (the instruction takes an immediate; the counter
+// has 6 bits, and a smaller n only waits longer)
+#define CVS_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+#define CVS_VMW8(a, b, c, d, e, f, g, h) CVS_VMW(a) CVS_VMW(b) CVS_VMW(c) CVS_VMW(d) CVS_VMW(e) CVS_VMW(f) CVS_VMW(g) CVS_VMW(h)
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+    switch (n < 63 ? n : 63) {
+        CVS_VMW8(0, 1, 2, 3, 4, 5, 6, 7) CVS_VMW8(8, 9, 10, 11, 12, 13, 14, 15) CVS_VMW8(16, 17, 18, 19, 20, 21, 22, 23)
+        CVS_VMW8(24, 25, 26, 27, 28, 29, 30, 31) CVS_VMW8(32, 33, 34, 35, 36, 37, 38, 39) CVS_VMW8(40, 41, 42, 43, 44, 45, 46, 47)
+        CVS_VMW8(48, 49, 50, 51, 52, 53, 54, 55) CVS_VMW8(56, 57, 58, 59, 60, 61, 62, 63)
+    }
+}
+#undef CVS_VMW8
+#undef CVS_VMW
+
 // a 64-bit value that is the same in every lane, moved to SGPRs (the compiler cannot prove that a
 // value loaded from the per-frame table is wave-uniform; without this every use becomes a VGPR
 // address + a readfirstlane "waterfall" loop around each buffer instruction)
@@ -197,8 +268,8 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 // its own XCD's queue and, when that is empty, of the queues of the others.  The grid has a quarter more tail workgroups than
 // tail tiles: the dispatcher deals every XCD the same number of workgroups, so an XCD that is ahead (on this box, with this
 // kernel, with this placement of the planes) works off its own queue early and spends its surplus workgroups on the tiles of
-// the others, whose surplus workgroups find nothing and leave.  Nothing about the speed of an XCD is assumed (rounds 2-3
-// dealt fixed even : odd shares, order 1, which helps in some processes and hurts in others).  Cost: one returning atomic
+// the others, whose surplus workgroups find nothing and leave.  Nothing about the speed of an XCD is assumed (rounds 2-4
+// also dealt fixed even : odd shares, which helped in some processes and hurt in others; removed in round 5).  Cost: one returning atomic
 // (~1 us) and one barrier at the START of a tail workgroup; the body is the same code as for the static orders.  Handing out
 // ALL tiles this way was measured too: 20-40 % slower (every workgroup then starts with that microsecond).
 // Measured (profiles/r04_order_probe.txt, six processes on one box): level with the plain order where that is at its best,
@@ -227,62 +298,22 @@ __device__ __forceinline__ int take_tile(const BasisArgs& a, int q0, int ntiles)
     return -1;
 }
 
-// static orders: the tile of this workgroup; false = none (padding workgroups of the weighted / XCD-column grids)
+// static orders: the tile of this workgroup; false = none (padding workgroups of the XCD-column grid)
 __device__ __forceinline__ bool static_tile(const BasisArgs& a, int& bx, int& by)
 {
-    // workgroup -> (column block bx, row band by).  block_order = 0: plain row-major grid.  block_order =
-    // T >= 2: 1-D grid, groups of T bands walked column by column, so T vertically adjacent bands are in
-    // flight together (T >= grid_y: column-major).  Which order the memory system prefers depends on the
-    // kernel variant (how many planes it writes) and on the box; the API layer picks it by timing the
-    // candidates on the caller's own launches, once per (variant, shape) -- cvs_tune.cpp.
+    // workgroup -> (column block bx, row band by).  block_order = 0: plain row-major grid (the default).
     bx = blockIdx.x;
     by = blockIdx.y;
-    if (a.block_order == 1) {
-        // XCD-weighted row-major order.  Workgroup b runs on XCD b % 8 (observed on every launch, tools/xcd_map.py;
-        // only speed depends on it), every XCD gets the same number of workgroups, and the XCDs are not equally
-        // fast at this kernel: the odd ones need ~25 % longer per strip (tools/k1_timeline.py), so in the plain
-        // order the even ones idle for the last fifth of the launch (measured on one handle: +2-3 % for every G2 variant).  Here the tiles are dealt in periods of
-        // 4 * (ce + co): an even XCD takes ce tiles per period, an odd one co, and the grid is padded with
-        // workgroups that find no tile and leave at once.  Period layout: cmin rows of the labels 0..7, then
-        // (cmax - cmin) rows of the four labels of the heavier parity.
-        const int ce = a.xcd_even, co = a.xcd_odd, cmin = min(ce, co);
-        const int label = blockIdx.x & 7, r = blockIdx.x >> 3;
-        const int cl = (label & 1) ? co : ce;
-        const int k = r / cl, j = r - k * cl;
-        const int pos = j < cmin ? j * 8 + label : cmin * 8 + (j - cmin) * 4 + (label >> 1);
-        const int tl = k * 4 * (ce + co) + pos;
-        if (tl >= a.grid_x * a.grid_y) return false;
-        by = tl / a.grid_x;
-        bx = tl - by * a.grid_x;
-    } else if (a.block_order == kOrderXcdColumns) {
+    if (a.block_order == kOrderXcdColumns) {
         // every XCD owns a contiguous range of column blocks and walks it row-major, so horizontally AND vertically adjacent
         // tiles share an L2 and the line at a tile's left / right edge is not fetched from HBM by two XCDs: on a stream of
-        // fresh images the L2 fetch drops from 1.24 x to 1.11 x the image (rocprofv3 FETCH_SIZE) at the same launch time --
-        // the default order for fresh images whose column blocks divide evenly among the 8 XCDs.
-        // The odd XCDs need longer per strip (see the weighted order above): with xcd_steal > 0 each of them leaves the last
-        // xcd_steal tiles of its range to its even neighbour, which takes them up when its own range is done.
+        // fresh images the L2 fetch drops from 1.24 x to 1.11 x the image (rocprofv3 FETCH_SIZE) at the same launch time.
+        // (workgroup b runs on XCD b % 8 on every launch observed; only speed depends on it)
         const int cpx = (a.grid_x + 7) >> 3, xcd = blockIdx.x & 7;
-        int k = blockIdx.x >> 3, owner = xcd;
-        if (a.xcd_steal > 0) {
-            const int n_own = cpx * a.grid_y;
-            if (xcd & 1) {
-                if (k >= n_own - a.xcd_steal) return false;
-            } else if (k >= n_own) {
-                if (k - n_own >= a.xcd_steal) return false;
-                owner = xcd + 1;
-                k = (n_own - a.xcd_steal) + (k - n_own);
-            }
-        }
+        const int k = blockIdx.x >> 3;
         by = k / cpx;
-        bx = owner * cpx + (k - by * cpx);
+        bx = xcd * cpx + (k - by * cpx);
         if (bx >= a.grid_x || by >= a.grid_y) return false;
-    } else if (a.block_order >= 2) {
-        const int T = min(a.block_order, a.grid_y);
-        const int per = T * a.grid_x, g = blockIdx.x / per, r = blockIdx.x % per;
-        const int tg = min(T, a.grid_y - g * T);  // bands in this (possibly last, shorter) group
-        by = g * T + r % tg;
-        bx = r / tg;
-        if (bx >= a.grid_x) return false;
     }
     return true;
 }
@@ -327,6 +358,13 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     constexpr unsigned EB = U8 ? 1u : 4u;   // bytes per input sample
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
     constexpr int LW = 64 + 2 * W;
+    constexpr bool DMA = CVS_INPUT_DMA != 0;   // input rows go straight into the wave's LDS ring
+    // vector-memory instructions per output row that EVERY launch of this variant issues (state planes, fused steer, the three
+    // maps of FEAT3; outputs selected at run time are not counted): a lower bound is all the hand-counted waits need
+    constexpr int S_ROW = (((FLAGS & F_NOSTATE) == 0 && (FLAGS & F_PYRONLY) == 0) ? NB : 0) +
+                          (((FLAGS & F_ORIENT) != 0 && B::KIND == 2 && (FLAGS & F_NOSTATE) == 0 && (FLAGS & F_PYRONLY) == 0) ? 5 : 0) +
+                          (((FLAGS & F_STEER) != 0 && (FLAGS & F_PYRONLY) == 0) ? (B::HALF == 0 ? 2 : 1) : 0) + ((FLAGS & F_FEAT3) != 0 ? 3 : 0);
+    constexpr int VM_ROWS = 2 * (NT - 1);   // loads of the NT - 1 rows issued after a row's own
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -361,6 +399,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     const unsigned xb = xin ? (unsigned)x * 4u : kLaneOff;
     const unsigned xmb = (unsigned)xm * EB;      // input column offsets (bytes of the image's own type)
     const unsigned xhb = is_halo ? (unsigned)xh * EB : kLaneOff;
+    // LDS-DMA form: lane l fetches column x0 - W + l into word l of the line, lanes < 2W also column x0 - W + 64 + l into word 64 + l
+    [[maybe_unused]] const unsigned dmb = (unsigned)max(0, min(reflect1(x0 - W + lane, a.cols), a.cols - 1)) * EB;
+    [[maybe_unused]] const unsigned dhb = is_halo ? (unsigned)max(0, min(reflect1(x0 - W + 64 + lane, a.cols), a.cols - 1)) * EB : kLaneOff;
     // left halo -> [0,W), right -> [64+W, 64+2W); lanes that carry no halo value write into the
     // 4 pad words behind the line, so the staging code has no exec-mask branch
     const int hslot = lane < W ? lane : (is_halo ? 64 + lane : LW + (lane & 3));
@@ -405,6 +446,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     const size_t plane_bytes = (size_t)(a.rows - rbase) * a.pitch * sizeof(float);
     const unsigned pitch_b = (unsigned)(a.pitch * sizeof(float));
     const rsrc_t r_in = plane_rsrc(in_p, (size_t)(a.rows - rbase) * in_pitch * EB);
+    [[maybe_unused]] const i4_t r_in_dma = raw_rsrc(in_p, (size_t)(a.rows - rbase) * in_pitch * EB);
+    [[maybe_unused]] const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(line));   // LDS byte address of this wave's ring
+    [[maybe_unused]] const unsigned lds_lane = (unsigned)reinterpret_cast<uintptr_t>(line) + (unsigned)lane * 4u;            // ... of this lane's first word in line 0
     // ONE: the frame's whole state block (basis + orientation planes, one allocation) is a single
     // resource and the plane is part of the scalar offset -- 4 SGPRs instead of 4 per plane, which is
     // what keeps the 20-plane pipeline variant from spilling SGPRs.  Needs the block to be < 2 GiB;
@@ -426,7 +470,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     const unsigned in_pitch_b = (unsigned)(in_pitch * EB);
 
     float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
-    float pre[NT], preh[NT];  // prefetched input rows (main lane value, halo-lane value)
+    [[maybe_unused]] float pre[NT], preh[NT];  // prefetched input rows (main lane value, halo-lane value); unused in the LDS-DMA form
     // F_PYR: the last five horizontally blurred rows ([1 4 6 4 1] at this lane's column); even lanes of even centre
     // rows make one pixel of the next pyramid level each (launch_pyr_down's arithmetic, op for op)
     [[maybe_unused]] float hw0 = 0.f, hw1 = 0.f, hw2 = 0.f, hw3 = 0.f, hw4 = 0.f;
@@ -472,21 +516,66 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     }
     [[maybe_unused]] unsigned orow2_run = ((unsigned)(y0 - rbase) - (unsigned)(2 * W)) * pitch2_b;   // row offset in the second group
 
+    if constexpr (DMA) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const unsigned ro = (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b;
-        pre[j] = bld_in<U8>(r_in, xmb, ro);
-        preh[j] = bld_in<U8>(r_in, xhb, ro);
-    }
-
-    for (int g = 0; g < ngroups; ++g) {
-        // Prefetch for the NEXT group is issued unconditionally (straight-line code: no phi copies,
-        // no early waits); in the last group the lane offsets are kLaneOff, so the hardware range
-        // check drops those loads without touching memory.
-        const bool more = g + 1 < ngroups;  // wave-uniform
-        const unsigned nxmb = more ? xmb : kLaneOff, nxhb = more ? xhb : kLaneOff;
+        for (int j = 0; j < NT; ++j)
+            dma_row<U8>(r_in_dma, dmb, dhb, (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b, ring_base + (unsigned)(j * kRingLine * 4));
+    } else {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            const unsigned ro = (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b;
+            pre[j] = bld_in<U8>(r_in, xmb, ro);
+            preh[j] = bld_in<U8>(r_in, xhb, ro);
+        }
+    }
+
+    // One row step: input row i = g NT + j is read back from its line (slot j), the line is refilled with row i + NT, the row pass
+    // feeds window slot j, and -- from step 2W on -- the column pass writes output row i - 2W.  PHASE 0 = the first group (window
+    // priming: no stores before its last step, the loads it waits for were issued by the prologue), PHASE 1 = every later group;
+    // the two differ in their hand-counted waits, and the priming steps carry no column-pass code at all.
+    auto row_step = [&](auto phase, const int g, const int j, const bool more) __attribute__((always_inline)) {
+        constexpr int PHASE = decltype(phase)::value;
+        // Prefetch for the NEXT group is issued unconditionally (straight-line code: no phi copies, no early waits); in the last
+        // group the lane offsets are kLaneOff, so the hardware range check drops those loads without touching memory.
+        [[maybe_unused]] const unsigned nxmb = more ? xmb : kLaneOff, nxhb = more ? xhb : kLaneOff;
+        {
+            float s[NT];
+            if constexpr (DMA) {
+                // Has row i = g NT + j landed in line j?  Operations issued after its halo load: the loads of the NT - 1 rows
+                // that followed it, and the stores of every OUTPUT row among the NT row steps since.  Steps 2W.. are output rows;
+                // so none in group 0, j + 1 of them in group 1, NT from group 2 on.  (Steps past the strip's last row wait for a
+                // row nobody uses; their count may be short, which only lets them read a line that is still being written.)
+                if constexpr (PHASE == 0) wait_vmcnt(VM_ROWS);
+                else if (VM_ROWS + S_ROW * (j + 1) >= 63) wait_vmcnt(63);   // (a constant once the loop is unrolled)
+                else if (g == 1) wait_vmcnt(VM_ROWS + S_ROW * (j + 1));
+                else wait_vmcnt(VM_ROWS + S_ROW * NT);
+                // this lane's window into line j: the address is made by an opaque instruction INSIDE the step -- written as plain
+                // pointer arithmetic the compiler pairs the reads into ds_read2_b32 (offsets of at most 1 KiB), builds one base
+                // register per pair and line, and hoists all NT x (W + 1) of them out of the loop (+50 VGPRs for G4)
+                unsigned lj;
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(lj) : "v"(lds_lane), "s"((unsigned)(j * kRingLine * 4)));
+                const lds_float* lp = reinterpret_cast<const lds_float*>(lj);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) s[k] = lp[k];
+                // the reads above must have left the LDS before the line is handed to the next row (the load lands hundreds of
+                // cycles later, but nothing else orders it behind them)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (U8) {
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) s[k] = (float)__float_as_uint(s[k]);   // the line holds the samples as integers 0..255
+                }
+                {
+                    unsigned ro;
+                    if constexpr (SRED) {
+                        ro = ro_lin >= ro_lim ? ro_mir - ro_lin : ro_lin;
+                        ro_lin += in_pitch_b;
+                    } else {
+                        ro = (unsigned)(reflect1(y0 - W + (g + 1) * NT + j, a.rows) - rbase) * in_pitch_b;
+                    }
+                    // in the last group the lane offsets are kLaneOff: the loads are dropped by the range check (and still counted)
+                    dma_row<U8>(r_in_dma, more ? dmb : kLaneOff, more ? dhb : kLaneOff, ro, ring_base + (unsigned)(j * kRingLine * 4));
+                }
+            } else {
             const float v = pre[j], vh = preh[j];
             // the register just consumed is refilled at once with the same row of the next group:
             // a full group (2W+1 rows) of loads stays in flight with a single set of registers
@@ -505,10 +594,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             line[W + lane] = v;
             line[hslot] = vh;
             wave_lds_fence();
-            float s[NT];
 #pragma unroll
             for (int k = 0; k < NT; ++k) s[k] = line[lane + k];
             wave_lds_fence();
+            }
 
             if constexpr ((FLAGS & F_PYR) != 0) {
                 static_assert(W >= 2, "the pyramid level needs two columns / rows of halo");
@@ -570,6 +659,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 yout = y0 + g * NT + j - 2 * W;
                 row_ok = yout >= y0 && yout < yend;
             }
+            if (PHASE == 0 && j < 2 * W) row_ok = false;   // window priming (what the run-time test says anyway): no column-pass code in these steps
             const unsigned xbr = xb;
             if (row_ok) {
 #ifdef CVS_DIAG_STAMPS
@@ -698,6 +788,16 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             }
             }  // !F_PYRONLY
         }
+    };
+    {
+        const bool more = 1 < ngroups;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NT; ++j) row_step(std::integral_constant<int, 0>{}, 0, j, more);
+    }
+    for (int g = 1; g < ngroups; ++g) {
+        const bool more = g + 1 < ngroups;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) row_step(std::integral_constant<int, 1>{}, g, j, more);
     }
 #ifdef CVS_DIAG_STAMPS
     if (stamp && lane == 0) {
@@ -713,7 +813,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int WPB = 4, bool U8 = false>
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
-    __shared__ float lds[WPB][64 + 2 * B::W + 4];
+    __shared__ float lds[WPB][CVS_INPUT_DMA != 0 ? (2 * B::W + 1) * kRingLine : 64 + 2 * B::W + 4];
     __shared__ int s_tile;
     // Frame batches with state kept: the frames are dispatched dealt from z_ways equal parts of the batch in turn (0, n/2, 1,
     // n/2 + 1, ... for two), so that the frames in flight together -- about ten of 1080p -- have their state planes, inputs and
@@ -740,7 +840,7 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
 template <class BG, class BH, int FLAGS, bool STREAM, bool ONE, bool U8 = false>
 __global__ __launch_bounds__(256) void k_basis_pair(const BasisArgs a, const Folded<BG> tg, const Folded<BH> th)
 {
-    __shared__ float lds[4][64 + 2 * BG::W + 4];
+    __shared__ float lds[4][CVS_INPUT_DMA != 0 ? (2 * BG::W + 1) * kRingLine : 64 + 2 * BG::W + 4];
     __shared__ int s_tile;
     int bx = 0, by = 0;
     unsigned z = 0;
@@ -843,33 +943,6 @@ bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], 
     return kMaxPlaneBytes / (max_pitch * sizeof(float)) < (size_t)(2 * width + 2);
 }
 
-// grid of the XCD-weighted order (see basis_body): whole periods, 8 labels x cmax workgroups each
-static unsigned weighted_grid(BasisArgs& a)
-{
-    if (a.xcd_even < 1 || a.xcd_even > 16) a.xcd_even = 4;
-    if (a.xcd_odd < 1 || a.xcd_odd > 16) a.xcd_odd = 3;
-    const size_t tiles = (size_t)a.grid_x * a.grid_y, period = 4 * (size_t)(a.xcd_even + a.xcd_odd);
-    const int cmax = a.xcd_even > a.xcd_odd ? a.xcd_even : a.xcd_odd;
-    return (unsigned)(((tiles + period - 1) / period) * 8 * cmax);
-}
-
-// Occupancy cap (BasisArgs::wg_per_cu = N > 0): dynamic LDS that no kernel touches, sized so that N workgroups fill a CU's
-// 160 KiB and N + 1 do not fit.  Why one would want FEWER waves: with the image resident in the Infinity Cache a 9..20-plane launch
-// is a pure write stream to HBM, every wave in flight is one more write front, and one workgroup per CU less than the registers
-// allow runs the fused steer 2-3.5 % faster on every handle measured, the full setup / pipeline 5 / 8 % faster on handles whose
-// two plane groups lie badly and 4 % slower where they lie well, the basis pass +-3 % (profiles/r04_occupancy_probe.txt).  On
-// new images (the reads need the waves) and at 8192^2 it loses.  So: CVS_OPT_WG_PER_CU for callers who know their images are
-// resident and want to pin it; nothing by default, and not a candidate of the online tuner (cvs_tune.cpp Cand::cap says why).
-static unsigned occupancy_pad(const BasisArgs& a)
-{
-    constexpr unsigned kLdsPerCu = 160u << 10, kStaticLds = 1536;   // static LDS of the strip kernels: 1220-1284 B, rounded up
-    if (a.wg_per_cu <= 0 || a.wg_per_cu > 8) return 0;
-    // N fit: N * (pad + static) <= LDS;  N + 1 do not: (N + 1) * (pad + static) > LDS.  The middle of that interval: at its upper
-    // end the allocation granularity already costs a workgroup (53 KiB behaved like "two per CU", 50 KiB like three)
-    const unsigned n = (unsigned)a.wg_per_cu;
-    return (kLdsPerCu / n + kLdsPerCu / (n + 1)) / 2 - kStaticLds;
-}
-
 // dynamic order: the last tenth of the tiles goes through the queues (the rest: tile = workgroup index) with a quarter more
 // workgroups than queued tiles (see pick_tile; both figures from the sweep in profiles/r04_order_probe.txt), a multiple of 8 so
 // that every XCD gets the same number
@@ -883,51 +956,59 @@ static unsigned dynamic_blocks(size_t ntiles, int* dyn_static)
     return (unsigned)(stat + (queued + queued * pct / 100 + 7) / 8 * 8);
 }
 
-// dynamic order: which of the handle's two sets of queues this launch uses (and which it zeroes for the next one); under
-// stream capture a memset node makes the set zero at every replay
-static hipError_t dynamic_queues(BasisArgs& a, hipStream_t s)
+// one set of queues back to zero, with the same agent-scope stores the strip kernels use on them.  (NOT hipMemsetAsync: a memset
+// node's fill writes through an XCD's L2 like any plain store, while the queue atomics execute at the memory side; inside a graph
+// the kernel that follows the fill can find the old values there -- seen as unwritten tail tiles in one process history out of
+// several, round 5.)
+__global__ void k_reset_queues(unsigned* set)
 {
+    if (threadIdx.x < 9) __hip_atomic_store(set + threadIdx.x * kQueueStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// dynamic order: which of the handle's two sets of queues this launch uses (and which it zeroes for the next one).  Under
+// stream capture the set is baked into the graph, so the launch is bracketed by two reset launches -- the set is made zero in
+// front of the kernel and again behind it -- and the host-side parity is left alone: whatever mix of replays and eager launches
+// follows, every launch finds its set at zero (round-4 advisor: replay, eager, replay, eager used to hand the second eager
+// launch a set the replay had left exhausted, and the tail tiles were not written).
+static hipError_t dynamic_queues(BasisArgs& a, hipStream_t s, bool* captured)
+{
+    *captured = false;
+    if (a.block_order != kOrderDynamic || !a.tile_ctr) return hipSuccess;
     const int p = a.tile_parity ? (*a.tile_parity & 1) : 0;
     unsigned* base = a.tile_ctr;
     a.tile_ctr = base + p * kQueueSetUints;
     a.tile_ctr_next = base + (1 - p) * kQueueSetUints;
-    if (a.tile_parity) *a.tile_parity ^= 1;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        return hipMemsetAsync(a.tile_ctr, 0, kQueueSetUints * sizeof(unsigned), s);
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        *captured = true;
+        hipLaunchKernelGGL(k_reset_queues, dim3(1), dim3(64), 0, s, a.tile_ctr);
+        return hipGetLastError();
+    }
+    if (a.tile_parity) *a.tile_parity ^= 1;
     return hipSuccess;
+}
+static hipError_t dynamic_queues_done(const BasisArgs& a, hipStream_t s, bool captured, hipError_t launched)
+{
+    if (launched != hipSuccess || !captured) return launched;
+    hipLaunchKernelGGL(k_reset_queues, dim3(1), dim3(64), 0, s, a.tile_ctr);
+    return hipGetLastError();
 }
 
 template <class B>
-static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStream_t s)
+static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t s)
 {
-    BasisArgs a = a_in;
     const int strips_x = (a.cols + 63) / 64;
     const bool orient_v = a.orient != nullptr && B::KIND == 2;
     constexpr int wpb = 4;
     dim3 grid((strips_x + wpb - 1) / wpb, (a.row_hi - a.row_lo + a.strip_rows - 1) / a.strip_rows);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
-    a.xcd_steal = 0;
     a.dyn_nz = 1;
     if (a.block_order == kOrderDynamic && !a.tile_ctr) a.block_order = 0;   // no queue slot for this handle: the plain order
+    if (a.block_order != kOrderDynamic && a.block_order != kOrderXcdColumns) a.block_order = 0;
     const bool dyn = a.block_order == kOrderDynamic;
-    if (dyn) {
-        // the grid is set at the launch itself (CVS_LAUNCH_K): it covers the frames of a batch as well
-        const hipError_t qe = dynamic_queues(a, s);
-        if (qe != hipSuccess) return qe;
-    } else if (a.block_order == kOrderXcdColumns) {
-        const int n_own = ((a.grid_x + 7) / 8) * a.grid_y;
-        // shares e : o for even : odd XCDs (the same pair of numbers as the weighted order's tiles per period); needs the
-        // column blocks to divide evenly (the API layer only picks this order then)
-        if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
-        grid = dim3(8u * (unsigned)(n_own + a.xcd_steal), 1);
-    } else if (a.block_order >= 2) {
-        const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
-        grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1);
-    } else if (a.block_order == 1) {
-        grid = dim3(weighted_grid(a));
-    }
+    // dynamic order: the grid is set at the launch itself (CVS_LAUNCH_K): it covers the frames of a batch as well
+    if (a.block_order == kOrderXcdColumns) grid = dim3(8u * (unsigned)(((a.grid_x + 7) / 8) * a.grid_y), 1);
     dim3 block(64 * wpb);
     const bool orient = orient_v;
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
@@ -942,7 +1023,7 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
             a.dyn_nz = (int)grid.z;                                                        \
             grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * grid.z, &a.dyn_static), 1, 1); \
         }                                                                                  \
-        hipLaunchKernelGGL((__VA_ARGS__), grid, block, occupancy_pad(a), s, a, f);         \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, f);         \
     } while (0)
 #define CVS_LAUNCH_U(FL, BATCHED, WP, U)                                                   \
     do {                                                                                   \
@@ -1020,40 +1101,36 @@ static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStre
     return hipGetLastError();
 }
 
-template <class BG, class BH>
-static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const Folded<BH>& fh, hipStream_t s)
+template <class B>
+static hipError_t launch_fast(const BasisArgs& a_in, const Folded<B>& f, hipStream_t s)
 {
     BasisArgs a = a_in;
+    bool captured = false;
+    const hipError_t qe = dynamic_queues(a, s, &captured);
+    if (qe != hipSuccess) return qe;
+    return dynamic_queues_done(a, s, captured, launch_fast_impl<B>(a, f, s));
+}
+
+template <class BG, class BH>
+static hipError_t launch_pair_impl(BasisArgs& a, const Folded<BG>& fg, const Folded<BH>& fh, hipStream_t s)
+{
     const int strips_x = (a.cols + 63) / 64;
     dim3 grid((strips_x + 3) / 4, (a.row_hi - a.row_lo + a.strip_rows - 1) / a.strip_rows, 2), block(256);
     a.grid_x = grid.x;
     a.grid_y = grid.y;
-    a.xcd_steal = 0;
     a.dyn_nz = 2;
     if (a.block_order == kOrderDynamic && !a.tile_ctr) a.block_order = 0;
+    if (a.block_order != kOrderDynamic && a.block_order != kOrderXcdColumns) a.block_order = 0;
     const bool dyn = a.block_order == kOrderDynamic;
-    if (dyn) {
-        // the grid is set at the launch (see launch_fast); tiles of both half banks share the queues
-        const hipError_t qe = dynamic_queues(a, s);
-        if (qe != hipSuccess) return qe;
-    } else if (a.block_order == kOrderXcdColumns) {  // as in launch_fast (found by tools/fuzz_campaign.py: this order, pinned by the caller, used to
-                                              // fall into the band-interleaved grid below and leave tiles of a G4 image unwritten)
-        const int n_own = ((a.grid_x + 7) / 8) * a.grid_y;
-        if (a.xcd_even > a.xcd_odd && a.xcd_odd >= 1 && a.grid_x % 8 == 0) a.xcd_steal = n_own * (a.xcd_even - a.xcd_odd) / (a.xcd_even + a.xcd_odd);
-        grid = dim3(8u * (unsigned)(n_own + a.xcd_steal), 1, 2);
-    } else if (a.block_order >= 2) {  // same 1-D band-interleaved walk as launch_fast; z still picks the half bank
-        const int T = a.block_order < a.grid_y ? a.block_order : a.grid_y;
-        grid = dim3(((a.grid_y + T - 1) / T) * T * a.grid_x, 1, 2);
-    } else if (a.block_order == 1) {
-        grid = dim3(weighted_grid(a), 1, 2);
-    }
+    // dynamic order: the grid is set at the launch (see launch_fast); tiles of both half banks share the queues
+    if (a.block_order == kOrderXcdColumns) grid = dim3(8u * (unsigned)(((a.grid_x + 7) / 8) * a.grid_y), 1, 2);
     const bool steer = a.steer_g != nullptr && a.steer_h != nullptr;
     const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;  // see launch_fast
     const bool one = !banded && a.state_bytes > 0 && a.state_bytes <= kMaxPlaneBytes;
 #define CVS_PAIR_K(...)                                                                                         \
     do {                                                                                                        \
         if (dyn) grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * 2, &a.dyn_static), 1, 1);             \
-        hipLaunchKernelGGL((__VA_ARGS__), grid, block, occupancy_pad(a), s, a, fg, fh);                         \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, fg, fh);                         \
     } while (0)
 #define CVS_PAIR(FL, ST, ON)                                                      \
     do {                                                                          \
@@ -1070,6 +1147,16 @@ static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const
 #undef CVS_PAIR
 #undef CVS_PAIR_K
     return hipGetLastError();
+}
+
+template <class BG, class BH>
+static hipError_t launch_pair(const BasisArgs& a_in, const Folded<BG>& fg, const Folded<BH>& fh, hipStream_t s)
+{
+    BasisArgs a = a_in;
+    bool captured = false;
+    const hipError_t qe = dynamic_queues(a, s, &captured);
+    if (qe != hipSuccess) return qe;
+    return dynamic_queues_done(a, s, captured, launch_pair_impl<BG, BH>(a, fg, fh, s));
 }
 
 static hipError_t launch_generic(int kind, int width, const float (*taps)[kMaxTaps], const BasisArgs& a,

@@ -385,38 +385,6 @@ __global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* src, size_t ss
             dst[(size_t)row * dpitch + c] = (float)src[(size_t)row * sstep + c];
 }
 
-// ---- placement probe (cvs_state.cpp): nothing but the basis kernel's store traffic ----
-struct ProbePlanes {
-    float* p[12];
-};
-template <int NPL>
-__global__ __launch_bounds__(256) void k_place_probe(ProbePlanes t, int rows, size_t pitch, int strip_rows)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const size_t x = (size_t)(blockIdx.x * 4 + wv) * 64 + lane;
-    if (x >= pitch) return;
-    const int y0 = blockIdx.y * strip_rows;
-    for (int y = y0; y < y0 + strip_rows && y < rows; ++y) {
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) __builtin_nontemporal_store((float)(y + p), t.p[p] + (size_t)y * pitch + x);
-    }
-}
-
-hipError_t launch_place_probe(float* const* planes, int n, int rows, size_t pitch, hipStream_t s)
-{
-    if (n < 1 || n > 12) return hipErrorInvalidValue;
-    ProbePlanes t;
-    for (int i = 0; i < 12; ++i) t.p[i] = planes[i < n ? i : 0];
-    const int sr = 19;
-    dim3 grid((unsigned)((pitch + 255) / 256), (unsigned)((rows + sr - 1) / sr)), block(256);
-    switch (n) {
-        case 9: hipLaunchKernelGGL(k_place_probe<9>, grid, block, 0, s, t, rows, pitch, sr); break;
-        case 12: hipLaunchKernelGGL(k_place_probe<12>, grid, block, 0, s, t, rows, pitch, sr); break;
-        default: hipLaunchKernelGGL(k_place_probe<7>, grid, block, 0, s, t, rows, pitch, sr); break;  // fewer planes: the first 7 (or fewer, repeated)
-    }
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------------------
 // Read-ahead pass: nothing but loads over an image, so that it sits in the Infinity Cache when the filter launch behind it
 // asks for it.  A filter launch on an image that comes from HBM mixes 10 % of reads into its write stream and loses more than

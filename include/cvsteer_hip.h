@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define CVS_ABI_VERSION 1
+/* 2 (round 5): cvs_launch_info carries its size; the placement-search, XCD-weight, store-policy, G4-split and
+ * workgroups-per-CU options are gone (9 options left) */
+#define CVS_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -70,77 +72,44 @@ enum {
     CVS_SETUP_FULL = 3u
 };
 
-/* options for cvs_set_option */
+/* options for cvs_set_option.  Process-wide overrides for new handles (A/B aids): the environment variable
+ * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2, pyr_strip=0|1, batch_ways=N, read_ahead=0|1, g4_split=0|1|2,
+ * nt_stores=0|1 (output stores plain / nontemporal instead of by size), verbose=1 (the tuner prints its decisions to stderr),
+ * pool_mb=N (state-block cache, default 4096, 0 = off).  Read at every call; results never depend on any of them. */
 enum {
     CVS_OPT_ATAN_MODE = 1,   /* 0 = OpenCV-compatible fastAtan2 polynomial (default), 1 = exact atan2f */
-    CVS_OPT_STRIP_ROWS = 2,  /* rows per wave strip of the basis kernel (0 = default: chosen by the engine / autotune) */
+    CVS_OPT_STRIP_ROWS = 2,  /* rows per wave strip of the basis kernel (0 = default: chosen by the engine / its tuner) */
     CVS_OPT_FIND_ON = 3,     /* cvs_pipeline: 0 = find*(magnitude, phase) as the reference's callers do
                                 (test/test.cpp:88-90), 1 = find*(e, phase) */
-    CVS_OPT_PERSIST_STATE = 9, /* cvs_pipeline / cvs_pipeline_batch: 1 (default) = keep basis + orientation planes like the
-                                  reference object does; 0 = write the requested outputs only (no state afterwards) */
     CVS_OPT_G4_EXTENSIONS = 6, /* 0 (default) = G4 exactly as the reference leaves it (no orientation, no e/mag/phase);
                                   1 = EXTENSION beyond the reference: cvs_setup(G4, CVS_SETUP_FULL) fills C1..C3 / theta /
                                   strength from the G4/H4 steering polynomials, and cvs_steer_* accept e/mag/phase */
-    CVS_OPT_BLOCK_ORDER = 8, /* order in which the basis kernel walks its strips: -1 (default) = the engine's choice (by kind,
-                                entry point, kind of state block and whether the image is a new one), checked by timing once
-                                per (kernel variant, image shape) and cached; 0 = row-major; 1 = row-major with more tiles for
-                                the faster XCDs (CVS_OPT_XCD_WEIGHTS); 2 <= T < 1000000 = groups of T row bands walked column
-                                by column (T >= number of bands: column-major); 1000000 = every XCD walks its own range of
-                                column blocks; with CVS_OPT_XCD_WEIGHTS e : o the odd XCDs leave the end of their range to
-                                their even neighbours (only when the 256-column blocks divide evenly among the 8 XCDs);
-                                2000000 = DYNAMIC: a persistent launch (as many workgroups as the chip holds at once) whose
-                                workgroups take tile after tile from eight per-XCD queues in device memory and help the other
-                                XCDs when their own queue is empty -- no assumption about which XCDs are faster on this box.
-                                Results do not depend on it. */
-    CVS_OPT_XCD_WEIGHTS = 10, /* block orders 1 and 1000000: 100 * e + o = shares of the even / odd XCDs (1..16 each; 101 =
-                                 equal); 0 (default) = the engine's choice, or what the autotuner found (tuning) */
-    CVS_OPT_AUTOTUNE = 12,   /* 1 (default): the first 20-45 calls of a shape each run one of a few launch configurations between two
-                                events on the caller's stream (no extra launches, no waiting); the engine then keeps the
-                                winner; 0 = always the defaults (A/B tools; also CVS_AUTOTUNE=0) */
-    CVS_OPT_PLACEMENT_SEARCH = 11, /* where the state planes of a large image (state >= 256 MiB) live.  0 (DEFAULT since round 3):
-                                      a plain hipMalloc block, no probe, no side effects.  1 (opt-in tuning knob; also
-                                      CVS_PLACEMENT_SEARCH=1 in the environment): one physical
-                                      allocation per plane, mapped back to back (planes then start on 2 MiB boundaries); when the
-                                      block is allocated, once, seven blocks' worth of pieces are created and mapped, a streaming-
-                                      store probe is slid over them (15-20 ms at 4096^2 on the handle's stream) and, if some window
-                                      of pieces straddles the end of a run of the VRAM allocator, that window becomes the block
-                                      (such planes stream at ~7.2 instead of ~5.7 TB/s, see cvs_state.cpp); the spare pieces are
-                                      released again, else everything is and the block is a plain hipMalloc.  Bounded: at most six
-                                      extra blocks of transient memory and never more than 8 GiB per pool (a search that finds nothing
-                                      retries ONCE on a second pool while the first is still held: 16 GiB at the most); one search at a time per
-                                      process; none under stream capture; each search keeps its virtual range reserved for the
-                                      life of the process (address space only, capped at 4 TiB); a chosen window is verified by
-                                      a fill + sampled readback before use and is made accessible to the peer devices of the
-                                      process.  Frame batches with state kept (cvs_pipeline_batch; the per-plane windows do not
-                                      fit hundreds of small planes): with 1 the first call of a block size times the REAL launch
-                                      on up to six candidate plain state blocks (bounded by the free memory) and keeps the
-                                      fastest (20-30 ms once for 32 x 1080p).  2 = always take the window in the middle of the
-                                      pool (tests).  Results never depend on it; cvs_get_launch_info reports what the last
-                                      allocation did. */
+    CVS_OPT_BLOCK_ORDER = 8, /* order in which the basis kernel's workgroups take their tiles: -1 (default) = the engine's choice
+                                (row-major, unless its tuner finds one of the others faster for this shape on the caller's own
+                                launches); 0 = row-major; 1000000 = every XCD walks its own range of column blocks;
+                                2000000 = row-major with a DYNAMIC TAIL: the last tenth of the tiles is handed out on demand
+                                from eight per-XCD queues in device memory (grid = static tiles + 1.25 x the tail tiles), so an
+                                XCD that is ahead takes over tiles of the others.  Results do not depend on it. */
+    CVS_OPT_PERSIST_STATE = 9, /* cvs_pipeline / cvs_pipeline_batch: 1 (default) = keep basis + orientation planes like the
+                                  reference object does; 0 = write the requested outputs only (no state afterwards) */
+    CVS_OPT_AUTOTUNE = 12,   /* 1 (default): while a (kind, entry point, shape bucket) is undecided, each call runs one of a few launch
+                                configurations between two events on the caller's stream (no extra launches, no waiting); the
+                                engine keeps a challenger only when its samples are separated from the default's beyond their
+                                spread; 0 = always the defaults */
     CVS_OPT_HOST_OVERLAP = 13, /* cvs_setup / cvs_setup_steer / cvs_pipeline with HOST planes on images of 1 Mpix and more:
                                   1 (default) = the image goes up, is filtered and comes down in row bands, all three at once
                                   (full-duplex host link, a second host thread for the downloads); 0 = one after the other */
-    CVS_OPT_STATE_LAYOUT = 14, /* how the handle's state planes lie in its block.  1 (default) = ROW-INTERLEAVED: row r of all basis
+    CVS_OPT_STATE_LAYOUT = 14  /* how the handle's state planes lie in its block.  1 (default) = ROW-INTERLEAVED: row r of all basis
                                   planes side by side ([row][plane][column]; the five orientation planes likewise, in a group of
                                   their own) -- a launch that writes 7..12 planes then streams ONE linear sweep per group instead of
-                                  one stream per plane 64 MiB apart, and runs 5-25 % faster on a plain block; every
-                                  plane is still an ordinary strided image (cvs_state_plane: step = planes x row length).  0 =
-                                  planar, plane after plane (rounds 1-3; also what per-plane placement windows and groups of
-                                  2 GiB and more use).  With 1 the engine also decides, by comparing both on the caller's launches,
-                                  whether a G2 launch that writes the orientation planes keeps them in a group of their own or
-                                  puts all twelve planes into one group (steadier across allocations; cvs_launch_info.state_layout
-                                  = 2 when it does); 2 = always one group of twelve for those launches.
-                                  Takes effect at the next cvs_setup*; results do not depend on it.  Also
-                                  CVS_STATE_LAYOUT in the environment (new handles). */
-    CVS_OPT_WG_PER_CU = 15,  /* strip kernels: at most N workgroups (of four waves) per CU, N = 1..8; 0 (default) = as many as the
-                                registers allow (4-5 for G2, 3 for the G4 half banks).  One less than that runs G2 launches on an
-                                image the Infinity Cache already holds 2-8 % faster in some processes (fewer write fronts) and
-                                4 % slower in others, and launches on new images slower everywhere (profiles/r04_occupancy_probe.txt):
-                                a knob for callers who measure, never set by the engine.  Results do not depend on it. */
-    CVS_OPT_G4_SPLIT = 5,    /* G4: 0 = one 11-plane kernel, 1 = G half and H half as two launches, 2 = both halves in one
-                                launch (blockIdx.z picks the half); -1 (default) = 2 (0 and 1 are 5-15 % slower everywhere measured and no longer tried by the tuner) */
-    CVS_OPT_STORE_POLICY = 4 /* output stores: 0 = auto (streaming stores once the state planes outgrow the
-                                256 MiB Infinity Cache), 1 = plain, 2 = always nontemporal (tuning) */
+                                  one stream per plane 64 MiB apart; every plane is still an ordinary strided
+                                  image (cvs_state_plane: step = planes x row length).  0 = planar, plane after plane (also what
+                                  groups of 2 GiB and more use).  With 1 the engine may also put all twelve G2 planes into one
+                                  group for launches that write the orientation planes (its tuner compares both;
+                                  cvs_launch_info.state_layout = 2 when it does); 2 = always one group of twelve for those
+                                  launches.  Takes effect at the next cvs_setup*; results do not depend on it.
+                                  NOTE: because the grouping may change from one setup to the next, a cvs_state_plane view is
+                                  valid only until the handle's next cvs_setup* / cvs_pipeline* call. */
 };
 
 /* state planes addressable through cvs_state_plane / cvs_read_state */
@@ -184,7 +153,7 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out);
 /* ~SteerableFiltersG2/G4.  The handle's state block (its largest allocation) is not freed but parked in a
  * process-wide cache -- the reference's callers build one short-lived object per image (example/steer.cpp:86,
  * test/test.cpp:85), and the next handle on the same device takes the block over instead of allocating.
- * The cache is bounded (CVS_STATE_POOL_MB, default 4096; 0 = off). */
+ * The cache is bounded (CVS_OPTS pool_mb, default 4096; 0 = off). */
 int cvs_destroy(cvs_handle h);
 /* frees every block held by that cache */
 int cvs_release_cached_memory(void);
@@ -194,28 +163,25 @@ const char* cvs_last_error(cvs_handle h);
 int cvs_set_stream(cvs_handle h, void* hip_stream);
 int cvs_set_option(cvs_handle h, int option, int value);
 int cvs_get_option(cvs_handle h, int option, int* value);
-/* What the engine decided by itself for this handle: where its state block lives (the opt-in placement search) and how
- * the last basis launch was configured (launch order, XCD weights, strip height, store policy: defaults or what the
- * launch-order tuner kept).  For benchmarks and tests -- a record must say whether a window was found, and a test asks
- * "did a probe run" instead of reading the wall clock.  Nothing of this changes results. */
+/* How the handle's last basis launch was configured (launch order, strip height, store policy, state layout: the defaults
+ * or what the online tuner kept).  For benchmarks and tests; nothing of this changes results.  The caller sets struct_size =
+ * sizeof(cvs_launch_info) before the call; the library fills at most that many bytes (a client built against an older, shorter
+ * struct keeps working). */
 typedef struct cvs_launch_info {
-    int32_t placement_mode;   /* CVS_OPT_PLACEMENT_SEARCH of the handle */
-    int32_t state_per_plane;  /* 1 = the current state block is a window of per-plane physical allocations */
-    int32_t window_found;     /* the allocation of the current state block found (or was handed) such a window */
-    int32_t probes_run;       /* placement probes this PROCESS has run so far */
-    double probe_ms;          /* host wall time of the probe this handle's current block paid for (0 = none) */
+    uint32_t struct_size;     /* in: sizeof(cvs_launch_info) of the caller */
     int32_t block_order;      /* last basis launch: CVS_OPT_BLOCK_ORDER value in effect */
-    int32_t xcd_weights;      /* ... 100 * even + odd */
     int32_t strip_rows;       /* ... output rows per wave strip */
     int32_t nt_stores;        /* ... 1 = streaming (nontemporal) stores */
-    int32_t g4_split;         /* ... CVS_OPT_G4_SPLIT value in effect */
+    int32_t g4_split;         /* ... G4: 2 = both half banks in one launch (the product's), 0 / 1 = A/B forms (CVS_OPTS g4_split) */
     int32_t state_layout;     /* layout of the current state block: 0 = planar, 1 = row-interleaved groups (CVS_OPT_STATE_LAYOUT),
                                  2 = row-interleaved with the G2 orientation planes in the basis planes' group (the tuner's choice) */
     int32_t read_ahead;       /* last basis launch: 1 = a pure-read pass over the image ran in front of it (a tuner candidate for
                                  launches on new images: the image then comes out of the Infinity Cache) */
-    int32_t tuning_launches;  /* launches the engine has issued on this handle's stream beyond the caller's own calls
-                                 (always 0 since round 4: configurations are compared on the caller's launches) */
-    int32_t wg_per_cu;        /* last basis launch: workgroups per CU it was capped to (CVS_OPT_WG_PER_CU); 0 = no cap */
+    int32_t tuning_launches;  /* launches the engine has issued on this handle's stream beyond the caller's own calls: always 0
+                                 (configurations are compared on the caller's launches) */
+    int32_t tuned;            /* 1 = the configuration above is a challenger the online tuner decided for; 0 = the engine's default */
+    int32_t tune_state;       /* the online tuner for this launch's key: 0 = off / not a tunable launch, 1 = still comparing on the
+                                 caller's launches, 2 = decided */
 } cvs_launch_info;
 int cvs_get_launch_info(cvs_handle h, cvs_launch_info* out);
 /* the handle's idx-th tap vector (m_g1.. members), 2*width+1 floats */
@@ -243,7 +209,8 @@ int cvs_setup_steer(cvs_handle h, const cvs_plane* image, unsigned flags, float 
  * take the generic path (non-default taps, tiny images) are filtered whole. */
 int cvs_setup_rows(cvs_handle h, const cvs_plane* image, unsigned flags, int row_lo, int row_hi);
 
-/* device view of a state plane (zero copy; valid until the next setup) */
+/* device view of a state plane (zero copy; valid until the handle's next cvs_setup* / cvs_pipeline* call: the engine may
+ * re-lay the planes between calls, see CVS_OPT_STATE_LAYOUT) */
 int cvs_state_plane(cvs_handle h, int which, cvs_plane* view);
 /* copy a state plane out (getDominantOrientationAngle()/Strength() getters, G2.h:40-41,
  * and the protected m_g2a.. members for tests) */

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported_and_bound(cv):
         assert hasattr(raw, name), "library does not export " + name
         assert name in _lib.SIGNATURES, "python binding misses " + name
     assert sorted(_lib.SIGNATURES) == declared
-    assert cv.abi_version() == 1
+    assert cv.abi_version() == 2
 
 
 def test_host_taps_bit_exact_vs_reference_functions(cv, golden_dir):

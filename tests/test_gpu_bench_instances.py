@@ -153,8 +153,8 @@ def test_config4_batched_pipeline_32x1080p_state_kept_and_outputs_only(cv, ora):
 def test_headline_fused_filter_steer_4096_streaming(cv, ora):
     """The headline of bench.py (`value`, M2): cvs_setup_steer(image, 0.3, CVS_SETUP_BASIS) at 4096 x 4096 =
     cvs::k_basis<BankG2, 2, true, 0, true, 4> (F_STEER, streaming stores, single state resource), in the launch
-    configurations the benchmark passes through (first call: fresh-image defaults; repeats: weighted order / whatever the
-    launch-order tuner keeps) and the bare defaults with the tuner off (`M2_untuned`).  g, h and the basis planes are
+    configurations the benchmark passes through (first call: fresh-image defaults; repeats: whatever the
+    launch tuner compares and keeps) and the bare defaults with the tuner off (`M2_untuned`).  g, h and the basis planes are
     compared with the oracle on top / middle / bottom bands; M1 (cvs::k_basis<BankG2, 0, true, 0, true, 4>) and M4
     (cvs::k_basis<BankG2, 1, true, 0, true, 4>) ride along on the same image."""
     import torch
@@ -189,7 +189,7 @@ def test_headline_fused_filter_steer_4096_streaming(cv, ora):
         torch.cuda.synchronize()
         info = f.launch_info()
         assert info["nt_stores"] == 1
-        key = (info["block_order"], info["xcd_weights"], info["strip_rows"])
+        key = (info["block_order"], info["strip_rows"], info["read_ahead"])
         if key not in seen:                                             # every configuration the loop passes through
             seen.add(key)
             check(f, ("call", call) + key)
@@ -286,22 +286,21 @@ def _small_shapes():
     return shapes + [(int(rng.integers(13, 140)), int(rng.integers(5, 330))) for _ in range(8)]
 
 
-def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora):
-    """CVS_OPT_STORE_POLICY = 2 (always nontemporal) on the small shapes of the parity fuzz, so that the STREAM = true
+def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora, monkeypatch):
+    """CVS_OPTS nt_stores=1 (always nontemporal) on the small shapes of the parity fuzz, so that the STREAM = true
     instances meet the oracle in every launch form: single image with the single state resource
     (cvs::k_basis<BankG2, 0 / 1 / 2 / 3 / 5 / 77, true, 0, true, 4>), the per-plane form of a row-range launch
     (cvs::k_basis<BankG2, 0 / 1, true, 0, false, 4>), frames from a device table (cvs::k_basis<BankG2, 5 / 13, true, 1, true, 4>)
     and the regular batch with one output resource per frame (cvs::k_basis<BankG2, 5 / 77, true, 2, true, 4>; the generic outputs-only instance 13 through a two-map request); G4 as
     cvs::k_basis_pair<BankG4G, BankG4H, 0 / 2, true, true / false>."""
     import torch
-    from cvsteer_amd import _lib as L
+    monkeypatch.setenv("CVS_OPTS", "nt_stores=1")
     for rows, cols in _small_shapes():
         img = rand_image(rows, cols, seed=rows * 1000 + cols) + (smooth_image(rows, cols) if rows > 30 else 0)
         img = img.astype(np.float32)
         dev = torch.from_numpy(img).cuda()
         truth = ora.basis(2, img, 4, 0.67, f64=True)
         f = cv.SteerableFiltersG2(None)
-        f.set_option(L.OPT_STORE_POLICY, 2)
         for flags in (cv.SETUP_BASIS, cv.SETUP_FULL):                      # FLAGS 0, 1
             f.setup(dev, flags=flags)
             assert f.launch_info()["nt_stores"] == 1
@@ -325,7 +324,6 @@ def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora):
         if rows >= 13 and cols >= 5:                                       # the per-plane form: a row range of the image
             lo, hi = rows // 3, max(rows // 3 + 1, 2 * rows // 3)
             fr = cv.SteerableFiltersG2(None)
-            fr.set_option(L.OPT_STORE_POLICY, 2)
             fr._like = dev
             fr._bind_stream(dev)
             pl = cv.api._plane(dev)
@@ -341,11 +339,9 @@ def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora):
         for persist in (True, False):
             sel = tuple(range(8)) if persist else (5, 6, 7)
             fb = cv.SteerableFiltersG2(None)
-            fb.set_option(L.OPT_STORE_POLICY, 2)
             fb.set_persist(persist)
             ob = fb.pipeline_batch(block, outputs=sel)
             fl = cv.SteerableFiltersG2(None)
-            fl.set_option(L.OPT_STORE_POLICY, 2)
             fl.set_persist(persist)
             ol = fl.pipeline_batch(loose, outputs=sel)
             torch.cuda.synchronize()
@@ -366,7 +362,6 @@ def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora):
                         assert torch.equal(ob[i, j], ref[k]), (rows, cols, i, k)
         # the GENERIC outputs-only instance (FLAGS 13: any other subset than the three feature maps): phase + bright lines
         fg = cv.SteerableFiltersG2(None)
-        fg.set_option(L.OPT_STORE_POLICY, 2)
         fg.set_persist(False)
         og = fg.pipeline_batch(block, outputs=(4, 7))
         for i in range(nb):
@@ -374,7 +369,6 @@ def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora):
             assert torch.equal(og[i, 0], ref[4]) and torch.equal(og[i, 1], ref[7]), (rows, cols, i)
         # G4: both halves in one launch, streaming, with and without the fused steer
         f4 = cv.SteerableFiltersG4(None)
-        f4.set_option(L.OPT_STORE_POLICY, 2)
         f4.setup(dev)
         t4 = ora.basis(4, img, 6, 0.5, f64=True)
         b4 = np.stack([f4.basis(p).cpu().numpy() for p in range(11)])

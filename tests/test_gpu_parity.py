@@ -738,16 +738,16 @@ def test_impulse_response_is_the_outer_product_of_the_reference_taps(cv, golden_
 
 
 def test_pipeline_batch_dispatch_order_of_frames_does_not_show(cv, monkeypatch):
-    """State-keeping batches dispatch their frames dealt from two halves of the batch (k_basis, z_ways; CVS_BATCH_WAYS is the
+    """State-keeping batches dispatch their frames dealt from two halves of the batch (k_basis, z_ways; CVS_OPTS batch_ways is the
     tuning aid): any number of parts, batches that do not divide, the frame-table form -- every plane of every frame as in order."""
     import torch
     n = 7
     block = torch.from_numpy(np.stack([smooth_image(61, 150) + 0.1 * rand_image(61, 150, seed=40 + s) for s in range(n)])).cuda()
     loose = [block[i].clone() for i in range(n)]                       # separately allocated frames: per-frame pointer table
-    monkeypatch.setenv("CVS_BATCH_WAYS", "1")
+    monkeypatch.setenv("CVS_OPTS", "batch_ways=1")
     want = cv.SteerableFiltersG2(None).pipeline_batch(block).clone()
     for ways in ("2", "3", "4", "7", "50"):
-        monkeypatch.setenv("CVS_BATCH_WAYS", ways)
+        monkeypatch.setenv("CVS_OPTS", "batch_ways=" + ways)
         eng = cv.SteerableFiltersG2(None)
         got = eng.pipeline_batch(block)
         assert torch.equal(got, want), ways
@@ -758,7 +758,7 @@ def test_pipeline_batch_dispatch_order_of_frames_does_not_show(cv, monkeypatch):
             assert torch.equal(eng.basis(5), single.basis(5)) and torch.equal(eng.getDominantOrientationAngle(), single.getDominantOrientationAngle())
         got_l = cv.SteerableFiltersG2(None).pipeline_batch(loose)
         assert torch.equal(got_l, want), ways
-    monkeypatch.delenv("CVS_BATCH_WAYS")
+    monkeypatch.delenv("CVS_OPTS")
     assert torch.equal(cv.SteerableFiltersG2(None).pipeline_batch(block), want)   # the default (two parts)
 
 
@@ -1111,42 +1111,22 @@ def test_g4_8192_band(cv, ora):
 
 
 def test_block_order_never_changes_results(cv):
-    """CVS_OPT_BLOCK_ORDER (row-major / band groups / column-major / autotuned): identical outputs"""
-    import torch
-    from cvsteer_amd import _lib as L
-    img = torch.rand((1100, 1500), device="cuda")     # >= 1 Mpix: eligible for autotune
-    ref = None
-    for order in (0, 1, 2, 7, 32, 100000, 1000000, 2000000, -1):   # 1000000 = XCD-owned column ranges, 2000000 = dynamic (tiles taken from per-XCD queues)
-        f = cv.SteerableFiltersG2(None)
-        f.set_option(L.OPT_BLOCK_ORDER, order)
-        outs = []
-        for _ in range(3):                              # the online tuner tries its candidates on these calls
-            outs = f.pipeline(img)
-        g, h = f.setup_steer(img, 0.3)
-        cur = [o.clone() for o in outs] + [g, h] + [f.basis(p) for p in range(7)]
-        if ref is None:
-            ref = cur
-        for a, b in zip(cur, ref):
-            assert torch.equal(a, b), order
-    with pytest.raises(cv.CvsError):
-        cv.SteerableFiltersG2(None).set_option(L.OPT_BLOCK_ORDER, -2)
-
-
-def test_xcd_weighted_order_never_changes_results(cv):
-    """block order 1 with any CVS_OPT_XCD_WEIGHTS (tiles dealt unevenly to the XCDs, padded grid): identical outputs for
-    every variant, ragged widths and heights too"""
+    """CVS_OPT_BLOCK_ORDER (row-major / every XCD on its own column range / dynamic tail / the engine's choice): identical outputs
+    for every variant, ragged widths and heights too"""
     import torch
     from cvsteer_amd import _lib as L
     for shape in ((1100, 1500), (257, 449), (300, 2048 + 64), (1030, 64)):
         img = torch.rand(shape, device="cuda")
         ref = None
-        for order, xw in ((0, 0), (1, 0), (1, 504), (1, 302), (1, 405), (1, 116), (1, 1601), (2000000, 0), (-1, 0)):
+        for order in (L.ORDER_PLAIN, L.ORDER_XCD_COLUMNS, L.ORDER_DYNAMIC_TAIL, -1):
             f = cv.SteerableFiltersG2(None)
             f.set_option(L.OPT_BLOCK_ORDER, order)
-            f.set_option(L.OPT_XCD_WEIGHTS, xw)
-            outs = f.pipeline(img)
-            f.setup(img)
-            cur = [o.clone() for o in outs] + [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle().clone()]
+            outs = []
+            for _ in range(3):                              # the online tuner tries its candidates on these calls
+                outs = f.pipeline(img)
+            theta = f.getDominantOrientationAngle().clone()
+            g, h = f.setup_steer(img, 0.3)
+            cur = [o.clone() for o in outs] + [g, h] + [f.basis(p) for p in range(7)] + [theta]
             f.set_persist(False)
             feat = [torch.empty_like(img) for _ in range(3)]
             f.pipeline(img, out=[None] * 5 + feat)
@@ -1156,26 +1136,25 @@ def test_xcd_weighted_order_never_changes_results(cv):
             if ref is None:
                 ref = cur
             for a_, b_ in zip(cur, ref):
-                assert torch.equal(a_, b_), (shape, order, xw)
-    with pytest.raises(cv.CvsError):
-        cv.SteerableFiltersG2(None).set_option(L.OPT_XCD_WEIGHTS, 1700)
+                assert torch.equal(a_, b_), (shape, order)
+    for bad in (-2, 1, 7, 1000001):    # the weighted and band-group orders of rounds 2-4 are gone
+        with pytest.raises(cv.CvsError):
+            cv.SteerableFiltersG2(None).set_option(L.OPT_BLOCK_ORDER, bad)
 
 
-def test_xcd_column_order_with_uneven_shares_and_g4(cv):
-    """block order 1000000 (every XCD on its own range of column blocks) with CVS_OPT_XCD_WEIGHTS e : o -- the odd XCDs leave the
-    end of their range to their even neighbours (BasisArgs::xcd_steal) -- on widths whose 256-column blocks divide among the 8
-    XCDs and on widths where they do not (equal shares then), short and tall images, G2 and G4: identical outputs.  (G4 with
-    this order pinned used to take the band-interleaved grid and leave tiles unwritten: tools/fuzz_campaign.py, seed 43.)"""
+def test_xcd_column_order_and_g4(cv):
+    """block order 1000000 (every XCD on its own range of column blocks) on widths whose 256-column blocks divide among the 8
+    XCDs and on widths where they do not, short and tall images, G2 and G4: identical outputs.  (G4 with this order pinned used
+    to take another grid and leave tiles unwritten: tools/fuzz_campaign.py, seed 43.)"""
     import torch
     from cvsteer_amd import _lib as L
     for shape in ((300, 2048), (61, 4096), (1200, 2048 - 70), (95, 449), (220, 309), (29, 255)):
         img = torch.rand(shape, device="cuda")
         for cls, n in ((cv.SteerableFiltersG2, 7), (cv.SteerableFiltersG4, 11)):
             ref = None
-            for order, xw in ((0, 0), (1000000, 0), (1000000, 101), (1000000, 706), (1000000, 403), (1000000, 1601), (1000000, 116)):
+            for order in (L.ORDER_PLAIN, L.ORDER_XCD_COLUMNS, L.ORDER_DYNAMIC_TAIL):
                 f = cls(None)
                 f.set_option(L.OPT_BLOCK_ORDER, order)
-                f.set_option(L.OPT_XCD_WEIGHTS, xw)
                 for sr in (0, 10):
                     if sr:
                         f.set_strip_rows(sr)
@@ -1186,7 +1165,7 @@ def test_xcd_column_order_with_uneven_shares_and_g4(cv):
                     if ref is None:
                         ref = cur
                     for a_, b_ in zip(cur, ref):
-                        assert torch.equal(a_, b_), (shape, cls.__name__, order, xw, sr)
+                        assert torch.equal(a_, b_), (shape, cls.__name__, order, sr)
 
 
 def test_planes_beyond_2gib_row_banded(cv):
@@ -1353,203 +1332,9 @@ def test_overlapped_host_path_matches_device_path(cv):
         assert np.array_equal(f4.basis(p), r4.basis(p).cpu().numpy())
 
 
-def test_plane_placement_keeps_results(cv):
-    """CVS_OPT_PLACEMENT_SEARCH: states of 256 MiB and more get one physical allocation per plane (virtual-memory
-    API), dealt from both sides of a run boundary when the allocation-time probe finds one (mode 1) or always (mode 2,
-    the test mode).  The planes then start at 2 MiB boundaries instead of back to back -- results, state access,
-    later stages, the row-band entry and the state-block cache must not notice."""
-    import ctypes as C
-    import torch
-    from cvsteer_amd import _lib as L
-    img = torch.rand((4099, 2563), device="cuda")          # state = 12 x 40 MiB, plane size not a multiple of 2 MiB
-    ref = cv.SteerableFiltersG2(None)
-    ref.set_option(L.OPT_PLACEMENT_SEARCH, 0)               # plain hipMalloc block
-    ref.setup(img)
-    want = [ref.basis(p).clone() for p in range(7)] + [ref.getDominantOrientationAngle().clone(), ref.getDominantOrientationStrength().clone()]
-    g0, h0 = ref.steer(0.3)
-    outs0 = ref.pipeline(img)
-    for mode in (2, 1):
-        f = cv.SteerableFiltersG2(None)
-        f.set_option(L.OPT_PLACEMENT_SEARCH, mode)
-        for it in range(3):
-            f.setup(img)
-            got = [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle(), f.getDominantOrientationStrength()]
-            for a, b in zip(got, want):
-                assert torch.equal(a, b), (mode, it)
-        g, h = f.steer(0.3)                                 # later stages read the per-plane state
-        assert torch.equal(g, g0) and torch.equal(h, h0)
-        for a, b in zip(f.pipeline(img), outs0):
-            assert torch.equal(a, b)
-        gs, hs = f.setup_steer(img, -0.8, flags=cv.SETUP_FULL)
-        gr, hr = ref.setup_steer(img, -0.8, flags=cv.SETUP_FULL)
-        assert torch.equal(gs, gr) and torch.equal(hs, hr)
-        # zero-copy views point into the mapped range, one piece per plane
-        p0, rows, cols, step = f.basis_view(0)
-        p1 = f.basis_view(1)[0]
-        assert (rows, cols) == (4099, 2563) and step == 2624 * 4
-        assert (p1 - p0) % (2 << 20) == 0 and p1 - p0 >= 4099 * 2624 * 4
-        # a smaller image afterwards (plain block), then the big one again
-        small = torch.rand((300, 400), device="cuda")
-        f.setup(small)
-        assert torch.equal(f.basis(3), cv.SteerableFiltersG2(small).basis(3))
-        f.setup(img)
-        assert torch.equal(f.basis(6), want[6])
-        # the row-band entry on a per-plane state
-        f2 = cv.SteerableFiltersG2(None)
-        f2.set_option(L.OPT_PLACEMENT_SEARCH, mode)
-        f2._like = img
-        f2._bind_stream(img)
-        pl = cv.api._plane(img)
-        f2._check(cv.lib().cvs_setup_rows(f2._h, C.byref(pl), cv.SETUP_FULL, 1000, 2500), "cvs_setup_rows")
-        assert torch.equal(f2.basis(5)[1000:2500], want[5][1000:2500])
-        del f, f2
-    # the cache of released blocks hands a per-plane block to the next handle of the same geometry
-    cv.lib().cvs_release_cached_memory()
-    fa = cv.SteerableFiltersG2(None); fa.set_option(L.OPT_PLACEMENT_SEARCH, 2); fa.setup(img)
-    addr = fa.basis_view(0)[0]
-    del fa
-    fb = cv.SteerableFiltersG2(None); fb.set_option(L.OPT_PLACEMENT_SEARCH, 2); fb.setup(img)
-    assert fb.basis_view(0)[0] == addr
-    assert torch.equal(fb.basis(1), want[1])
-    cv.lib().cvs_release_cached_memory()
-    # G4 (16 planes) through the same allocation path
-    f4 = cv.SteerableFiltersG4(None); f4.set_option(L.OPT_PLACEMENT_SEARCH, 2)
-    r4 = cv.SteerableFiltersG4(None); r4.set_option(L.OPT_PLACEMENT_SEARCH, 0)
-    a4, b4 = f4.setup_steer(img, 0.3)
-    c4, d4 = r4.setup_steer(img, 0.3)
-    assert torch.equal(a4, c4) and torch.equal(b4, d4)
-    for p in (0, 4, 10):
-        assert torch.equal(f4.basis(p), r4.basis(p))
-
-
-def test_one_object_per_image_probes_once_when_no_window_is_found(cv, monkeypatch):
-    """the reference's usage is one short-lived object per image (example/steer.cpp:86).  With the (opt-in) placement search
-    on and a box where the allocation-time probe finds no window, the verdict is remembered per geometry: the second object
-    must not probe again but take the parked plain block.  cvs_release_cached_memory() forgets the verdict.  Asked of the
-    library's own counter (cvs_get_launch_info: probes this process has run), not of the wall clock."""
-    import torch
-    from cvsteer_amd import _lib as L
-    monkeypatch.setenv("CVS_TEST_NO_WINDOW", "1")
-    x = torch.rand((2048, 4096), device="cuda")          # 12 planes x 32 MiB = 384 MiB of state: large enough to be probed
-    g, h = torch.empty_like(x), torch.empty_like(x)
-    cv.lib().cvs_release_cached_memory()
-
-    def one_object(search=1):
-        f = cv.SteerableFiltersG2(None)
-        f.set_option(L.OPT_PLACEMENT_SEARCH, search)
-        f.setup_steer(x, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
-        torch.cuda.synchronize()
-        info = f.launch_info()
-        del f
-        return info
-
-    off = one_object(search=0)                            # the default: no probe, no window, nothing reserved
-    assert off["placement_mode"] == 0 and off["window_found"] == 0 and off["state_per_plane"] == 0 and off["probe_ms"] == 0.0
-    cv.lib().cvs_release_cached_memory()
-    n0 = off["probes_run"]
-    first = one_object()
-    assert first["probes_run"] == n0 + 1 and first["probe_ms"] > 0.0 and first["window_found"] == 0   # the probe ran once ...
-    later = [one_object() for _ in range(4)]
-    assert all(i["probes_run"] == n0 + 1 and i["probe_ms"] == 0.0 for i in later), later            # ... and never again
-    cv.lib().cvs_release_cached_memory()
-    again = one_object()
-    assert again["probes_run"] == n0 + 2
-    cv.lib().cvs_release_cached_memory()
-
-
-def test_placement_search_is_opt_in_and_reports_what_it_did(cv):
-    """a drop-in for fa::SteerableFiltersG2 must not probe or reserve address space on first use by default (round-2 verdict):
-    a new handle has CVS_OPT_PLACEMENT_SEARCH = 0; with the option on, cvs_get_launch_info says whether a window was found,
-    what the probe cost, and how the last launch was configured."""
-    import torch
-    from cvsteer_amd import _lib as L
-    x = torch.rand((2048, 4096), device="cuda")
-    cv.lib().cvs_release_cached_memory()
-    f = cv.SteerableFiltersG2(None)
-    val = C.c_int(-1)
-    assert cv.lib().cvs_get_option(f._h, L.OPT_PLACEMENT_SEARCH, C.byref(val)) == 0 and val.value == 0
-    n0 = f.launch_info()["probes_run"]
-    f.setup(x)
-    info = f.launch_info()
-    assert info["probes_run"] == n0 and info["state_per_plane"] == 0 and info["probe_ms"] == 0.0
-    assert info["strip_rows"] > 0 and info["nt_stores"] == 1 and info["block_order"] in (0, 1, 1000000, 2000000)
-    want = f.basis(3).clone()
-    del f
-    cv.lib().cvs_release_cached_memory()
-    f1 = cv.SteerableFiltersG2(None)
-    f1.set_option(L.OPT_PLACEMENT_SEARCH, 1)
-    f1.setup(x)
-    i1 = f1.launch_info()
-    # one pool searched, or two: a pool that finds nothing is followed by ONE retry on a second pool before the verdict stands
-    assert i1["placement_mode"] == 1 and i1["probes_run"] in (n0 + 1, n0 + 2) and i1["probe_ms"] > 0.0
-    assert i1["window_found"] == 1 or i1["probes_run"] == n0 + 2
-    assert i1["window_found"] == i1["state_per_plane"]
-    assert torch.equal(f1.basis(3), want)
-    del f1
-    cv.lib().cvs_release_cached_memory()
-
-
-def test_placement_retry_on_a_second_pool(cv, monkeypatch):
-    """a pool in which the probe finds nothing is followed by ONE retry on a second pool, created while the first is still
-    held (cvs_state.cpp); CVS_TEST_FIRST_POOL_EMPTY makes the first pool come up empty.  Two probes run, the block is whatever
-    the second pool offers, results do not notice."""
-    import torch
-    from cvsteer_amd import _lib as L
-    monkeypatch.setenv("CVS_TEST_FIRST_POOL_EMPTY", "1")
-    x = torch.rand((2048, 4096), device="cuda")
-    cv.lib().cvs_release_cached_memory()
-    ref = cv.SteerableFiltersG2(x)
-    n0 = ref.launch_info()["probes_run"]
-    f = cv.SteerableFiltersG2(None)
-    f.set_option(L.OPT_PLACEMENT_SEARCH, 1)
-    f.setup(x)
-    info = f.launch_info()
-    assert info["probes_run"] == n0 + 2 and info["probe_ms"] > 0.0
-    assert info["state_per_plane"] == info["window_found"]
-    for p in (0, 6):
-        assert torch.equal(f.basis(p), ref.basis(p))
-    assert torch.equal(f.getDominantOrientationAngle(), ref.getDominantOrientationAngle())
-    del f, ref
-    cv.lib().cvs_release_cached_memory()
-
-
-def test_batch_block_search_keeps_results(cv):
-    """CVS_OPT_PLACEMENT_SEARCH = 1 on a frame batch with state kept: the first call times the REAL launch on up to six candidate
-    state blocks and keeps the fastest (cvs_tune.cpp batch_block_search).  Outputs, every frame's state and later calls must not
-    notice; the search runs once per block size; stateless batches and the default (0) never search."""
-    import torch
-    from cvsteer_amd import _lib as L
-    frames = torch.rand((4, 1080, 1920), generator=torch.Generator(device="cuda").manual_seed(5), device="cuda")   # 4 x 99.5 MB of state
-    ref = cv.SteerableFiltersG2(None)
-    want = ref.pipeline_batch(frames).clone()
-    assert ref.launch_info()["probe_ms"] == 0.0
-    f = cv.SteerableFiltersG2(None)
-    f.set_option(L.OPT_PLACEMENT_SEARCH, 1)
-    got = f.pipeline_batch(frames)
-    torch.cuda.synchronize()
-    info = f.launch_info()
-    assert info["probe_ms"] > 0.0 and info["state_per_plane"] == 0      # searched; a plain block either way
-    assert torch.equal(got, want)
-    for i in (0, 3):
-        f.select_frame(i)
-        ref.select_frame(i)
-        assert torch.equal(f.basis(6), ref.basis(6)) and torch.equal(f.getDominantOrientationAngle(), ref.getDominantOrientationAngle())
-        g, h = f.steer(0.3)
-        g0, h0 = ref.steer(0.3)
-        assert torch.equal(g, g0) and torch.equal(h, h0)
-    got2 = f.pipeline_batch(frames)                                       # same block size: no second search
-    torch.cuda.synchronize()
-    assert f.launch_info()["probe_ms"] == info["probe_ms"] and torch.equal(got2, want)
-    f.set_persist(False)                                                  # nothing is kept: nothing to place
-    fo = f.pipeline_batch(frames, outputs=(5, 6, 7))
-    assert torch.equal(fo, want[:, 5:8])
-    del f, ref
-    cv.lib().cvs_release_cached_memory()
-
-
 def test_hip_graph_capture_and_replay(cv):
-    """the engine's launches can be captured into a HIP graph on the caller's stream (no tuning, no allocation, no
-    placement search happens under capture) and replayed on new data in the same buffers"""
+    """the engine's launches can be captured into a HIP graph on the caller's stream (no tuning and no allocation happen
+    under capture) and replayed on new data in the same buffers"""
     import torch
     img = torch.rand((1200, 1600), device="cuda")
     f = cv.SteerableFiltersG2(None)
@@ -1582,41 +1367,73 @@ def test_hip_graph_capture_and_replay(cv):
         assert torch.equal(a, b)
 
 
-def test_g4_bank_layouts_never_change_results(cv):
-    """CVS_OPT_G4_SPLIT 0..2 (one 11-plane kernel / two launches / both halves in one launch) x block orders:
-    identical planes and steered outputs, ragged shapes and a streaming-store size included"""
+@pytest.mark.parametrize("kind", [2, 4])
+def test_dynamic_tail_replays_and_eager_launches_mixed(cv, kind):
+    """the dynamic tail (block order 2000000) hands the last tiles out from per-handle queues in device memory, two sets used
+    alternately.  A captured launch bakes its set into the graph; ONE such launch in a graph, then (replay, eager) twice -- the
+    sequence in which the second eager launch used to find its set exhausted by the replay and left the tail tiles unwritten
+    (round-4 advisor) -- and eager, eager, replay, replay for good measure: every launch must write every tile."""
     import torch
     from cvsteer_amd import _lib as L
-    for shape in ((1100, 1500), (301, 449), (64, 257), (2100, 600), (2048, 2100)):
-        img = torch.rand(shape, device="cuda")
-        ref = None
-        for split in (0, 1, 2):
-            for order in (0, 1, 5, 100000, 2000000):
-                f = cv.SteerableFiltersG4(None)
-                f.set_option(L.OPT_G4_SPLIT, split)
-                f.set_option(L.OPT_BLOCK_ORDER, order)
-                g, h = f.setup_steer(img, 0.7)
-                cur = [g, h] + [f.basis(p).clone() for p in range(11)]
-                f.setup(img)
-                cur += [f.basis(p).clone() for p in (0, 5, 10)]
-                if ref is None:
-                    ref = cur
-                for a, b in zip(cur, ref):
-                    assert torch.equal(a, b), (shape, split, order)
+    shape = (1400, 1800)
+    imgs = [torch.rand(shape, device="cuda") for _ in range(2)]
+    cls, nb = (cv.SteerableFiltersG2, 7) if kind == 2 else (cv.SteerableFiltersG4, 11)
+    ref = cls(None)
+    ref.set_option(L.OPT_BLOCK_ORDER, L.ORDER_PLAIN)
+    want = []
+    for im in imgs:
+        gq, hq = ref.setup_steer(im, 0.3)
+        want.append([gq.clone(), hq.clone()] + [ref.basis(p).clone() for p in range(nb)])
+    f = cls(None)
+    f.set_option(L.OPT_BLOCK_ORDER, L.ORDER_DYNAMIC_TAIL)
+    f.set_option(L.OPT_AUTOTUNE, 0)
+    buf = torch.empty(shape, device="cuda")
+    g, h = torch.empty_like(buf), torch.empty_like(buf)
+
+    def run():
+        f.setup_steer(buf, 0.3, out=(g, h))
+
+    def poison():     # a tile that is not written keeps this
+        g.fill_(-7.0); h.fill_(-7.0)
+        for p in range(nb):
+            f.basis(p).fill_(-7.0)
+
+    def check(which, tag):
+        torch.cuda.synchronize()
+        cur = [g, h] + [f.basis(p) for p in range(nb)]
+        for a_, b_ in zip(cur, want[which]):
+            assert torch.equal(a_, b_), tag
+
+    buf.copy_(imgs[0]); run(); check(0, "first eager")
+    assert f.launch_info()["block_order"] == L.ORDER_DYNAMIC_TAIL
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        run()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            run()                                # exactly ONE dynamic launch in the graph
+    torch.cuda.synchronize()
+    seq = ["replay", "eager", "replay", "eager", "eager", "eager", "replay", "replay", "eager"]
+    for n, what in enumerate(seq):
+        which = n & 1
+        buf.copy_(imgs[which])
+        poison()
+        torch.cuda.synchronize()
+        if what == "replay":
+            graph.replay()
+        else:
+            run()
+        check(which, (n, what))
 
 
-@pytest.mark.parametrize("search", [0, 1])
-def test_one_object_per_image_per_worker_thread(cv, monkeypatch, search):
-    """(search = 1: the opt-in placement search switched on for every new handle through the environment, so that its
-    process-wide lock, verdict memory and address-space budget are shared by the threads too.)
-    The reference's usage model (example/steer.cpp:69-71,86: cv::parallel_for_ over files, one SteerableFiltersG2
+def test_one_object_per_image_per_worker_thread(cv):
+    """The reference's usage model (example/steer.cpp:69-71,86: cv::parallel_for_ over files, one SteerableFiltersG2
     per image inside the body): eight host threads, each constructing short-lived objects on its own images --
-    device planes and host planes, two sizes (one large enough for the allocation-time placement probe and the
-    launch tuner) -- while the others do the same.  Everything process-wide (state-block cache, tuner memory,
-    placement probe, address-space budget) is shared; results must equal the serial ones bit for bit."""
+    device planes and host planes, two sizes (one large enough for the launch tuner) -- while the others do the same.
+    Everything process-wide (state-block cache, tuner memory, tile-queue slots) is shared; results must equal the serial
+    ones bit for bit."""
     import threading
     import torch
-    monkeypatch.setenv("CVS_PLACEMENT_SEARCH", str(search))
     shapes = [(200, 333), (2112, 4096)]
     rng = np.random.default_rng(77)
     images = [[torch.from_numpy(rng.random(s, dtype=np.float32)).cuda() for _ in range(3)] for s in shapes]
