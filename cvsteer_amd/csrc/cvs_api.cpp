@@ -113,7 +113,6 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     h->last_image = image->data;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols, fresh);
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
-    a.g4_split = h->g4_split;
     a.diag = h->diag;
     a.out_row_lo = out_row_lo;
     a.out_row_hi = out_row_hi;
@@ -302,7 +301,6 @@ int cvs_create(int kind, int width, float spacing, int device, cvs_handle* out)
     if (eo.autotune >= 0) h->autotune = eo.autotune;
     if (eo.layout >= 0) h->layout = eo.layout;
     if (eo.pyr_strip >= 0) h->pyr_strip = eo.pyr_strip;
-    if (eo.g4_split >= 0) h->g4_split = eo.g4_split;
     *out = h;
     return CVS_OK;
 }
@@ -856,7 +854,6 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.no_state = h->persist ? 0 : 1;
     a.find_on_e = h->find_on;
     a.frames = regular ? nullptr : h->frame_tab;
-    a.g4_split = h->g4_split;
     a.batch = n;
     // state kept: frames from the two halves of the batch in flight together (see k_basis); the stateless launch is bound by
     // the SIMDs and does not care.  CVS_OPTS batch_ways=<n> is a tuning aid (1 = frames in order).

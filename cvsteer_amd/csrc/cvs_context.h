@@ -51,7 +51,6 @@ struct cvs_context {
     const void* last_image = nullptr;    // input pointer of the previous setup (fresh-input heuristic)
     int layout = 1;   // CVS_OPT_STATE_LAYOUT: 0 = planar, 1 = row-interleaved (default), 2 = one group of twelve for full G2 setups
     int atan_mode = 0, strip_rows = 0, find_on = 0, block_order = -1, persist = 1, g4_ext = 0, autotune = 1;
-    int g4_split = 2;    // G4 bank form: 2 = both half banks in one launch (the product's); 0 / 1 only through CVS_OPTS (A/B)
     cvs_launch_info last{};   // what the last basis launch of this handle did (cvs_get_launch_info)
     int pyr_strip = 1;   // cvs_pyr_down as a strip march (CVS_OPTS pyr_strip=0: the stand-alone kernel; A/B only, same values)
     hipEvent_t ev_order = nullptr;            // cvs_set_stream: orders the new stream behind the old one
@@ -151,7 +150,7 @@ int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input = fals
 int use_nt_stores(cvs_handle h, size_t npix);
 // process-wide overrides parsed once from the environment variable CVS_OPTS="name=value,..." (include/cvsteer_hip.h)
 struct EnvOpts {
-    int autotune = -1, layout = -1, pyr_strip = -1, batch_ways = -1, read_ahead = -1, g4_split = -1, nt_stores = -1, verbose = 0;
+    int autotune = -1, layout = -1, pyr_strip = -1, batch_ways = -1, read_ahead = -1, nt_stores = -1, verbose = 0;
     long pool_mb = 4096;
 };
 EnvOpts env_opts();

@@ -53,7 +53,6 @@ struct BasisArgs {
     int strip_rows;       // output rows per wave strip
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
-    int g4_split;         // 0 = one 11-plane kernel, 1 = two half launches, 2 = both halves in one launch
     int read_ahead;       // host only (cvs_tune.cpp -> do_setup): a pure-read pass over the image in front of the launch
     int merge_orient;     // host only (cvs_tune.cpp -> do_setup): lay the G2 orientation planes out in one group with the basis planes
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at

@@ -9,8 +9,8 @@
 // Design (HBM-bound: 4 B read + 28/44 B written per pixel, ~102/290 VALU instructions per row):
 //  * one WAVE owns a strip 64 columns wide and `strip_rows` tall and marches down it; the four
 //    waves of a workgroup own four adjacent strips and never synchronise with each other.
-//  * per input row the wave issues one coalesced 256-B row load (+ one 2W-lane halo load),
-//    stages the 64+2W values in its private LDS line, and every lane reads its 2W+1
+//  * per input row the wave issues one 256-B row load (+ one 2W-lane halo load) that lands DIRECTLY in the wave's ring of
+//    2W+1 LDS lines (buffer_load ... lds: no prefetch registers, no LDS stores), and every lane reads its 2W+1
 //    neighbours back: the row pass.  REFLECT_101 is folded into the load addresses, so the
 //    border costs nothing in the loop.
 //  * the 6 (10) distinct row-filtered values enter a (2W+1)-deep sliding window held in
@@ -18,8 +18,8 @@
 //    the column pass runs on that window, also in folded symmetric / antisymmetric form.
 //  * the input is read once and every output plane is written once with 256-B row segments,
 //    nontemporal once the planes outgrow the Infinity Cache.
-//  * loads for the next 2W+1 rows are in flight while the current ones are filtered (the register
-//    just consumed is refilled at once; the prefetch is branch-free).
+//  * loads for the next 2W+1 rows are in flight while the current ones are filtered (the line
+//    just consumed is refilled at once; the prefetch is branch-free; waits are counted by hand, see dma_row).
 //  * every memory access is a buffer instruction: plane = resource (SGPRs), row = scalar offset,
 //    column = one per-lane byte offset shared by all loads and stores; masked lanes use an
 //    out-of-range offset that the hardware range check drops.
@@ -61,26 +61,13 @@ struct BankG2 {  // SteerableFiltersG2.cpp:62-68
     static constexpr bool SRED = false;
 };
 
-struct BankG4 {  // SteerableFiltersG4.cpp:69-80
-    static constexpr int KIND = 4, W = 6, NE = 5, NO = 5, NB = 11;
-    static constexpr int MIN_WAVES = 1;
-    // even: E0=G41 E1=G42(=H42) E2=G45 E3=H43 E4=H46 ; odd: O0=G43 O1=G44 O2=H41 O3=H44 O4=H45 (ids 5..9)
-    __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 5, 2, 6, 1, 7, 3, 9, 4, 8, 1}; return t[p]; }
-    __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 6, 2, 5, 0, 1, 8, 4, 9, 3, 7}; return t[p]; }
-    static constexpr int even_member(int r) { constexpr int t[NE] = {0, 1, 4, 7, 10}; return t[r]; }
-    static constexpr int odd_member(int r) { constexpr int t[NO] = {2, 3, 5, 8, 9}; return t[r]; }
-    static constexpr int dup_a = 1, dup_b = 6;  // m_g2 == m_h2
-    static constexpr int PLANE0 = 0, HALF = 0;
-    static constexpr bool VOFF = false;
-    static constexpr bool SRED = true;
-};
-
-// The 11-plane bank needs a 10 x 13 register window (187 VGPRs, 2 waves/SIMD).  Its G and H
-// halves share no row-filtered plane, so they also run as two launches with 65- and 78-register
-// windows; the image is read twice (the second read is an L2 / Infinity-Cache hit).
+// The 11-plane G4 bank as ONE kernel needs a 10 x 13 register window (158 VGPRs with the LDS-DMA input path, three waves per
+// SIMD) and runs 3-6 % behind this form at every strip height and order (profiles/r05_input_dma_ab.txt; removed in round 5): its
+// G and H halves share no row-filtered plane, so they run as the two z-planes of one launch with 65- and 78-register windows
+// (126 VGPRs, four waves per SIMD); the image is read twice (the second read is an L2 / Infinity-Cache hit).
 struct BankG4G {  // planes g4a..g4e, SteerableFiltersG4.cpp:69-73
     static constexpr int KIND = 4, W = 6, NE = 3, NO = 2, NB = 5;
-    static constexpr int MIN_WAVES = 1;  // forcing 4 waves/SIMD (128 VGPRs) costs scratch spills and ~4 points (measured)
+    static constexpr int MIN_WAVES = 1;
     // even: E0=G41 E1=G42 E2=G45 ; odd: O0=G43 O1=G44 (ids 3,4)
     __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {0, 3, 2, 4, 1}; return t[p]; }
     __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {1, 4, 2, 3, 0}; return t[p]; }
@@ -97,7 +84,7 @@ struct BankG4G {  // planes g4a..g4e, SteerableFiltersG4.cpp:69-73
 
 struct BankG4H {  // planes h4a..h4f, SteerableFiltersG4.cpp:75-80
     static constexpr int KIND = 4, W = 6, NE = 3, NO = 3, NB = 6;
-    static constexpr int MIN_WAVES = 1;  // forcing 4 waves/SIMD (128 VGPRs) costs scratch spills and ~4 points (measured)
+    static constexpr int MIN_WAVES = 1;
     // even: E0=H42 E1=H43 E2=H46 ; odd: O0=H41 O1=H44 O2=H45 (ids 3,4,5)
     __host__ __device__ static constexpr int rx(int p) { constexpr int t[NB] = {3, 1, 5, 2, 4, 0}; return t[p]; }
     __host__ __device__ static constexpr int cy(int p) { constexpr int t[NB] = {0, 4, 2, 5, 1, 3}; return t[p]; }
@@ -122,15 +109,6 @@ enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8, F_PYR = 16, F_PYRON
                                                                             // loop, no second arctangent path in the instruction cache (+3.5 % on 32 x 1080p; same values);
                                                                             // F_PYR: also emit cv::pyrDown(image) (next pyramid level);
                                                                             // F_PYRONLY (with F_PYR): nothing but that -- cvs_pyr_down as a strip march
-
-// LDS hand-off inside ONE wave: DS ops of a wave execute in issue order, so only the compiler
-// must be kept from moving them across this point.
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Addressing idiom: buffer instructions.  A plane is a raw buffer resource (4 SGPRs, built from
 // wave-uniform values only), the row is the scalar offset (one SGPR, `soffset`), the lane's column
@@ -158,17 +136,6 @@ __device__ __forceinline__ rsrc_t plane_rsrc(const float* base, size_t bytes)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
                                              (int)(bytes > kMaxPlaneBytes ? kMaxPlaneBytes : bytes), 0x00020000);
 }
-__device__ __forceinline__ float bld(rsrc_t r, unsigned lane_off, unsigned row_off)
-{
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));
-}
-// one 8-bit sample per lane, widened unscaled (0..255) like cv::Mat1f(const Mat&); out-of-range lanes read 0
-template <bool U8>
-__device__ __forceinline__ float bld_in(rsrc_t r, unsigned lane_off, unsigned row_off)
-{
-    if constexpr (U8) return (float)__builtin_amdgcn_raw_buffer_load_b8(r, lane_off, row_off, 0);
-    else return bld(r, lane_off, row_off);
-}
 // cache policy of the streaming stores (aux bits of the buffer store on gfx94x / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt alone is the
 // product's; `make storepolicy` builds twins with other policies for tools/store_policy_probe.sh
 #ifndef CVS_STREAM_AUX
@@ -191,9 +158,6 @@ __device__ __forceinline__ void bst(rsrc_t r, unsigned lane_off, unsigned row_of
 // counted by hand: vector-memory operations retire in issue order and `s_waitcnt vmcnt(N)` waits until at most N are
 // outstanding, so a row has landed once N = number of loads and stores issued after its halo load (see the row loop).
 // ---------------------------------------------------------------------------------------
-#ifndef CVS_INPUT_DMA
-#define CVS_INPUT_DMA 1   // 0: every variant stages through VGPRs as in rounds 1-4 (A/B twin, `make nodma`)
-#endif
 constexpr int kRingLine = 128;   // floats per ring line (512 B): 64 + 2W used, the rest takes the zeros of the halo load's idle lanes
 typedef int i4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_float;
@@ -346,7 +310,7 @@ __device__ __forceinline__ bool pick_tile(const BasisArgs& a, int* s_tile, int& 
     return true;
 }
 
-// the kernel body: one wave filters one strip.  `line` = this wave's LDS line (64 + 2W + 4 floats),
+// the kernel body: one wave filters one strip.  `line` = this wave's LDS ring ((2W+1) x kRingLine floats),
 // `zframe` = frame index of a batched launch.
 // WPB = waves (adjacent 64-column strips of one row band) per workgroup.  Always 4: 8-wave workgroups were built
 // and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones; one- and
@@ -357,8 +321,6 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 {
     constexpr unsigned EB = U8 ? 1u : 4u;   // bytes per input sample
     constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
-    constexpr int LW = 64 + 2 * W;
-    constexpr bool DMA = CVS_INPUT_DMA != 0;   // input rows go straight into the wave's LDS ring
     // vector-memory instructions per output row that EVERY launch of this variant issues (state planes, fused steer, the three
     // maps of FEAT3; outputs selected at run time are not counted): a lower bound is all the hand-counted waits need
     constexpr int S_ROW = (((FLAGS & F_NOSTATE) == 0 && (FLAGS & F_PYRONLY) == 0) ? NB : 0) +
@@ -390,21 +352,12 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     const int yend = min(y0 + a.strip_rows, ONE ? a.rows : a.row_hi);
     const int x = x0 + lane;
     const bool xin = x < a.cols;
-    // REFLECT_101 source columns, fixed for the whole strip.  Columns beyond cols+W feed no valid
-    // output; they are clamped so the address stays inside the row.
-    const int xm = min(reflect1(x, a.cols), a.cols - 1);
-    const bool is_halo = lane < 2 * W;
-    const int xh = min(reflect1(lane < W ? x0 - W + lane : x0 + 64 + (lane - W), a.cols), a.cols - 1);
-    // per-lane byte offsets; kLaneOff = "this lane does not take part" (hardware range check)
+    // per-lane byte offsets, fixed for the whole strip; kLaneOff = "this lane does not take part" (hardware range check)
     const unsigned xb = xin ? (unsigned)x * 4u : kLaneOff;
-    const unsigned xmb = (unsigned)xm * EB;      // input column offsets (bytes of the image's own type)
-    const unsigned xhb = is_halo ? (unsigned)xh * EB : kLaneOff;
-    // LDS-DMA form: lane l fetches column x0 - W + l into word l of the line, lanes < 2W also column x0 - W + 64 + l into word 64 + l
-    [[maybe_unused]] const unsigned dmb = (unsigned)max(0, min(reflect1(x0 - W + lane, a.cols), a.cols - 1)) * EB;
-    [[maybe_unused]] const unsigned dhb = is_halo ? (unsigned)max(0, min(reflect1(x0 - W + 64 + lane, a.cols), a.cols - 1)) * EB : kLaneOff;
-    // left halo -> [0,W), right -> [64+W, 64+2W); lanes that carry no halo value write into the
-    // 4 pad words behind the line, so the staging code has no exec-mask branch
-    const int hslot = lane < W ? lane : (is_halo ? 64 + lane : LW + (lane & 3));
+    // input columns (REFLECT_101, bytes of the image's own type): lane l fetches column x0 - W + l into word l of the line, lanes
+    // < 2W also column x0 - W + 64 + l into word 64 + l.  Columns beyond cols + W feed no valid output; they are clamped into the row.
+    const unsigned dmb = (unsigned)max(0, min(reflect1(x0 - W + lane, a.cols), a.cols - 1)) * EB;
+    const unsigned dhb = lane < 2 * W ? (unsigned)max(0, min(reflect1(x0 - W + 64 + lane, a.cols), a.cols - 1)) * EB : kLaneOff;
     // per-frame pointers: kernel arguments, or (batched launch) entry blockIdx.z of the frame table
     const float* in_p = a.in;
     size_t in_pitch = a.in_pitch;
@@ -445,10 +398,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // buffer resources (wave-uniform): input plane, state planes
     const size_t plane_bytes = (size_t)(a.rows - rbase) * a.pitch * sizeof(float);
     const unsigned pitch_b = (unsigned)(a.pitch * sizeof(float));
-    const rsrc_t r_in = plane_rsrc(in_p, (size_t)(a.rows - rbase) * in_pitch * EB);
-    [[maybe_unused]] const i4_t r_in_dma = raw_rsrc(in_p, (size_t)(a.rows - rbase) * in_pitch * EB);
-    [[maybe_unused]] const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(line));   // LDS byte address of this wave's ring
-    [[maybe_unused]] const unsigned lds_lane = (unsigned)reinterpret_cast<uintptr_t>(line) + (unsigned)lane * 4u;            // ... of this lane's first word in line 0
+    const i4_t r_in_dma = raw_rsrc(in_p, (size_t)(a.rows - rbase) * in_pitch * EB);
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(line));   // LDS byte address of this wave's ring
+    const unsigned lds_lane = (unsigned)reinterpret_cast<uintptr_t>(line) + (unsigned)lane * 4u;            // ... of this lane's first word in line 0
     // ONE: the frame's whole state block (basis + orientation planes, one allocation) is a single
     // resource and the plane is part of the scalar offset -- 4 SGPRs instead of 4 per plane, which is
     // what keeps the 20-plane pipeline variant from spilling SGPRs.  Needs the block to be < 2 GiB;
@@ -470,7 +422,6 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     const unsigned in_pitch_b = (unsigned)(in_pitch * EB);
 
     float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
-    [[maybe_unused]] float pre[NT], preh[NT];  // prefetched input rows (main lane value, halo-lane value); unused in the LDS-DMA form
     // F_PYR: the last five horizontally blurred rows ([1 4 6 4 1] at this lane's column); even lanes of even centre
     // rows make one pixel of the next pyramid level each (launch_pyr_down's arithmetic, op for op)
     [[maybe_unused]] float hw0 = 0.f, hw1 = 0.f, hw2 = 0.f, hw3 = 0.f, hw4 = 0.f;
@@ -516,18 +467,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     }
     [[maybe_unused]] unsigned orow2_run = ((unsigned)(y0 - rbase) - (unsigned)(2 * W)) * pitch2_b;   // row offset in the second group
 
-    if constexpr (DMA) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            dma_row<U8>(r_in_dma, dmb, dhb, (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b, ring_base + (unsigned)(j * kRingLine * 4));
-    } else {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const unsigned ro = (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b;
-            pre[j] = bld_in<U8>(r_in, xmb, ro);
-            preh[j] = bld_in<U8>(r_in, xhb, ro);
-        }
-    }
+    for (int j = 0; j < NT; ++j)   // the first 2W+1 rows, one per ring line
+        dma_row<U8>(r_in_dma, dmb, dhb, (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b, ring_base + (unsigned)(j * kRingLine * 4));
 
     // One row step: input row i = g NT + j is read back from its line (slot j), the line is refilled with row i + NT, the row pass
     // feeds window slot j, and -- from step 2W on -- the column pass writes output row i - 2W.  PHASE 0 = the first group (window
@@ -535,12 +477,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // the two differ in their hand-counted waits, and the priming steps carry no column-pass code at all.
     auto row_step = [&](auto phase, const int g, const int j, const bool more) __attribute__((always_inline)) {
         constexpr int PHASE = decltype(phase)::value;
-        // Prefetch for the NEXT group is issued unconditionally (straight-line code: no phi copies, no early waits); in the last
-        // group the lane offsets are kLaneOff, so the hardware range check drops those loads without touching memory.
-        [[maybe_unused]] const unsigned nxmb = more ? xmb : kLaneOff, nxhb = more ? xhb : kLaneOff;
         {
             float s[NT];
-            if constexpr (DMA) {
+            {
                 // Has row i = g NT + j landed in line j?  Operations issued after its halo load: the loads of the NT - 1 rows
                 // that followed it, and the stores of every OUTPUT row among the NT row steps since.  Steps 2W.. are output rows;
                 // so none in group 0, j + 1 of them in group 1, NT from group 2 on.  (Steps past the strip's last row wait for a
@@ -572,31 +511,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     } else {
                         ro = (unsigned)(reflect1(y0 - W + (g + 1) * NT + j, a.rows) - rbase) * in_pitch_b;
                     }
-                    // in the last group the lane offsets are kLaneOff: the loads are dropped by the range check (and still counted)
+                    // The load for the NEXT group is issued unconditionally (straight-line code); in the last group the lane offsets are
+                    // kLaneOff: the loads are dropped by the range check without touching memory (and are still counted)
                     dma_row<U8>(r_in_dma, more ? dmb : kLaneOff, more ? dhb : kLaneOff, ro, ring_base + (unsigned)(j * kRingLine * 4));
                 }
-            } else {
-            const float v = pre[j], vh = preh[j];
-            // the register just consumed is refilled at once with the same row of the next group:
-            // a full group (2W+1 rows) of loads stays in flight with a single set of registers
-            {
-                unsigned ro;
-                if constexpr (SRED) {
-                    ro = ro_lin >= ro_lim ? ro_mir - ro_lin : ro_lin;
-                    ro_lin += in_pitch_b;
-                } else {
-                    ro = (unsigned)(reflect1(y0 - W + (g + 1) * NT + j, a.rows) - rbase) * in_pitch_b;
-                }
-                pre[j] = bld_in<U8>(r_in, nxmb, ro);
-                preh[j] = bld_in<U8>(r_in, nxhb, ro);
-            }
-            // ---- row pass: stage the line, read the 2W+1 neighbours ----
-            line[W + lane] = v;
-            line[hslot] = vh;
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < NT; ++k) s[k] = line[lane + k];
-            wave_lds_fence();
             }
 
             if constexpr ((FLAGS & F_PYR) != 0) {
@@ -768,9 +686,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     const unsigned og = yo * (unsigned)(a.steer_g_pitch * sizeof(float));
                     const unsigned oh = yo * (unsigned)(a.steer_h_pitch * sizeof(float));
                     if constexpr (B::HALF == 0) {
+                        static_assert(B::KIND == 2, "the whole-bank form exists for G2 only");
                         float gq, hq;
-                        if constexpr (B::KIND == 2) g2_steer_weights(b, a.steer_w, gq, hq);
-                        else g4_steer_weights(b, a.steer_w, gq, hq);
+                        g2_steer_weights(b, a.steer_w, gq, hq);
                         bst<STREAM>(rg, xbr, og, gq);
                         bst<STREAM>(rh, xbr, oh, hq);
                     } else if constexpr (B::HALF == 1) {  // the G sum of G2.cpp:143 / G4.cpp:120, left to right
@@ -813,7 +731,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int WPB = 4, bool U8 = false>
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
-    __shared__ float lds[WPB][CVS_INPUT_DMA != 0 ? (2 * B::W + 1) * kRingLine : 64 + 2 * B::W + 4];
+    __shared__ float lds[WPB][(2 * B::W + 1) * kRingLine];   // one ring of 2W+1 lines per wave
     __shared__ int s_tile;
     // Frame batches with state kept: the frames are dispatched dealt from z_ways equal parts of the batch in turn (0, n/2, 1,
     // n/2 + 1, ... for two), so that the frames in flight together -- about ten of 1080p -- have their state planes, inputs and
@@ -840,7 +758,7 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
 template <class BG, class BH, int FLAGS, bool STREAM, bool ONE, bool U8 = false>
 __global__ __launch_bounds__(256) void k_basis_pair(const BasisArgs a, const Folded<BG> tg, const Folded<BH> th)
 {
-    __shared__ float lds[4][CVS_INPUT_DMA != 0 ? (2 * BG::W + 1) * kRingLine : 64 + 2 * BG::W + 4];
+    __shared__ float lds[4][(2 * BG::W + 1) * kRingLine];
     __shared__ int s_tile;
     int bx = 0, by = 0;
     unsigned z = 0;
@@ -924,7 +842,11 @@ static bool fold_taps(const float (*taps)[kMaxTaps], Folded<B>& f)
 bool basis_fast_path(int kind, int width, const float (*taps)[kMaxTaps])
 {
     if (kind == 2 && width == BankG2::W) { Folded<BankG2> f; return fold_taps<BankG2>(taps, f); }
-    if (kind == 4 && width == BankG4::W) { Folded<BankG4> f; return fold_taps<BankG4>(taps, f); }
+    if (kind == 4 && width == BankG4G::W) {
+        Folded<BankG4G> fg;
+        Folded<BankG4H> fh;
+        return fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh);
+    }
     return false;
 }
 
@@ -1090,8 +1012,7 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
             }
         }
     } else {
-        if (steer) CVS_LAUNCH(F_STEER);
-        else CVS_LAUNCH(0);
+        return hipErrorInvalidValue;   // G4 runs as the pair launch (launch_pair)
     }
 #undef CVS_LAUNCH_B
 #undef CVS_LAUNCH_W
@@ -1341,24 +1262,11 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
         Folded<BankG2> f;
         if (fold_taps<BankG2>(taps, f)) return for_each_band(a, width, [&](const BasisArgs& b) { return launch_fast<BankG2>(b, f, s); });
     }
-    if (kind == 4 && width == BankG4::W && a.g4_split == 2) {
+    if (kind == 4 && width == BankG4G::W) {
         Folded<BankG4G> fg;
         Folded<BankG4H> fh;
         if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh))
             return for_each_band(a, width, [&](const BasisArgs& b) { return launch_pair<BankG4G, BankG4H>(b, fg, fh, s); });
-    }
-    if (kind == 4 && width == BankG4::W) {
-        if (a.g4_split) {
-            Folded<BankG4G> fg;
-            Folded<BankG4H> fh;
-            if (fold_taps<BankG4G>(taps, fg) && fold_taps<BankG4H>(taps, fh))
-                return for_each_band(a, width, [&](const BasisArgs& b) {
-                    hipError_t e = launch_fast<BankG4G>(b, fg, s);
-                    return e != hipSuccess ? e : launch_fast<BankG4H>(b, fh, s);
-                });
-        }
-        Folded<BankG4> f;
-        if (fold_taps<BankG4>(taps, f)) return for_each_band(a, width, [&](const BasisArgs& b) { return launch_fast<BankG4>(b, f, s); });
     }
     return launch_generic(kind, width, taps, a, scratch, s);
 }

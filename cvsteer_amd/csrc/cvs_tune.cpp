@@ -76,10 +76,10 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // Process-wide, keyed by device, kind, kernel variant, bucket, batch size, layout and what the caller pinned.
 // ---------------------------------------------------------------------------------------------------------------------
 struct Cand {
-    int order, strip, split;
+    int order, strip;
     int ahead = 0;   // launches on new images: a pure-read pass over the image first (cvs_kernels_point.hip k_read_ahead)
     int merge = 0;   // G2 launches that write orientation planes: one 12-plane group instead of basis | orientation (cvs_handle.cpp layout_state)
-    bool operator==(const Cand& o) const { return order == o.order && strip == o.strip && split == o.split && merge == o.merge && ahead == o.ahead; }
+    bool operator==(const Cand& o) const { return order == o.order && strip == o.strip && merge == o.merge && ahead == o.ahead; }
 };
 
 struct TuneEntry {
@@ -114,7 +114,6 @@ static void apply(BasisArgs& a, const Cand& c)
 {
     a.block_order = c.order;
     a.strip_rows = c.strip;
-    a.g4_split = c.split;
     a.merge_orient = c.merge;
     a.read_ahead = c.ahead;
 }
@@ -192,7 +191,7 @@ static void evaluate(TuneEntry& e)
         if (env_opts().verbose) {
             std::fprintf(stderr, "[cvsteer] tuned on the caller's launches (ns/pix median x samples):");
             for (size_t c = 0; c < e.cand.size(); ++c)
-                std::fprintf(stderr, " (order %d, strip %d, split %d, merged %d, read-ahead %d%s) %.5f x%zu", e.cand[c].order, e.cand[c].strip, e.cand[c].split,
+                std::fprintf(stderr, " (order %d, strip %d, merged %d, read-ahead %d%s) %.5f x%zu", e.cand[c].order, e.cand[c].strip,
                              e.cand[c].merge, e.cand[c].ahead, e.dropped[c] ? ", dropped" : "", e.samples[c].empty() ? 0.f : median_of(e.samples[c]), e.samples[c].size());
             std::fprintf(stderr, " -> candidate %d after %d rounds\n", decision, e.round);
         }
@@ -246,7 +245,6 @@ static hipEvent_t take_event(int device)   // the caller has made `device` curre
 // the engine's default configuration for this launch; true = the launch is of a kind whose alternatives are worth comparing
 static bool default_config(cvs_handle h, BasisArgs& a)
 {
-    a.g4_split = h->g4_split;
     // CVS_OPT_STATE_LAYOUT = 2 pins the grouping: launches that write orientation planes use ONE group of twelve planes
     a.merge_orient = (h->layout == 2 && h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0) ? 1 : 0;
     const bool fast = basis_fast_path(h->kind, h->width, h->taps);
@@ -261,7 +259,7 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
 {
     const bool free_order = h->block_order < 0;
     const bool free_strip = h->strip_rows <= 0 && (a.batch == 0 || !a.no_state);
-    Cand def{a.block_order, a.strip_rows, a.g4_split};
+    Cand def{a.block_order, a.strip_rows};
     def.merge = a.merge_orient;
     e.cand.assign(1, def);
     auto add = [&](Cand c) {
@@ -290,8 +288,8 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
                 e.cand.push_back(m);
             }
             if ((size_t)a.rows * a.cols < ((size_t)8 << 20)) {
-                add({kOrderDynamic, sr_short, def.split});
-                add({kOrderXcdColumns, sr_short, def.split});
+                add({kOrderDynamic, sr_short});
+                add({kOrderXcdColumns, sr_short});
             }
         } else {
             // Resident image.  What has beaten the default (plain order, 10-row strips) by more than 2 % in SUSTAINED side-by-side
@@ -301,16 +299,16 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
             // those are not tuned at all.
             const bool multi = a.orient != nullptr || a.pipe;
             const bool large = (size_t)a.rows * a.cols >= ((size_t)8 << 20);
-            if (multi || !large) add({kOrderDynamic, sr_short, def.split});
+            if (multi || !large) add({kOrderDynamic, sr_short});
             if (!large) {   // smaller images (the default there is the 19-row strip): both heights, the column order
-                add({0, sr_short, def.split});
-                add({0, sr_tall, def.split});
-                add({kOrderXcdColumns, sr_short, def.split});
+                add({0, sr_short});
+                add({0, sr_tall});
+                add({kOrderXcdColumns, sr_short});
             }
         }
     } else {
         // G4: the dynamic tail (+6 % on one box, level on the others)
-        add({kOrderDynamic, def.strip, def.split});
+        add({kOrderDynamic, def.strip});
         if (ahead_ok && e.cand.size() < 4) {
             Cand m = def;
             m.ahead = 1;
@@ -344,7 +342,7 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     const bool tunable = default_config(h, a);
     if (!tunable || !h->autotune) return CVS_OK;
     if (h->block_order >= 0 && h->strip_rows > 0) return CVS_OK;   // everything pinned
-    const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->g4_split != 2 ? 1 : 0) + (h->last.state_layout ? 4 : 0) + (h->layout << 3) + ((h->block_order + 1) ? 32 : 0);
+    const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->last.state_layout ? 4 : 0) + (h->layout << 3) + ((h->block_order + 1) ? 32 : 0);
     const TuneKey key = std::make_tuple(h->device, variant | (fresh_input ? 256 : 0) | (h->kind << 12) | (pins << 16) | (a.in_u8 << 24),
                                         pix_bucket(a.rows, a.cols), h->block_order, a.batch);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -434,7 +432,6 @@ void note_launch(cvs_handle h, const BasisArgs& a)
     h->last.block_order = a.block_order;
     h->last.strip_rows = a.strip_rows;
     h->last.nt_stores = a.nt_stores;
-    h->last.g4_split = a.g4_split;
     h->last.read_ahead = a.read_ahead;
     h->last.tuning_launches = 0;   // nothing is ever launched beyond the caller's own calls
 }

@@ -64,10 +64,24 @@ std::string slurp(const std::string& path)
     return ss.str();
 }
 
-// binary PGM: "P5" ws width ws height ws maxval single-ws raster ('#' comments allowed in the header)
-Image read_pgm(const std::string& path)
+// a decimal header field: digits only, at most 9 of them (no sign, no overflow); -1 = anything else
+long header_number(const std::string& t)
 {
-    const std::string d = slurp(path);
+    if (t.empty() || t.size() > 9) return -1;
+    long v = 0;
+    for (char c : t) {
+        if (c < '0' || c > '9') return -1;
+        v = v * 10 + (c - '0');
+    }
+    return v;
+}
+
+constexpr long kMaxDim = 1 << 20;   // rows / columns this driver accepts (the engine itself takes larger planes)
+
+// binary PGM: "P5" ws width ws height ws maxval single-ws raster ('#' comments allowed in the header).  `d` = the file's bytes:
+// untrusted input -- every size is checked against the bytes that are really there before anything is copied.
+Image parse_pgm(const std::string& d, const std::string& path)
+{
     size_t pos = 0;
     auto token = [&]() {
         for (;;) {
@@ -85,41 +99,55 @@ Image read_pgm(const std::string& path)
     if (token() != "P5") throw std::runtime_error(path + ": not a binary PGM (P5)");
     Image im;
     im.path = path;
-    im.cols = std::atoi(token().c_str());
-    im.rows = std::atoi(token().c_str());
-    const int maxval = std::atoi(token().c_str());
+    const long cols = header_number(token()), rows = header_number(token()), maxval = header_number(token());
+    if (rows <= 0 || cols <= 0 || rows > kMaxDim || cols > kMaxDim || maxval <= 0 || maxval > 255) throw std::runtime_error(path + ": unsupported PGM header");
+    if (pos >= d.size()) throw std::runtime_error(path + ": truncated raster");
     ++pos;  // the single whitespace byte after maxval
-    if (im.rows <= 0 || im.cols <= 0 || maxval <= 0 || maxval > 255) throw std::runtime_error(path + ": unsupported PGM header");
-    const size_t n = (size_t)im.rows * im.cols;
-    if (d.size() < pos + n) throw std::runtime_error(path + ": truncated raster");
+    const size_t n = (size_t)rows * (size_t)cols;
+    if (d.size() - pos < n) throw std::runtime_error(path + ": truncated raster");
+    im.rows = (int)rows;
+    im.cols = (int)cols;
     im.bytes.assign(reinterpret_cast<const uint8_t*>(d.data()) + pos, reinterpret_cast<const uint8_t*>(d.data()) + pos + n);
     return im;
 }
 
-// NumPy .npy version 1.x / 2.x, 2-D, '|u1' or '<f4', fortran_order False
-Image read_npy(const std::string& path)
+Image read_pgm(const std::string& path) { return parse_pgm(slurp(path), path); }
+
+// NumPy .npy version 1.x / 2.x, 2-D, '|u1' or '<f4', fortran_order False (`d` = the file's bytes, untrusted)
+Image parse_npy(const std::string& d, const std::string& path)
 {
-    const std::string d = slurp(path);
     if (d.size() < 12 || std::memcmp(d.data(), "\x93NUMPY", 6) != 0) throw std::runtime_error(path + ": not an .npy file");
     const int major = (unsigned char)d[6];
     size_t hlen, off;
     if (major == 1) { hlen = (unsigned char)d[8] | ((size_t)(unsigned char)d[9] << 8); off = 10; }
     else { hlen = (unsigned char)d[8] | ((size_t)(unsigned char)d[9] << 8) | ((size_t)(unsigned char)d[10] << 16) | ((size_t)(unsigned char)d[11] << 24); off = 12; }
-    if (d.size() < off + hlen) throw std::runtime_error(path + ": truncated header");
+    if (d.size() - off < hlen) throw std::runtime_error(path + ": truncated header");
     const std::string h = d.substr(off, hlen);
     const bool u1 = h.find("'|u1'") != std::string::npos, f4 = h.find("'<f4'") != std::string::npos;
     if (!u1 && !f4) throw std::runtime_error(path + ": dtype must be uint8 or little-endian float32");
     if (h.find("'fortran_order': False") == std::string::npos) throw std::runtime_error(path + ": fortran order is not supported");
     const size_t sp = h.find("'shape': (");
     if (sp == std::string::npos) throw std::runtime_error(path + ": no shape");
-    int r = 0, c = 0;
-    if (std::sscanf(h.c_str() + sp + 10, "%d, %d", &r, &c) != 2 || r <= 0 || c <= 0) throw std::runtime_error(path + ": expected a 2-D array");
+    // "(rows, cols)": two decimal fields, nothing else
+    size_t q = sp + 10;
+    auto field = [&]() {
+        while (q < h.size() && h[q] == ' ') ++q;
+        const size_t b = q;
+        while (q < h.size() && h[q] >= '0' && h[q] <= '9') ++q;
+        return header_number(h.substr(b, q - b));
+    };
+    const long r = field();
+    if (q >= h.size() || h[q] != ',') throw std::runtime_error(path + ": expected a 2-D array");
+    ++q;
+    const long c = field();
+    while (q < h.size() && h[q] == ' ') ++q;
+    if (q >= h.size() || h[q] != ')' || r <= 0 || c <= 0 || r > kMaxDim || c > kMaxDim) throw std::runtime_error(path + ": expected a 2-D array");
     Image im;
     im.path = path;
-    im.rows = r;
-    im.cols = c;
-    const size_t n = (size_t)r * c, data = off + hlen;
-    if (d.size() < data + n * (u1 ? 1 : 4)) throw std::runtime_error(path + ": truncated data");
+    im.rows = (int)r;
+    im.cols = (int)c;
+    const size_t n = (size_t)r * (size_t)c, data = off + hlen, elem = u1 ? 1 : 4;
+    if ((d.size() - data) / elem < n) throw std::runtime_error(path + ": truncated data");
     im.u8 = u1;
     if (u1) im.bytes.assign(reinterpret_cast<const uint8_t*>(d.data()) + data, reinterpret_cast<const uint8_t*>(d.data()) + data + n);
     else {
@@ -128,6 +156,8 @@ Image read_npy(const std::string& path)
     }
     return im;
 }
+
+Image read_npy(const std::string& path) { return parse_npy(slurp(path), path); }
 
 Image read_gray(const std::string& path)
 {
@@ -174,6 +204,7 @@ std::vector<std::string> input_list(const std::string& arg)
     return out;
 }
 
+#ifndef CVSTEER_RUN_NO_MAIN   // (tests/cpp/fuzz_readers.cpp includes this file for the readers above)
 // the status first, THEN the error text: written as `check(call(&batch), ..., cvs_batch_last_error(batch))` the two
 // arguments are evaluated in unspecified order and the text may be read before the call has run (or created `batch`)
 #define CHECK_BATCH(batch, call, what)                         \
@@ -187,8 +218,10 @@ void check(int rc, const char* what, const char* detail)
     if (rc != CVS_OK) throw std::runtime_error(std::string(what) + ": " + cvs_status_string(rc) + (detail && *detail ? std::string(" -- ") + detail : ""));
 }
 
+#endif
 }  // namespace
 
+#ifndef CVSTEER_RUN_NO_MAIN
 int main(int argc, char** argv)
 {
     std::string input, output, ext = ".pgm";
@@ -296,3 +329,4 @@ int main(int argc, char** argv)
     if (batch) cvs_batch_destroy(batch);
     return failures ? 1 : 0;
 }
+#endif

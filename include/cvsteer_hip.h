@@ -73,7 +73,7 @@ enum {
 };
 
 /* options for cvs_set_option.  Process-wide overrides for new handles (A/B aids): the environment variable
- * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2, pyr_strip=0|1, batch_ways=N, read_ahead=0|1, g4_split=0|1|2,
+ * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2, pyr_strip=0|1, batch_ways=N, read_ahead=0|1,
  * nt_stores=0|1 (output stores plain / nontemporal instead of by size), verbose=1 (the tuner prints its decisions to stderr),
  * pool_mb=N (state-block cache, default 4096, 0 = off).  Read at every call; results never depend on any of them. */
 enum {
@@ -172,7 +172,6 @@ typedef struct cvs_launch_info {
     int32_t block_order;      /* last basis launch: CVS_OPT_BLOCK_ORDER value in effect */
     int32_t strip_rows;       /* ... output rows per wave strip */
     int32_t nt_stores;        /* ... 1 = streaming (nontemporal) stores */
-    int32_t g4_split;         /* ... G4: 2 = both half banks in one launch (the product's), 0 / 1 = A/B forms (CVS_OPTS g4_split) */
     int32_t state_layout;     /* layout of the current state block: 0 = planar, 1 = row-interleaved groups (CVS_OPT_STATE_LAYOUT),
                                  2 = row-interleaved with the G2 orientation planes in the basis planes' group (the tuner's choice) */
     int32_t read_ahead;       /* last basis launch: 1 = a pure-read pass over the image ran in front of it (a tuner candidate for

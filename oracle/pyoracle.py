@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle_cvsteer.so")
+_SO = os.environ.get("ORACLE_LIB", os.path.join(_HERE, "liboracle_cvsteer.so"))  # override: the sanitizer twin (tools/run_sanitizers.sh)
 
 KIND_G2, KIND_G4 = 2, 4
 ATAN_CV, ATAN_EXACT = 0, 1
