@@ -499,7 +499,7 @@ def main():
                         if legs:
                             snap["legs_fmt"] = "[frac_hbm, ms, ms_min, ms_max, launch_configs index, frac_valu]"
                             snap["legs"] = dict(legs)
-                            snap["launch_configs_fmt"] = "[block_order, strip_rows, nt_stores, state_layout, read_ahead, tuned]"
+                            snap["launch_configs_fmt"] = "[block_order, strip_rows, nt_stores, state_layout, warm, tuned]"
                             snap["launch_configs"] = list(configs)
                         if not final:
                             snap["extra_error"] = why or "incomplete"
@@ -522,7 +522,7 @@ def main():
 
     def cfg_index(handle):
         li = handle.launch_info()
-        c = [li["block_order"], li["strip_rows"], li["nt_stores"], li["state_layout"], li["read_ahead"], li["tuned"]]
+        c = [li["block_order"], li["strip_rows"], li["nt_stores"], li["state_layout"], li["warm"], li["tuned"]]
         if c not in configs:
             configs.append(c)
         return configs.index(c)

@@ -112,6 +112,19 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     const bool fresh = h->last_image != (const void*)image->data && !pipe_outs;
     h->last_image = image->data;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols, fresh);
+    // New G2 images of 24 MiB and more: the waves of the launch's first fifth of row bands also touch the rest of the image (four
+    // bands each), so that it is requested from HBM while the launch is young and most of the launch streams its writes without
+    // reads mixed in.  Same process, alternating settings (profiles/r05_fresh_warm.txt): basis pass on alternating 8192^2 images
+    // 0.626 -> 0.744 of the HBM roofline, fused steer on rotating 4096^2 images 0.624 -> 0.716, one object per image 0.614 ->
+    // 0.700, full setup 0.624 -> 0.697; a separate read pass in front of the launch (round 4's tuner candidate, removed) reached
+    // 0.708 where this reaches 0.729 and cannot serve an 8192^2 image at all.  Not for: the launch that also emits the next pyramid
+    // level (-8 %: its cached half-line stores want the L2 for themselves), G4 and the 20-plane pipeline at the SIMDs' limit
+    // (level), 8-bit and small images (level to -3 %).  CVS_OPTS warm=K overrides K (0 = off).
+    {
+        const size_t in_bytes = (size_t)a.rows * a.cols * (a.in_u8 ? 1 : sizeof(float));
+        const int wk = env_opts().warm;
+        a.warm_k = (fresh && h->kind == CVS_KIND_G2 && !pyr && in_bytes >= ((size_t)24 << 20)) ? (wk >= 0 ? wk : 4) : 0;
+    }
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     a.diag = h->diag;
     a.out_row_lo = out_row_lo;
@@ -155,10 +168,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
             fill_state_args(h, a, orient_k);
         }
         note_launch(h, a);
-        hipError_t le = hipSuccess;
-        if (a.read_ahead)   // the image in one pure-read burst first (a tuner candidate for launches on new images)
-            le = launch_read_ahead(a.in, a.in_pitch * (a.in_u8 ? 1 : sizeof(float)), a.rows, (size_t)a.cols * (a.in_u8 ? 1 : sizeof(float)), h->stream);
-        if (le == hipSuccess) le = launch_basis(h->kind, h->width, h->taps, a, scr, h->stream);
+        const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, scr, h->stream);
         tune_end(h, tok);
         HIP_TRY(h, le);
     }

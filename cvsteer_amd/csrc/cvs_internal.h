@@ -53,7 +53,9 @@ struct BasisArgs {
     int strip_rows;       // output rows per wave strip
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
-    int read_ahead;       // host only (cvs_tune.cpp -> do_setup): a pure-read pass over the image in front of the launch
+    int warm_k;           // new images (set by the API layer; 0 = off): the waves of the launch's first row bands also touch the rows of warm_k
+                          // bands further down each, so that the rest of the image is requested while the launch is young (dma_warm)
+    int warm_bands;       // ... how many bands do that: ceil(bands / (warm_k + 1)); filled by the launcher
     int merge_orient;     // host only (cvs_tune.cpp -> do_setup): lay the G2 orientation planes out in one group with the basis planes
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
     int out_row_lo, out_row_hi;    // caller: compute output rows [out_row_lo, out_row_hi) only (0, 0 = the whole image);
@@ -168,8 +170,6 @@ hipError_t launch_quantize_u8(const float* src, size_t pitch, int rows, int cols
 
 hipError_t launch_convert_u8(const float* src, size_t pitch, int rows, int cols, float alpha, float beta, uint8_t* dst,
                              size_t dst_step, hipStream_t s);
-// pure-read pass over an image (rows x row_bytes, step_bytes apart): pulls it into the Infinity Cache ahead of a filter launch
-hipError_t launch_read_ahead(const void* src, size_t step_bytes, int rows, size_t row_bytes, hipStream_t s);
 hipError_t launch_u8_to_f32(const uint8_t* src, size_t sstep, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 hipError_t launch_pyr_down(const float* src, size_t spitch, int rows, int cols, float* dst, size_t dpitch, hipStream_t s);
 // the same as a strip march of the basis kernel's machinery (cvs_kernels_basis.hip); false = geometry not covered, use launch_pyr_down

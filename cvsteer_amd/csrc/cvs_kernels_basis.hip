@@ -199,6 +199,14 @@ __device__ __forceinline__ void dma_row(i4_t rsrc, unsigned vmain, unsigned vhal
                      : "v"(vmain), "v"(vhalo), "s"(rsrc), "s"(lds_line), "s"(soff)
                      : "memory", "scc");
 }
+// one load whose only purpose is to bring a row segment into this XCD's L2 ahead of the workgroup that will need it: it lands in a
+// spare LDS line nobody reads (no VGPR whose late write-back could hit a register the compiler has given to something else)
+template <bool U8>
+__device__ __forceinline__ void dma_warm(i4_t rsrc, unsigned voff, unsigned soff, unsigned lds_line)
+{
+    if constexpr (U8) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_ubyte %0, %1, %3 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_line), "s"(soff) : "memory");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %3 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_line), "s"(soff) : "memory");
+}
 // s_waitcnt vmcnt(n) for an n that is a constant once the row loop is unrolled (the instruction takes an immediate; the counter
 // has 6 bits, and a smaller n only waits longer)
 #define CVS_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
@@ -470,6 +478,19 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #pragma unroll
     for (int j = 0; j < NT; ++j)   // the first 2W+1 rows, one per ring line
         dma_row<U8>(r_in_dma, dmb, dhb, (unsigned)(reflect1(y0 - W + j, a.rows) - rbase) * in_pitch_b, ring_base + (unsigned)(j * kRingLine * 4));
+    // New images (BasisArgs::warm_k > 0): the waves of the first warm_bands row bands of the launch also touch, 64 columns each, the
+    // rows of warm_k bands further down -- band warm_bands + by * warm_k + k -- behind their own first rows: the rest of the image is
+    // requested from HBM while the launch is young and comes out of the Infinity Cache when its tiles run, so that most of the
+    // launch streams its writes without reads mixed in (profiles/r05_fresh_warm.txt).  Results do not depend on it.
+    int nwarm = 0;   // wave-uniform
+    if (a.warm_k > 0 && by < a.warm_bands) {
+        const int rows_end = ONE ? a.rows : a.row_hi;
+        for (int k = 0; k < a.warm_k; ++k) {
+            const int wy = (ONE ? 0 : a.row_lo) + (a.warm_bands + by * a.warm_k + k) * a.strip_rows;
+            for (int j = 0; j < a.strip_rows && wy + j < rows_end; ++j, ++nwarm)
+                dma_warm<U8>(r_in_dma, (unsigned)min(x, a.cols - 1) * EB, (unsigned)(wy + j - rbase) * in_pitch_b, ring_base + (unsigned)(NT * kRingLine * 4));
+        }
+    }
 
     // One row step: input row i = g NT + j is read back from its line (slot j), the line is refilled with row i + NT, the row pass
     // feeds window slot j, and -- from step 2W on -- the column pass writes output row i - 2W.  PHASE 0 = the first group (window
@@ -484,7 +505,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 // that followed it, and the stores of every OUTPUT row among the NT row steps since.  Steps 2W.. are output rows;
                 // so none in group 0, j + 1 of them in group 1, NT from group 2 on.  (Steps past the strip's last row wait for a
                 // row nobody uses; their count may be short, which only lets them read a line that is still being written.)
-                if constexpr (PHASE == 0) wait_vmcnt(VM_ROWS);
+                if constexpr (PHASE == 0) {
+                    if (nwarm >= NT) wait_vmcnt(VM_ROWS + NT);   // (at least) that many warm loads were issued behind the first rows
+                    else wait_vmcnt(VM_ROWS);
+                }
                 else if (VM_ROWS + S_ROW * (j + 1) >= 63) wait_vmcnt(63);   // (a constant once the loop is unrolled)
                 else if (g == 1) wait_vmcnt(VM_ROWS + S_ROW * (j + 1));
                 else wait_vmcnt(VM_ROWS + S_ROW * NT);
@@ -731,7 +755,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int WPB = 4, bool U8 = false>
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
-    __shared__ float lds[WPB][(2 * B::W + 1) * kRingLine];   // one ring of 2W+1 lines per wave
+    __shared__ float lds[WPB][(2 * B::W + 2) * kRingLine];   // per wave: a ring of 2W+1 lines + one spare line (dma_warm)
     __shared__ int s_tile;
     // Frame batches with state kept: the frames are dispatched dealt from z_ways equal parts of the batch in turn (0, n/2, 1,
     // n/2 + 1, ... for two), so that the frames in flight together -- about ten of 1080p -- have their state planes, inputs and
@@ -758,7 +782,7 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
 template <class BG, class BH, int FLAGS, bool STREAM, bool ONE, bool U8 = false>
 __global__ __launch_bounds__(256) void k_basis_pair(const BasisArgs a, const Folded<BG> tg, const Folded<BH> th)
 {
-    __shared__ float lds[4][(2 * BG::W + 1) * kRingLine];
+    __shared__ float lds[4][(2 * BG::W + 2) * kRingLine];
     __shared__ int s_tile;
     int bx = 0, by = 0;
     unsigned z = 0;
@@ -926,6 +950,8 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
     a.grid_x = grid.x;
     a.grid_y = grid.y;
     a.dyn_nz = 1;
+    a.warm_bands = a.warm_k > 0 ? (a.grid_y + a.warm_k) / (a.warm_k + 1) : 0;
+    if (a.grid_y < 10 || a.frames || a.batch_regular) a.warm_k = 0;   // (frame batches: every frame is a small image)
     if (a.block_order == kOrderDynamic && !a.tile_ctr) a.block_order = 0;   // no queue slot for this handle: the plain order
     if (a.block_order != kOrderDynamic && a.block_order != kOrderXcdColumns) a.block_order = 0;
     const bool dyn = a.block_order == kOrderDynamic;
@@ -1040,6 +1066,8 @@ static hipError_t launch_pair_impl(BasisArgs& a, const Folded<BG>& fg, const Fol
     a.grid_x = grid.x;
     a.grid_y = grid.y;
     a.dyn_nz = 2;
+    a.warm_bands = a.warm_k > 0 ? (a.grid_y + a.warm_k) / (a.warm_k + 1) : 0;
+    if (a.grid_y < 10) a.warm_k = 0;
     if (a.block_order == kOrderDynamic && !a.tile_ctr) a.block_order = 0;
     if (a.block_order != kOrderDynamic && a.block_order != kOrderXcdColumns) a.block_order = 0;
     const bool dyn = a.block_order == kOrderDynamic;

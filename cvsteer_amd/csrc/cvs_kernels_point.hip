@@ -385,41 +385,6 @@ __global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* src, size_t ss
             dst[(size_t)row * dpitch + c] = (float)src[(size_t)row * sstep + c];
 }
 
-// ---------------------------------------------------------------------------------------
-// Read-ahead pass: nothing but loads over an image, so that it sits in the Infinity Cache when the filter launch behind it
-// asks for it.  A filter launch on an image that comes from HBM mixes 10 % of reads into its write stream and loses more than
-// those 10 % (the memory runs reads and writes in turns); the same bytes as ONE pure-read burst in front of the launch cost
-// less (a 64 MiB image: ~12 us) than they slow the launch down by (~20 us).  Whether an image IS in the cache already the
-// engine cannot know -- so this is a candidate of the online tuner for launches on new images, kept only where it wins.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_read_ahead(const unsigned char* src, size_t step, int rows, size_t row_bytes, unsigned* sink)
-{
-    // 16 bytes per lane where the row allows, whole rows per workgroup-y
-    unsigned acc = 0;
-    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
-        const unsigned char* rp = src + (size_t)row * step;
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(rp);
-        const size_t head = (16 - (a0 & 15)) & 15;                 // bytes up to the first 16-byte boundary: skipped (their line is
-        const size_t nvec = row_bytes > head ? (row_bytes - head) / 16 : 0;   // fetched by the first vector load or the previous row's last)
-        const uint4* vp = reinterpret_cast<const uint4*>(rp + head);
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-            const uint4 v = vp[i];
-            acc ^= v.x ^ v.y ^ v.z ^ v.w;
-        }
-    }
-    if (acc == 0x9e3779b9u && sink) *sink = acc;   // keeps the loads alive; practically never taken, and harmless if it is
-}
-
-hipError_t launch_read_ahead(const void* src, size_t step_bytes, int rows, size_t row_bytes, hipStream_t s)
-{
-    if (rows <= 0 || row_bytes < 16) return hipSuccess;
-    int gx = (int)((row_bytes / 16 + 255) / 256);
-    if (gx > 8) gx = 8;
-    int gy = rows > 2048 ? 2048 : rows;
-    hipLaunchKernelGGL(k_read_ahead, dim3(gx, gy), dim3(256), 0, s, static_cast<const unsigned char*>(src), step_bytes, rows, row_bytes, (unsigned*)nullptr);
-    return hipGetLastError();
-}
-
 hipError_t launch_u8_to_f32(const uint8_t* src, size_t sstep, int rows, int cols, float* dst, size_t dpitch, hipStream_t s)
 {
     int gx = (cols + 255) / 256; if (gx > 16) gx = 16;

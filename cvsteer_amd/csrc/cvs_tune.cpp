@@ -53,8 +53,7 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // Launch configuration: defaults, and the ONLINE comparison of a few alternatives on the caller's own launches.
 //
 // What a basis launch leaves open is the order in which its tiles are dealt to the chip (plain row-major, the XCD-column
-// order, the dynamic tail), the strip height, for launches on new images a pure-read pass in front, and for full G2 setups the
-// grouping of the state planes.  Which combination is fastest depends on the box and -- more -- on the PROCESS, i.e. on where
+// order, the dynamic tail), the strip height, and for full G2 setups the grouping of the state planes.  Which combination is fastest depends on the box and -- more -- on the PROCESS, i.e. on where
 // the allocator put the planes, so a short list (at most four) is compared where the code runs.  NOTHING extra is launched:
 // while a key is undecided each of the caller's own calls runs one candidate, bracketed by a pair of events on the caller's
 // stream; candidates take turns in blocks of kBlock consecutive calls (the first call of a block is not counted: a
@@ -77,9 +76,8 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // ---------------------------------------------------------------------------------------------------------------------
 struct Cand {
     int order, strip;
-    int ahead = 0;   // launches on new images: a pure-read pass over the image first (cvs_kernels_point.hip k_read_ahead)
     int merge = 0;   // G2 launches that write orientation planes: one 12-plane group instead of basis | orientation (cvs_handle.cpp layout_state)
-    bool operator==(const Cand& o) const { return order == o.order && strip == o.strip && merge == o.merge && ahead == o.ahead; }
+    bool operator==(const Cand& o) const { return order == o.order && strip == o.strip && merge == o.merge; }
 };
 
 struct TuneEntry {
@@ -115,7 +113,6 @@ static void apply(BasisArgs& a, const Cand& c)
     a.block_order = c.order;
     a.strip_rows = c.strip;
     a.merge_orient = c.merge;
-    a.read_ahead = c.ahead;
 }
 
 // a configuration decided for the bucket must fit THIS launch
@@ -191,8 +188,7 @@ static void evaluate(TuneEntry& e)
         if (env_opts().verbose) {
             std::fprintf(stderr, "[cvsteer] tuned on the caller's launches (ns/pix median x samples):");
             for (size_t c = 0; c < e.cand.size(); ++c)
-                std::fprintf(stderr, " (order %d, strip %d, merged %d, read-ahead %d%s) %.5f x%zu", e.cand[c].order, e.cand[c].strip,
-                             e.cand[c].merge, e.cand[c].ahead, e.dropped[c] ? ", dropped" : "", e.samples[c].empty() ? 0.f : median_of(e.samples[c]), e.samples[c].size());
+                std::fprintf(stderr, " (order %d, strip %d, merged %d%s) %.5f x%zu", e.cand[c].order, e.cand[c].strip, e.cand[c].merge, e.dropped[c] ? ", dropped" : "", e.samples[c].empty() ? 0.f : median_of(e.samples[c]), e.samples[c].size());
             std::fprintf(stderr, " -> candidate %d after %d rounds\n", decision, e.round);
         }
     }
@@ -274,19 +270,12 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     };
     const int nt = 2 * h->width + 1, halo = 2 * h->width;
     const int sr_short = 2 * nt - halo, sr_tall = 3 * nt - halo;
-    const size_t in_bytes = (size_t)a.rows * a.cols * (a.in_u8 ? 1 : sizeof(float));
-    const bool ahead_ok = fresh_input && a.batch == 0 && in_bytes >= ((size_t)4 << 20) && in_bytes <= ((size_t)128 << 20) && env_opts().read_ahead != 0;
     if (h->kind == CVS_KIND_G2) {
         if (fresh_input) {
             // a stream of new images: short strips are a must (the halo rows of vertically adjacent strips only hit in cache when
             // those strips run close in time); the plain order, the XCD-column order and the dynamic tail are within 1 % of each
-            // other in sustained runs.  The one candidate worth 3-5 % here is a pure-read pass over the image in front of the
-            // launch (where the image really comes from HBM; where the previous kernel made it, it loses its 5-12 us and is dropped).
-            if (ahead_ok) {
-                Cand m = def;
-                m.ahead = 1;
-                e.cand.push_back(m);
-            }
+            // other in sustained runs on large images, so only smaller ones compare them.  (Rounds 4 also offered a pure-read pass
+            // over the image in front of the launch; the first waves of the launch do that themselves now: BasisArgs::warm_k.)
             if ((size_t)a.rows * a.cols < ((size_t)8 << 20)) {
                 add({kOrderDynamic, sr_short});
                 add({kOrderXcdColumns, sr_short});
@@ -309,11 +298,6 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     } else {
         // G4: the dynamic tail (+6 % on one box, level on the others)
         add({kOrderDynamic, def.strip});
-        if (ahead_ok && e.cand.size() < 4) {
-            Cand m = def;
-            m.ahead = 1;
-            e.cand.push_back(m);
-        }
     }
     // G2 launches that write the orientation planes too (full setup, pipeline), row-interleaved state, single image: the two
     // leading configurations with ALL twelve planes in one group -- steadier (0.81-0.82 for the full setup in every process)
@@ -432,7 +416,7 @@ void note_launch(cvs_handle h, const BasisArgs& a)
     h->last.block_order = a.block_order;
     h->last.strip_rows = a.strip_rows;
     h->last.nt_stores = a.nt_stores;
-    h->last.read_ahead = a.read_ahead;
+    h->last.warm = a.warm_k;
     h->last.tuning_launches = 0;   // nothing is ever launched beyond the caller's own calls
 }
 

@@ -73,7 +73,7 @@ enum {
 };
 
 /* options for cvs_set_option.  Process-wide overrides for new handles (A/B aids): the environment variable
- * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2, pyr_strip=0|1, batch_ways=N, read_ahead=0|1,
+ * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2, pyr_strip=0|1, batch_ways=N, warm=K (0 = off),
  * nt_stores=0|1 (output stores plain / nontemporal instead of by size), verbose=1 (the tuner prints its decisions to stderr),
  * pool_mb=N (state-block cache, default 4096, 0 = off).  Read at every call; results never depend on any of them. */
 enum {
@@ -174,8 +174,9 @@ typedef struct cvs_launch_info {
     int32_t nt_stores;        /* ... 1 = streaming (nontemporal) stores */
     int32_t state_layout;     /* layout of the current state block: 0 = planar, 1 = row-interleaved groups (CVS_OPT_STATE_LAYOUT),
                                  2 = row-interleaved with the G2 orientation planes in the basis planes' group (the tuner's choice) */
-    int32_t read_ahead;       /* last basis launch: 1 = a pure-read pass over the image ran in front of it (a tuner candidate for
-                                 launches on new images: the image then comes out of the Infinity Cache) */
+    int32_t warm;             /* last basis launch: K > 0 = the launch took its image for a NEW one (another pointer than the handle's
+                                 previous call) and the waves of its first row bands requested the rest of the image ahead of need,
+                                 K bands each (images of 8 MiB and more); 0 = not */
     int32_t tuning_launches;  /* launches the engine has issued on this handle's stream beyond the caller's own calls: always 0
                                  (configurations are compared on the caller's launches) */
     int32_t tuned;            /* 1 = the configuration above is a challenger the online tuner decided for; 0 = the engine's default */

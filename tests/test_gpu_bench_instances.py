@@ -189,7 +189,7 @@ def test_headline_fused_filter_steer_4096_streaming(cv, ora):
         torch.cuda.synchronize()
         info = f.launch_info()
         assert info["nt_stores"] == 1
-        key = (info["block_order"], info["strip_rows"], info["read_ahead"])
+        key = (info["block_order"], info["strip_rows"], info["warm"])
         if key not in seen:                                             # every configuration the loop passes through
             seen.add(key)
             check(f, ("call", call) + key)

@@ -96,33 +96,65 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     assert len(seen) == 1, seen
 
 
-def test_tuner_candidates_on_new_images_never_change_results(cv):
-    """launches on NEW images (another image every call): the online tuner's candidates there include a pure-read pass over the
-    image in front of the filter launch (cvs_launch_info.read_ahead); whatever runs, every image's outputs are the bits of the
-    tuner-less handle, f32 and 8-bit images"""
+def test_new_images_are_requested_ahead_and_results_do_not_change(cv, monkeypatch):
+    """launches on NEW G2 images (another pointer than the handle's previous call) of 24 MiB and more: the waves of the launch's first
+    row bands also touch the rest of the image (cvs_launch_info.warm = bands per wave; cvs_kernels_basis.hip dma_warm), every
+    variant, order and kind; the same image again is not a new one.  Whatever runs, the outputs are the bits of a handle with
+    CVS_OPTS warm=0, f32 and 8-bit images, ragged sizes, row ranges."""
+    import ctypes as C
     import torch
     from cvsteer_amd import _lib as L
-    n = 2560
     gen = torch.Generator(device="cuda").manual_seed(9)
-    imgs = [torch.rand((n, n), device="cuda", generator=gen) for _ in range(4)]
-    imgs += [(im * 255).to(torch.uint8) for im in imgs[:2]]
-    plain = cv.SteerableFiltersG2(None)
-    plain.set_option(L.OPT_AUTOTUNE, 0)
-    refs = []
-    for im in imgs:
-        g, h = plain.setup_steer(im, 0.3, flags=cv.SETUP_BASIS)
-        refs.append((g.clone(), h.clone(), plain.basis(5).clone()))
-    f = cv.SteerableFiltersG2(None)
-    seen_ahead = set()
-    for it in range(90):
-        k = it % len(imgs)
-        g, h = f.setup_steer(imgs[k], 0.3, flags=cv.SETUP_BASIS)
-        li = f.launch_info()
-        seen_ahead.add(li["read_ahead"])
-        assert li["tuning_launches"] == 0
-        if it % 3 == 0 or li["read_ahead"]:
-            assert torch.equal(g, refs[k][0]) and torch.equal(h, refs[k][1]) and torch.equal(f.basis(5), refs[k][2]), (it, k, li)
-    assert seen_ahead == {0, 1}, seen_ahead      # the read-ahead candidates did take their turns
+    for shape in ((2560, 2560), (1500, 3001), (2100, 3200)):
+        imgs = [torch.rand(shape, device="cuda", generator=gen) for _ in range(3)]
+        imgs += [(im * 255).to(torch.uint8) for im in imgs[:1]]
+        big = shape[0] * shape[1] * 4 >= (24 << 20)
+        monkeypatch.setenv("CVS_OPTS", "warm=0")
+        plain = cv.SteerableFiltersG2(None)
+        plain.set_option(L.OPT_AUTOTUNE, 0)
+        refs = []
+        for im in imgs:
+            g, h = plain.setup_steer(im, 0.3, flags=cv.SETUP_FULL)
+            assert plain.launch_info()["warm"] == 0
+            refs.append([g.clone(), h.clone()] + [plain.basis(p).clone() for p in range(7)] + [plain.getDominantOrientationAngle().clone()] +
+                        [o.clone() for o in plain.pipeline(im)])
+        monkeypatch.delenv("CVS_OPTS")
+        for order in (L.ORDER_PLAIN, L.ORDER_DYNAMIC_TAIL, L.ORDER_XCD_COLUMNS, -1):
+            f = cv.SteerableFiltersG2(None)
+            f.set_option(L.OPT_BLOCK_ORDER, order)
+            for it in range(2 * len(imgs)):
+                k = it % len(imgs)
+                g, h = f.setup_steer(imgs[k], 0.3, flags=cv.SETUP_FULL)
+                li = f.launch_info()
+                u8 = imgs[k].dtype == torch.uint8
+                assert li["warm"] == (4 if big and not u8 else 0), (shape, k, li)     # (the 8-bit images here are below 24 MiB)
+                cur = [g, h] + [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle().clone()] + list(f.pipeline(imgs[k]))
+                for a_, b_ in zip(cur, refs[k]):
+                    assert torch.equal(a_, b_), (shape, order, it)
+            f.setup(imgs[0]); f.setup(imgs[0])
+            assert f.launch_info()["warm"] == 0          # the same image again: resident, nothing to request ahead
+        # forced on where the engine leaves it off (G4: both half banks; the launch that emits the next pyramid level), and a row range
+        f4w, f4p = cv.SteerableFiltersG4(None), cv.SteerableFiltersG4(None)
+        f4p.setup(imgs[1])
+        assert f4p.launch_info()["warm"] == 0
+        monkeypatch.setenv("CVS_OPTS", "warm=3")
+        f4w.setup(imgs[1])
+        fpw = cv.SteerableFiltersG2(None)
+        lvl_w = fpw.setup_pyr(imgs[2], flags=cv.SETUP_BASIS)
+        monkeypatch.delenv("CVS_OPTS")
+        for p in range(11):
+            assert torch.equal(f4w.basis(p), f4p.basis(p)), (shape, p)
+        fpp = cv.SteerableFiltersG2(None)
+        lvl_p = fpp.setup_pyr(imgs[2], flags=cv.SETUP_BASIS)
+        assert fpp.launch_info()["warm"] == 0 and torch.equal(lvl_w, lvl_p) and torch.equal(fpw.basis(4), fpp.basis(4))
+        fr = cv.SteerableFiltersG2(None)
+        fr._like = imgs[2]
+        fr._bind_stream(imgs[2])
+        pl = cv.api._plane(imgs[2])
+        lo, hi = shape[0] // 5, shape[0] - 7
+        fr._check(cv.lib().cvs_setup_rows(fr._h, C.byref(pl), cv.SETUP_BASIS, lo, hi), "cvs_setup_rows")
+        for p in (0, 6):
+            assert torch.equal(fr.basis(p)[lo:hi], refs[2][2 + p][lo:hi]), (shape, p, "rows")
 
 
 def test_objects_come_and_go_without_draining_the_device(cv):
