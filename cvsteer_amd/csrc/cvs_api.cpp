@@ -118,8 +118,9 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     // 0.626 -> 0.744 of the HBM roofline, fused steer on rotating 4096^2 images 0.624 -> 0.716, one object per image 0.614 ->
     // 0.700, full setup 0.624 -> 0.697; a separate read pass in front of the launch (round 4's tuner candidate, removed) reached
     // 0.708 where this reaches 0.729 and cannot serve an 8192^2 image at all.  Not for: the launch that also emits the next pyramid
-    // level (-8 %: its cached half-line stores want the L2 for themselves), G4 and the 20-plane pipeline at the SIMDs' limit
-    // (level), 8-bit and small images (level to -3 %).  CVS_OPTS warm=K overrides K (0 = off).
+    // level (-8 %: its cached half-line stores want the L2 for themselves; with streaming stores for the level the launch gains
+    // 13 % and the next level's launch, which then reads its image from HBM, loses more: config 3 0.658 -> 0.640), G4 and the
+    // 20-plane pipeline at the SIMDs' limit (level), 8-bit and small images (level to -3 %).  CVS_OPTS warm=K overrides K (0 = off).
     {
         const size_t in_bytes = (size_t)a.rows * a.cols * (a.in_u8 ? 1 : sizeof(float));
         const int wk = env_opts().warm;
