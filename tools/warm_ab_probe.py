@@ -41,9 +41,38 @@ def lvl0m1():
     flip[0] ^= 1
     hp[0].setup(bigs[flip[0]], flags=cv.SETUP_BASIS)
 ab("   M1 on alternating 8192^2 images", lvl0m1, 32 * 8192 * 8192, 10)
-os.environ["CVS_WARM_PYR"] = "1"
-ab("C3 with the level launch warmed too (nt level stores)", pyr, 32 * ppix + 4 * (ppix - 8192 * 8192), 10)
-ab("   level 0 alone, warmed too", lvl0, 33 * 8192 * 8192, 10)
-os.environ["CVS_WARM_PYR"] = "2"
-ab("C3, every level's image taken for new", pyr, 32 * ppix + 4 * (ppix - 8192 * 8192), 10)
-sys.exit(0)
+del bigs, lv, hp, fp3
+n = 4096
+imgs = [torch.rand((n, n), device=dev) for _ in range(8)]
+g, h = cv.alloc_planes(2, n, n, device=dev)
+k = [0]
+def objs():
+    k[0] = (k[0] + 1) & 7
+    fo = cv.SteerableFiltersG2(None, 4, 0.67)
+    fo.setup_steer(imgs[k[0]], 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+    del fo
+ab("M2 one object per image (8 images)", objs, 40 * n * n, 48)
+f = cv.SteerableFiltersG2(None, 4, 0.67)
+def rot():
+    k[0] = (k[0] + 1) & 7
+    f.setup_steer(imgs[k[0]], 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+ab("M2 rotating 8 images, one handle", rot, 40 * n * n, 24)
+outs8 = cv.alloc_planes(8, n, n, device=dev)
+def pipe():
+    k[0] = (k[0] + 1) & 7
+    f.pipeline(imgs[k[0]], out=outs8)
+ab("M5 pipeline on rotating images", pipe, 84 * n * n, 16)
+def full():
+    k[0] = (k[0] + 1) & 7
+    f.setup(imgs[k[0]], flags=cv.SETUP_FULL)
+ab("M4 full setup on rotating images", full, 52 * n * n, 24)
+f4 = cv.SteerableFiltersG4(None, 6, 0.5)
+def g4():
+    k[0] = (k[0] + 1) & 7
+    f4.setup(imgs[k[0]])
+ab("M6 G4 basis on rotating images", g4, 48 * n * n, 16)
+u8 = [(im * 255).to(torch.uint8) for im in imgs]
+def rot8():
+    k[0] = (k[0] + 1) & 7
+    f.setup_steer(u8[k[0]], 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+ab("M2 rotating 8-bit images (16 MiB each)", rot8, 37 * n * n, 24)
