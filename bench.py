@@ -499,7 +499,7 @@ def main():
                         if legs:
                             snap["legs_fmt"] = "[frac_hbm, ms, ms_min, ms_max, launch_configs index, frac_valu]"
                             snap["legs"] = dict(legs)
-                            snap["launch_configs_fmt"] = "[block_order, strip_rows, nt_stores, state_layout, warm, tuned]"
+                            snap["launch_configs_fmt"] = "[block_order, strip_rows, nt_stores, state_layout, warm, wg_per_cu, tuned]"
                             snap["launch_configs"] = list(configs)
                         if not final:
                             snap["extra_error"] = why or "incomplete"
@@ -522,7 +522,7 @@ def main():
 
     def cfg_index(handle):
         li = handle.launch_info()
-        c = [li["block_order"], li["strip_rows"], li["nt_stores"], li["state_layout"], li["warm"], li["tuned"]]
+        c = [li["block_order"], li["strip_rows"], li["nt_stores"], li["state_layout"], li["warm"], li["wg_per_cu"], li["tuned"]]
         if c not in configs:
             configs.append(c)
         return configs.index(c)
@@ -873,7 +873,7 @@ def main():
                 if ws > 1 and distinct and nbat.transport != "rccl":
                     raise RuntimeError("%d ranks on distinct GPUs but the batch layer chose transport %r -- a rehearsal transport must "
                                        "never carry a real multi-GPU run" % (ws, nbat.transport))
-                rf["transport"] = nbat.transport
+                rf["transport"] = nbat.transport if ws > 1 else nbat.transport + " (one-rank world: plumbing only)"
                 nbat.set_persist(False)
                 e2e_out = torch.empty((n_all, 3) + shape, device=dev) if rank == 0 else None
                 reps, acc, wall_e2e = 5, {"scatter": 0.0, "compute": 0.0, "gather": 0.0}, 0.0

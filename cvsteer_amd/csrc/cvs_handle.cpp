@@ -25,7 +25,7 @@
 
 namespace cvs {
 
-// CVS_OPTS="autotune=0,layout=1,pyr_strip=1,batch_ways=2,warm=4,nt_stores=1,verbose=1,pool_mb=4096": the one documented
+// CVS_OPTS="autotune=0,layout=1,pyr_strip=1,batch_ways=2,warm=4,wgcap=3,nt_stores=1,verbose=1,pool_mb=4096": the one documented
 // environment hook (A/B aids for new handles; unknown names are reported once on stderr and ignored)
 EnvOpts env_opts()
 {
@@ -54,6 +54,7 @@ EnvOpts env_opts()
         else if (name == "batch_ways") v.batch_ways = (int)std::max(1L, val);
         else if (name == "nt_stores") v.nt_stores = val != 0;
         else if (name == "warm") v.warm = (int)std::max(0L, std::min(16L, val));
+        else if (name == "wgcap") v.wgcap = (int)std::max(0L, std::min(8L, val));
         else if (name == "verbose") v.verbose = val != 0;
         else if (name == "pool_mb") v.pool_mb = val;
         else std::fprintf(stderr, "[cvsteer] CVS_OPTS: unknown name '%s' ignored\n", name.c_str());

@@ -51,6 +51,8 @@ struct BasisArgs {
     size_t steer_h_pitch;
     float steer_w[kMaxBasis];  // scalar steering weights (host-computed)
     int strip_rows;       // output rows per wave strip
+    int wg_per_cu;        // host only: at most this many workgroups per CU (0 = whatever registers and LDS allow); the launcher turns it into
+                          // dynamic LDS no kernel touches (cvs_tune.cpp default_config says where and why)
     int atan_mode;
     int nt_stores;        // 1 = nontemporal (streaming) output stores
     int warm_k;           // new images (set by the API layer; 0 = off): the waves of the launch's first row bands also touch the rows of warm_k

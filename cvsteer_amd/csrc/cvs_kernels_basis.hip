@@ -965,13 +965,20 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
     // which honours row_lo / row_hi / row_base
     const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;
     const bool one = !banded && a.state_bytes > 0 && a.state_bytes <= kMaxPlaneBytes;
+    // BasisArgs::wg_per_cu: the launch asks for more LDS than it uses, so that at most that many workgroups share a CU (see cvs_tune.cpp)
+    unsigned lds_pad = 0;
+    if (a.wg_per_cu > 0 && a.wg_per_cu < 8) {
+        constexpr unsigned kLds = 160u << 10, kStatic = (unsigned)(wpb * (2 * B::W + 2) * kRingLine * sizeof(float) + 64);
+        const unsigned n = (unsigned)a.wg_per_cu, want = (kLds / n + kLds / (n + 1)) / 2;   // N fit, N + 1 do not: the middle of that interval
+        lds_pad = want > kStatic ? want - kStatic : 0;
+    }
 #define CVS_LAUNCH_K(...)                                                                  \
     do {                                                                                   \
         if (dyn) {                                                                         \
             a.dyn_nz = (int)grid.z;                                                        \
             grid = dim3(dynamic_blocks((size_t)a.grid_x * a.grid_y * grid.z, &a.dyn_static), 1, 1); \
         }                                                                                  \
-        hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, s, a, f);         \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, lds_pad, s, a, f);         \
     } while (0)
 #define CVS_LAUNCH_U(FL, BATCHED, WP, U)                                                   \
     do {                                                                                   \

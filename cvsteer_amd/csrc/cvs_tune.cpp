@@ -239,8 +239,21 @@ static hipEvent_t take_event(int device)   // the caller has made `device` curre
 }
 
 // the engine's default configuration for this launch; true = the launch is of a kind whose alternatives are worth comparing
-static bool default_config(cvs_handle h, BasisArgs& a)
+static bool default_config(cvs_handle h, BasisArgs& a, int variant)
 {
+    // Workgroups per CU.  Since the input rows go straight into LDS (round 5) the G2 kernels need 80-93 VGPRs and five to six
+    // workgroups share a CU; every resident wave is one more write front in HBM, and two launches stream faster with fewer
+    // (three processes on one box, profiles/r05_occupancy_cap.txt): the fused steer at three per CU (0.798 -> 0.842 on a resident
+    // 4096^2 image, 0.72 -> 0.758 on new ones, in every process; level at 8192^2) and the 20-plane pipeline at four (+1-4 %).
+    // The basis pass loses with any cap, the full setup gains 6 % or loses 3 % depending on where its plane groups lie (left
+    // alone), G4 does not care.  CVS_OPTS wgcap=N overrides (0 = none).
+    const size_t npix_cfg = (size_t)a.rows * a.cols;
+    a.wg_per_cu = 0;
+    if (h->kind == CVS_KIND_G2 && a.batch == 0 && npix_cfg >= ((size_t)2 << 20) && npix_cfg < ((size_t)32 << 20)) {
+        if (variant == 2) a.wg_per_cu = 3;
+        else if (variant == 5) a.wg_per_cu = 4;
+    }
+    if (const int forced = env_opts().wgcap; forced >= 0) a.wg_per_cu = forced;
     // CVS_OPT_STATE_LAYOUT = 2 pins the grouping: launches that write orientation planes use ONE group of twelve planes
     a.merge_orient = (h->layout == 2 && h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0) ? 1 : 0;
     const bool fast = basis_fast_path(h->kind, h->width, h->taps);
@@ -323,7 +336,7 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     tok = TuneToken();
     h->last.tuned = 0;
     h->last.tune_state = 0;
-    const bool tunable = default_config(h, a);
+    const bool tunable = default_config(h, a, variant);
     if (!tunable || !h->autotune) return CVS_OK;
     if (h->block_order >= 0 && h->strip_rows > 0) return CVS_OK;   // everything pinned
     const int pins = (h->strip_rows > 0 ? 2 : 0) + (h->last.state_layout ? 4 : 0) + (h->layout << 3) + ((h->block_order + 1) ? 32 : 0);
@@ -417,6 +430,7 @@ void note_launch(cvs_handle h, const BasisArgs& a)
     h->last.strip_rows = a.strip_rows;
     h->last.nt_stores = a.nt_stores;
     h->last.warm = a.warm_k;
+    h->last.wg_per_cu = a.wg_per_cu;
     h->last.tuning_launches = 0;   // nothing is ever launched beyond the caller's own calls
 }
 

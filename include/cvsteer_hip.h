@@ -73,7 +73,7 @@ enum {
 };
 
 /* options for cvs_set_option.  Process-wide overrides for new handles (A/B aids): the environment variable
- * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2, pyr_strip=0|1, batch_ways=N, warm=K (0 = off),
+ * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2, pyr_strip=0|1, batch_ways=N, warm=K (0 = off), wgcap=N (workgroups per CU, 0 = no cap),
  * nt_stores=0|1 (output stores plain / nontemporal instead of by size), verbose=1 (the tuner prints its decisions to stderr),
  * pool_mb=N (state-block cache, default 4096, 0 = off).  Read at every call; results never depend on any of them. */
 enum {
@@ -182,6 +182,8 @@ typedef struct cvs_launch_info {
     int32_t tuned;            /* 1 = the configuration above is a challenger the online tuner decided for; 0 = the engine's default */
     int32_t tune_state;       /* the online tuner for this launch's key: 0 = off / not a tunable launch, 1 = still comparing on the
                                  caller's launches, 2 = decided */
+    int32_t wg_per_cu;        /* last basis launch: workgroups per CU it was held to (the fused steer 3, the caller pipeline 4 on single G2
+                                 images of 2-32 Mpix: fewer write fronts); 0 = no cap */
 } cvs_launch_info;
 int cvs_get_launch_info(cvs_handle h, cvs_launch_info* out);
 /* the handle's idx-th tap vector (m_g1.. members), 2*width+1 floats */

@@ -477,7 +477,7 @@ def test_bench_starts_its_own_ranks_and_watchdog_emits_the_headline(tmp_path):
     assert all(not isinstance(v, (dict, list)) for v in d["config"].values()) and all(not isinstance(v, (dict, list)) for v in d["cpu_baseline"].values())
     assert 0 < rf["m1_frac"] < 1.2 and rf["m1_ms_min"] <= rf["m1_ms"] <= rf["m1_ms_max"]      # north_star's own target, inside the kept dict
     cfg = d["launch_configs"][d["config"]["launch_config"]]
-    assert cfg[3] == 1 and len(cfg) == 6                                                        # row-interleaved state
+    assert cfg[3] == 1 and len(cfg) == 7 and cfg[5] == 3                                        # row-interleaved state; the fused steer at three workgroups per CU
     assert d["legs"]["M1_basis"][0] == rf["m1_frac"]
     assert rf["rccl_ranks"] == 0 and d["config"]["distinct_devices"] is False                 # rehearsal on one GPU
     assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"        # rank 0 measures it for N > 1 as well
