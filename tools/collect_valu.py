@@ -13,8 +13,9 @@ def rows(sub):
         out += [r for r in csv.DictReader(open(fn)) if r["Counter_Name"] == "SQ_INSTS_VALU"]
     return out
 cal = [float(r["Counter_Value"]) for r in rows("pmc_valu_cal") if "k<false>" in r["Kernel_Name"] or "ILb0E" in r["Kernel_Name"]]
-# tools/valu_rate.hip k<false>: 2048 workgroups x 4 waves, 4096 iterations x 16 v_fma_f32 per wave (+ ~60 instructions of set-up and the final sum)
-known = 2048 * 4 * (4096 * 16 + 60)
+# tools/valu_rate.hip k<false> as tools/profile_all_r05.sh builds it (-O3 without -fno-slp-vectorize): the 16 fmaf of an iteration are packed
+# into 8 v_pk_fma_f32 (checked in the ISA): 2048 workgroups x 4 waves, 4096 iterations x 8 vector instructions per wave (+ ~60 of set-up / final sum)
+known = 2048 * 4 * (4096 * 8 + 60)
 factor = known / (sum(cal) / len(cal)) if cal else 1.0
 pix4096, pixc4 = 4096 * 4096, 32 * 1080 * 1920
 legs = {"M1": ("k_basis<cvs::BankG2, 0, true, 0, true", pix4096), "M2": ("k_basis<cvs::BankG2, 2, true, 0, true", pix4096),

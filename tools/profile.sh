@@ -17,7 +17,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stat
 echo "stats rc=$?" >> $O/prof_stats.log
 # (since round 4 the headline IS the library's default allocation: no separate plain-block pass)
 [ -x tools/membench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o tools/membench > $O/membench_build.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_all -- python3 bench.py --no-live-traffic --steps 50 --warmup 5 --repeats 3 --leg-repeats 1 --no-cpu > $O/prof_stats_all.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_all -- python3 bench.py --all-legs --no-live-traffic --steps 50 --warmup 5 --repeats 3 --leg-repeats 1 --no-cpu > $O/prof_stats_all.log 2>&1
 # (counter passes: the library's default, a plain state block -- few launches in all, the probe's would be among them)
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python3 bench.py --no-live-traffic --steps 5 --warmup 3 --repeats 1 --lead-ms 2 --no-cpu --no-extra > $O/pmc_$C.log 2>&1
