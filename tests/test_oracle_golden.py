@@ -321,7 +321,7 @@ def test_every_timed_kernel_instance_has_a_parity_test():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     mapping = json.load(open(os.path.join(root, "tests", "golden", "timed_instances.json")))
-    timed = [r[0] for r in csv.reader(open(os.path.join(root, "profiles", "r03_kernel_stats_all_legs.csv"))) if r and r[0].startswith("cvs::")]
+    timed = [r[0] for r in csv.reader(open(os.path.join(root, "profiles", "r05_kernel_stats_all_legs.csv"))) if r and r[0].startswith("cvs::")]
     assert len(timed) >= 12
     for name in timed:
         key = name.split("(unsigned char")[0]
