@@ -534,8 +534,10 @@ def main():
             n = MAX_SETTLE_CALLS if handle is not None else 8
         for i in range(n):
             fn()
-            if handle is not None and i >= 3 and i % 4 == 3 and handle.launch_info()["tune_state"] != 1:
-                break
+            if handle is not None and i % 5 == 4:
+                torch.cuda.synchronize()     # the tuner reads its samples back when their launches have finished, never by waiting
+                if handle.launch_info()["tune_state"] != 1:
+                    break
         torch.cuda.synchronize()
 
     # ---- start-up self-test of the transport (runs of several ranks on distinct GPUs): one 1080p frame per rank through the

@@ -2,7 +2,7 @@
 """tools/fuzz_campaign.py [iterations] [seed] -- a long randomised differential run of the HIP path against the oracle, beyond
 what the test suite can afford every time: random kind, shape (1 x 1 ... 400 x 900, biased towards the fast / generic path
 boundaries and multiples of 64), device or host planes, strided (ROI) inputs and outputs, launch options (strip height, block
-order, XCD weights, store policy, G4 layout, persist), entry points (setup flags, fused steer, pipeline, batch with random
+order, persist; CVS_OPTS store policy, warm, workgroups per CU), entry points (setup flags, fused steer, pipeline, batch with random
 frame counts and dispatch parts, row ranges), non-finite pixels.  Prints one line per failure with everything needed to replay
 it, and a summary.  Nothing here is timed."""
 import os, sys, traceback
@@ -89,13 +89,15 @@ for it in range(iters):
     if rng.integers(0, 2):
         opts[L.OPT_STRIP_ROWS] = int(rng.choice([1, 5, 10, 19, 28, 37, 64, 131]))
     if rng.integers(0, 2):
-        opts[L.OPT_BLOCK_ORDER] = int(rng.choice([0, 1, 2, 3, 8, 1000, 1000000, 1000000, 2000000, 2000000]))   # 1000000 = every XCD on its own column blocks, 2000000 = dynamic tail
-    if rng.integers(0, 3) == 0:
-        opts[L.OPT_XCD_WEIGHTS] = int(rng.choice([403, 504, 101, 302, 706, 1601, 116]))
+        opts[L.OPT_BLOCK_ORDER] = int(rng.choice([0, 1000000, 1000000, 2000000, 2000000]))   # 1000000 = every XCD on its own column blocks, 2000000 = dynamic tail
+    env = []                                                   # CVS_OPTS (read at every call): store policy, requesting new images ahead, workgroups per CU
     if rng.integers(0, 2):
-        opts[L.OPT_STORE_POLICY] = int(rng.choice([0, 1, 2]))
-    if kind == 4 and rng.integers(0, 2):
-        opts[L.OPT_G4_SPLIT] = int(rng.integers(0, 3))
+        env.append("nt_stores=%d" % int(rng.integers(0, 2)))
+    if rng.integers(0, 2):
+        env.append("warm=%d" % int(rng.choice([0, 1, 3, 4, 9])))
+    if rng.integers(0, 3) == 0:
+        env.append("wgcap=%d" % int(rng.integers(0, 6)))
+    os.environ["CVS_OPTS"] = ",".join(env)
     if rng.integers(0, 2):
         opts[L.OPT_STATE_LAYOUT] = int(rng.integers(0, 3))    # planar / row-interleaved groups / one merged group (round 4)
     if rng.integers(0, 4) == 0:
@@ -110,7 +112,7 @@ for it in range(iters):
     if as_u8:   # 8-bit image (what the reference's callers hold): read as bytes inside the filter kernel, widened unscaled
         img = np.floor(rng.random((rows, cols)) * 256.0).clip(0, 255).astype(np.float32)
         scale = 255.0
-    desc = dict(it=it, seed=seed, nonfinite=nonfinite, kind=kind, rows=rows, cols=cols, device=device, strided=strided, opts=opts, entry=entry, theta=round(theta, 4))
+    desc = dict(it=it, seed=seed, nonfinite=nonfinite, kind=kind, rows=rows, cols=cols, device=device, strided=strided, opts=opts, env=os.environ.get("CVS_OPTS", ""), entry=entry, theta=round(theta, 4))
     try:
         w, s = (4, 0.67) if kind == 2 else (6, 0.5)
         if custom:
@@ -202,14 +204,14 @@ for it in range(iters):
         elif entry == "batch":
             n = int(rng.integers(1, 9))
             ways = int(rng.integers(1, 5))
-            os.environ["CVS_BATCH_WAYS"] = str(ways)
+            os.environ["CVS_OPTS"] = ",".join(env + ["batch_ways=%d" % ways])
             frames = np.stack([make_image(rows, cols) for _ in range(n)])
             persist = bool(rng.integers(0, 2))
             f.set_persist(persist)
             fx = torch.from_numpy(frames).cuda() if device else frames
             sel = None if persist else (5, 6, 7)
             out = f.pipeline_batch(fx, outputs=sel)
-            os.environ.pop("CVS_BATCH_WAYS", None)
+            os.environ["CVS_OPTS"] = ",".join(env)
             for i in range(n):
                 single = cv.SteerableFiltersG2(None).pipeline(fx[i])
                 for j, k in enumerate(range(8) if sel is None else sel):
@@ -220,8 +222,7 @@ for it in range(iters):
                 kind = 2
                 f = cv.SteerableFiltersG2(None)
                 for o, v in opts.items():
-                    if o != L.OPT_G4_SPLIT:
-                        f.set_option(o, v)
+                    f.set_option(o, v)
                 nb, truth = 7, ora.basis(2, img, 4, 0.67, f64=True)
             want = ora.pyr_down(img)
             down = f.pyrDown(x)

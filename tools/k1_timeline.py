@@ -18,7 +18,6 @@ img = torch.rand((n, n), device="cuda")
 f = cv.SteerableFiltersG2(None)
 f.set_strip_rows(sr)
 f.set_option(L.OPT_BLOCK_ORDER, order)
-f.set_option(L.OPT_XCD_WEIGHTS, xw)
 lib = cv.lib()
 lib.cvs_diag_set_buffer.argtypes = [C.c_void_p, C.c_void_p]
 bands = (n + sr - 1) // sr

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""tools/tuner_value_probe.py -- what the online tuner's decision is worth on the SAME handle (same state block): every leg settles
-with the tuner on, then tuner-on and tuner-off (CVS_OPT_AUTOTUNE 0 = the engine's default configuration) take turns, sustained
-launches.  PROBE_HANDLES handles per process."""
+"""tools/tuner_value_probe.py -- what the online tuner's decision is worth on the SAME handle (same state block): every leg calls until
+the tuner has decided (cvs_launch_info.tune_state), then tuner-on and tuner-off (CVS_OPT_AUTOTUNE 0 = the engine's default configuration)
+take turns, sustained launches of 150.  Run it in many processes (the tuner's memory is per process): a pick that is more than 1 %
+slower sustained than the default is a wrong decision.  PROBE_HANDLES handles per process (the later ones inherit the decisions)."""
 import os, sys, statistics
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -27,12 +28,20 @@ def timeit(fn, steps=150):
 
 for hi in range(int(os.environ.get("PROBE_HANDLES", "3"))):
     f = cv.SteerableFiltersG2(None)
-    legs = (("M1", 32, lambda: f.setup(img, flags=cv.SETUP_BASIS)), ("M2", 40, lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))),
-            ("M4", 52, lambda: f.setup(img, flags=cv.SETUP_FULL)), ("M5", 84, lambda: f.pipeline(img, out=outs)))
-    for name, bpp, fn in legs:
+    f4 = cv.SteerableFiltersG4(None)
+    small = img[:1536, :2048].contiguous()
+    legs = (("M4", 52, n * n, f, lambda: f.setup(img, flags=cv.SETUP_FULL)), ("M5", 84, n * n, f, lambda: f.pipeline(img, out=outs)),
+            ("G4", 48, n * n, f4, lambda: f4.setup(img)), ("M4 1536x2048", 52, 1536 * 2048, f, lambda: f.setup(small, flags=cv.SETUP_FULL)))
+    for name, bpp, npx, f, fn in legs:
         f.set_option(L.OPT_AUTOTUNE, 1)
-        for _ in range(100):
-            fn()
+        calls = 0
+        for _ in range(60):          # the tuner says when it has decided
+            for _ in range(5):
+                fn()
+            calls += 5
+            torch.cuda.synchronize()     # (the tuner reads its samples back when their launches have finished, never by waiting)
+            if f.launch_info()["tune_state"] != 1:
+                break
         torch.cuda.synchronize()
         li = f.launch_info()
         res = {1: [], 0: []}
@@ -41,7 +50,7 @@ for hi in range(int(os.environ.get("PROBE_HANDLES", "3"))):
                 f.set_option(L.OPT_AUTOTUNE, mode)
                 fn(); fn()
                 res[mode].append(timeit(fn))
-        a, b = (bpp * n * n / (statistics.median(res[m]) * 1e-3) / 8e12 for m in (1, 0))
-        print("handle %d %s  tuned %.3f | default %.3f  (%+.1f %%)   kept: order %d xcd %d strip %d layout %d wg/cu %d" %
-              (hi, name, a, b, 100 * (a / b - 1), li["block_order"], li["xcd_weights"], li["strip_rows"], li["state_layout"], li["wg_per_cu"]), flush=True)
-    del f
+        a, b = (bpp * npx / (statistics.median(res[m]) * 1e-3) / 8e12 for m in (1, 0))
+        print("handle %d %-13s tuned %.3f | default %.3f  (%+.1f %%)  decided after %3d calls (state %d): challenger kept %d -- order %d strip %d layout %d" %
+              (hi, name, a, b, 100 * (a / b - 1), calls, li["tune_state"], li["tuned"], li["block_order"], li["strip_rows"], li["state_layout"]), flush=True)
+    del f, f4
