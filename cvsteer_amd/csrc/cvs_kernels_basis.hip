@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "cvs_device_math.h"
 #include "cvs_internal.h"
@@ -44,6 +45,24 @@ namespace cvs {
 // filter-bank descriptors: which distinct 1-D kernels exist and which (row, column) pair
 // makes each basis plane.  Kernel ids: [0, NE) even (mirror), [NE, NE+NO) odd (anti-mirror).
 // ---------------------------------------------------------------------------------------
+// Packed f32.  A wave64 f32 vector instruction occupies its SIMD for FOUR cycles on this GPU, a packed one (v_pk_fma_f32,
+// v_pk_add_f32, v_pk_mul_f32: two f32 results per lane) for four as well (tools/valu_rate.hip: 566 G plain / 536 G packed wave
+// instructions per second chip-wide, profiles/r05_valu_rate.txt), and the strip kernels issue 70-100 % of what the SIMDs take.
+// So the two passes work on PAIRS: an even (mirror) and an odd (anti-mirror) 1-D kernel side by side in the two halves of a
+// register pair.
+//   row pass     {s[W+i], s[W-i]} -> {sum_i, dif_i} in one v_pk_add_f32 (neg_hi on the second operand); row pair k accumulates
+//                {even kernel te(k), odd kernel to(k)} with tap pairs from SGPR pairs -- one v_pk_fma_f32 per tap index;
+//   window       f2 per row pair and slot;
+//   column pass  a PLANE pair (lo, hi) whose row kernels are a row pair takes its column taps from a tap table as well (halves
+//                swapped by op_sel where the lo plane's column kernel is the odd one): W v_pk_add_f32 (+ / - per half by
+//                neg_lo / neg_hi), W packed multiply-adds, and ONE plain fma for the centre tap of the even half (the odd column
+//                kernel has no centre term in the reference's folded column filter; the row filter has, +0.0).
+// Per result the operations and their order are those of the plain form (an fma is an fma): results are bit-identical.
+// Planes and kernels left over (G2: g2c; G4 G bank: g4c and its row kernel G45) stay on plain instructions.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct PairOp { int lo, hi, w, t; bool swap; };   // basis planes (bank-local) in the lo / hi half, window pair, tap table; swap: lo plane's column kernel = the table's odd one
+struct SingleOp { int plane, w, t; };             // w >= 0: lo half of window pair w, else single window -1-w; t >= 0: even kernel of table t, else single taps -1-t
+
 struct BankG2 {  // SteerableFiltersG2.cpp:62-68
     static constexpr int KIND = 2, W = 4, NE = 3, NO = 3, NB = 7;
     static constexpr int MIN_WAVES = 1;  // waves per SIMD the register allocator must leave room for (1 = unconstrained)
@@ -59,6 +78,13 @@ struct BankG2 {  // SteerableFiltersG2.cpp:62-68
     // on per variant in basis_body for the basis / orientation / fused-steer launches (FLAGS 0..3)
     static constexpr bool VOFF = false;
     static constexpr bool SRED = false;
+    // packed arithmetic (see "Packed f32" below): tap tables (even, odd), the first NRP of them are the row pairs = window pairs
+    static constexpr int NTP = 4, NRP = 3, NS = 0, NPP = 3, NSP = 1;
+    static constexpr int te(int m) { constexpr int t[NTP] = {0, 1, 2, 1}; return t[m]; }
+    static constexpr int to(int m) { constexpr int t[NTP] = {0, 1, 2, 0}; return t[m]; }
+    static constexpr int se(int) { return 0; }
+    static constexpr PairOp pp(int q) { constexpr PairOp t[NPP] = {{6, 3, 1, 1, true}, {4, 5, 2, 2, true}, {0, 1, 0, 3, false}}; return t[q]; }
+    static constexpr SingleOp sp(int q) { constexpr SingleOp t[NSP] = {{2, 1, 0}}; return t[q]; }
 };
 
 // The 11-plane G4 bank as ONE kernel needs a 10 x 13 register window (158 VGPRs with the LDS-DMA input path, three waves per
@@ -80,6 +106,12 @@ struct BankG4G {  // planes g4a..g4e, SteerableFiltersG4.cpp:69-73
     // have the registers to spare (131 -> 137 VGPRs, still three waves per SIMD) and are sensitive to the scalar unit
     static constexpr bool VOFF = true;
     static constexpr bool SRED = true;
+    static constexpr int NTP = 2, NRP = 2, NS = 1, NPP = 2, NSP = 1;
+    static constexpr int te(int m) { constexpr int t[NTP] = {0, 1}; return t[m]; }
+    static constexpr int to(int m) { constexpr int t[NTP] = {0, 1}; return t[m]; }
+    static constexpr int se(int) { return 2; }   // G45: row and column kernel of g4c, in no pair
+    static constexpr PairOp pp(int q) { constexpr PairOp t[NPP] = {{0, 1, 0, 1, false}, {4, 3, 1, 0, false}}; return t[q]; }
+    static constexpr SingleOp sp(int q) { constexpr SingleOp t[NSP] = {{2, -1, -1}}; return t[q]; }
 };
 
 struct BankG4H {  // planes h4a..h4f, SteerableFiltersG4.cpp:75-80
@@ -94,14 +126,109 @@ struct BankG4H {  // planes h4a..h4f, SteerableFiltersG4.cpp:75-80
     static constexpr int PLANE0 = 5, HALF = 2;
     static constexpr bool VOFF = true;
     static constexpr bool SRED = true;
+    static constexpr int NTP = 3, NRP = 3, NS = 0, NPP = 3, NSP = 0;
+    static constexpr int te(int m) { return m; }
+    static constexpr int to(int m) { return m; }
+    static constexpr int se(int) { return 0; }
+    static constexpr PairOp pp(int q) { constexpr PairOp t[NPP] = {{5, 0, 0, 0, true}, {1, 4, 1, 1, true}, {3, 2, 2, 2, true}}; return t[q]; }
+    static constexpr SingleOp sp(int) { return SingleOp{0, 0, 0}; }
 };
 
-// folded taps: ev[r][i] = tap at offset +/-i (i = 0..W); od[r][i-1] = tap at offset +i (i = 1..W)
+// the tables above against rx / cy: every plane exactly once, row kernels = the window pair's, column kernels = the tap table's
+template <class B>
+constexpr bool bank_tables_ok()
+{
+    int seen[B::NB] = {};
+    for (int q = 0; q < B::NPP; ++q) {
+        const PairOp o = B::pp(q);
+        if (o.w >= B::NRP || o.t >= B::NTP) return false;
+        if (B::rx(o.lo) != B::te(o.w) || B::rx(o.hi) != B::NE + B::to(o.w)) return false;
+        if (B::cy(o.lo) != (o.swap ? B::NE + B::to(o.t) : B::te(o.t)) || B::cy(o.hi) != (o.swap ? B::te(o.t) : B::NE + B::to(o.t))) return false;
+        ++seen[o.lo]; ++seen[o.hi];
+    }
+    for (int q = 0; q < B::NSP; ++q) {
+        const SingleOp o = B::sp(q);
+        if (B::rx(o.plane) != (o.w >= 0 ? B::te(o.w) : B::se(-1 - o.w)) || B::cy(o.plane) != (o.t >= 0 ? B::te(o.t) : B::se(-1 - o.t))) return false;
+        ++seen[o.plane];
+    }
+    for (int p = 0; p < B::NB; ++p) if (seen[p] != 1) return false;
+    for (int k = 0; k < B::NRP; ++k) if (B::te(k) >= B::NE || B::to(k) >= B::NO) return false;
+    return true;
+}
+static_assert(bank_tables_ok<BankG2>() && bank_tables_ok<BankG4G>() && bank_tables_ok<BankG4H>(), "pair tables do not match rx / cy");
+
+// folded taps in pairs: tp[m][i] = {even kernel te(m) at offset +/-i, odd kernel to(m) at offset +i}, i = 0..W; the odd kernel's centre
+// tap tp[m][0].y is +0.0 (what the row filter multiplies the centre sample with).  ts[q][i]: the even kernels no table holds.
 template <class B>
 struct Folded {
-    float ev[B::NE][B::W + 1];
-    float od[B::NO][B::W];
+    f2 tp[B::NTP][B::W + 1];
+    float ts[B::NS ? B::NS : 1][B::W + 1];
 };
+
+// PK = false: the same results from plain instructions on the two halves (same operations, same order).
+// {a.x + a.y, a.x - a.y}
+template <bool PK>
+__device__ __forceinline__ f2 pk_sumdif(f2 a)
+{
+    if constexpr (!PK) return f2{a.x + a.y, a.x - a.y};
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+// {a.x +/- b.x, a.y +/- b.y}: minus where the half's column kernel is odd
+template <bool PK, bool ODD_LO, bool ODD_HI>
+__device__ __forceinline__ f2 pk_addsub(f2 a, f2 b)
+{
+    if constexpr (!PK) return f2{ODD_LO ? a.x - b.x : a.x + b.x, ODD_HI ? a.y - b.y : a.y + b.y};
+    f2 r;
+    if constexpr (ODD_LO && ODD_HI) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else if constexpr (ODD_LO) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else if constexpr (ODD_HI) asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// t (a pair of SGPRs; halves exchanged when SWAP) * x
+template <bool PK, bool SWAP>
+__device__ __forceinline__ f2 pk_mul(f2 t, f2 x)
+{
+    if constexpr (!PK) return f2{(SWAP ? t.y : t.x) * x.x, (SWAP ? t.x : t.y) * x.y};
+    f2 r;
+    if constexpr (SWAP) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "s"(t), "v"(x));
+    else asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "s"(t), "v"(x));
+    return r;
+}
+// {word W + i, word W - i} of this lane's window into a ring line (addr = LDS byte address of word 0); asynchronous: the caller waits
+// lgkmcnt(0) before it uses the value
+template <int W, int I>
+__device__ __forceinline__ f2 lds_pair(unsigned addr)
+{
+    f2 r;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(W + I), "n"(W - I) : "memory");
+    return r;
+}
+template <int W, int... I>
+__device__ __forceinline__ void lds_pairs(unsigned addr, f2* P, std::integer_sequence<int, I...>)
+{
+    ((P[I] = lds_pair<W, I>(addr)), ...);
+}
+// The launch's BasisArgs as they lie in the kernel-argument segment (first argument of every strip kernel), through a pointer the
+// compiler must treat as new at every call: what is read through it is loaded where it is used (s_load, scalar cache) and not kept
+// in scalar registers across the row loop.
+typedef const __attribute__((address_space(4))) BasisArgs* kernarg_ptr_t;
+__device__ __forceinline__ kernarg_ptr_t kernarg_fresh()
+{
+    kernarg_ptr_t ka = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return ka;
+}
+template <bool PK, bool SWAP>
+__device__ __forceinline__ f2 pk_fma(f2 t, f2 x, f2 acc)
+{
+    if constexpr (!PK) return f2{fmaf(SWAP ? t.y : t.x, x.x, acc.x), fmaf(SWAP ? t.x : t.y, x.y, acc.y)};
+    if constexpr (SWAP) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(t), "v"(x));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "s"(t), "v"(x));
+    return acc;
+}
 
 enum { F_ORIENT = 1, F_STEER = 2, F_PIPE = 4, F_NOSTATE = 8, F_PYR = 16, F_PYRONLY = 32, F_FEAT3 = 64 };  // F_PIPE implies F_ORIENT; F_NOSTATE: outputs only;
                                                                             // F_FEAT3 (with F_NOSTATE): exactly the three feature maps, find*(magnitude, phase), fastAtan2 --
@@ -328,7 +455,10 @@ template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB, bool U8
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe, const int bx, const int by)
 {
     constexpr unsigned EB = U8 ? 1u : 4u;   // bytes per input sample
-    constexpr int W = B::W, NT = 2 * W + 1, NE = B::NE, NO = B::NO, NR = NE + NO, NB = B::NB;
+    constexpr int W = B::W, NT = 2 * W + 1, NB = B::NB;
+    // packed arithmetic everywhere but in the three-maps-only pipeline: packed instructions take the whole SIMD, plain ones with a scalar tap leave
+    // its second half to another wave's tap-free instructions, and that variant's long epilogue is made of those (see "Packed f32")
+    constexpr bool PK = (FLAGS & F_FEAT3) == 0;
     // vector-memory instructions per output row that EVERY launch of this variant issues (state planes, fused steer, the three
     // maps of FEAT3; outputs selected at run time are not counted): a lower bound is all the hand-counted waits need
     constexpr int S_ROW = (((FLAGS & F_NOSTATE) == 0 && (FLAGS & F_PYRONLY) == 0) ? NB : 0) +
@@ -401,7 +531,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pipe_out[k] = a.pipe_out[k];
+        for (int k = 0; k < 8; ++k) pipe_out[k] = PlaneRef{nullptr, 0};   // one image: read per row (kernarg_fresh)
     }
     // buffer resources (wave-uniform): input plane, state planes
     const size_t plane_bytes = (size_t)(a.rows - rbase) * a.pitch * sizeof(float);
@@ -429,7 +559,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     [[maybe_unused]] const size_t oplane_bytes = (size_t)(a.rows - rbase) * a.orient_pitch * sizeof(float);
     const unsigned in_pitch_b = (unsigned)(in_pitch * EB);
 
-    float win[NR][NT];  // sliding window of row-filtered values, slot = input row mod NT
+    // sliding window of row-filtered values, slot = input row mod NT: one register pair per row pair, one register per single row kernel
+    f2 win2[B::NRP][NT];
+    [[maybe_unused]] float win1[B::NS ? B::NS : 1][NT];
     // F_PYR: the last five horizontally blurred rows ([1 4 6 4 1] at this lane's column); even lanes of even centre
     // rows make one pixel of the next pyramid level each (launch_pyr_down's arithmetic, op for op)
     [[maybe_unused]] float hw0 = 0.f, hw1 = 0.f, hw2 = 0.f, hw3 = 0.f, hw4 = 0.f;
@@ -499,7 +631,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     auto row_step = [&](auto phase, const int g, const int j, const bool more) __attribute__((always_inline)) {
         constexpr int PHASE = decltype(phase)::value;
         {
-            float s[NT];
+            f2 P[W + 1];
             {
                 // Has row i = g NT + j landed in line j?  Operations issued after its halo load: the loads of the NT - 1 rows
                 // that followed it, and the stores of every OUTPUT row among the NT row steps since.  Steps 2W.. are output rows;
@@ -517,15 +649,19 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 // register per pair and line, and hoists all NT x (W + 1) of them out of the loop (+50 VGPRs for G4)
                 unsigned lj;
                 asm volatile("v_add_u32 %0, %1, %2" : "=v"(lj) : "v"(lds_lane), "s"((unsigned)(j * kRingLine * 4)));
-                const lds_float* lp = reinterpret_cast<const lds_float*>(lj);
-#pragma unroll
-                for (int k = 0; k < NT; ++k) s[k] = lp[k];
+                // P[i] = {sample at column offset +i, at -i} in one ds_read2_b32 each (the pass works on these pairs); P[0] = the centre twice
+                lds_pairs<W>(lj, P, std::make_integer_sequence<int, W + 1>{});
                 // the reads above must have left the LDS before the line is handed to the next row (the load lands hundreds of
                 // cycles later, but nothing else orders it behind them)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i <= W; ++i) asm volatile("" : "+v"(P[i]));   // (the compiler does not know that the reads are asynchronous: nothing that uses them may move above the wait)
                 if constexpr (U8) {
 #pragma unroll
-                    for (int k = 0; k < NT; ++k) s[k] = (float)__float_as_uint(s[k]);   // the line holds the samples as integers 0..255
+                    for (int i = 0; i <= W; ++i) {   // the line holds the samples as integers 0..255
+                        P[i].x = (float)__float_as_uint(P[i].x);
+                        P[i].y = i ? (float)__float_as_uint(P[i].y) : P[i].x;
+                    }
                 }
                 {
                     unsigned ro;
@@ -544,7 +680,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             if constexpr ((FLAGS & F_PYR) != 0) {
                 static_assert(W >= 2, "the pyramid level needs two columns / rows of halo");
                 hw0 = hw1; hw1 = hw2; hw2 = hw3; hw3 = hw4;
-                hw4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(s[W], 6.0f), __fmul_rn(__fadd_rn(s[W - 1], s[W + 1]), 4.0f)), s[W - 2]), s[W + 2]);
+                hw4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P[0].x, 6.0f), __fmul_rn(__fadd_rn(P[1].y, P[1].x), 4.0f)), P[2].y), P[2].x);
                 // newest staged row = y0 - W + i (reflected like the image rows themselves); it completes the 5-row window of
                 // centre row c = y0 + i - W - 2.  This strip owns the even centre rows in [y0, yend).
                 const int ci = g * NT + j - W - 2;  // centre row relative to y0, wave-uniform
@@ -554,27 +690,30 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 }
             }
             if constexpr ((FLAGS & F_PYRONLY) == 0) {
-            float sum[W + 1], dif[W + 1];
+            f2 SD[W + 1];   // {sum_i, dif_i}
 #pragma unroll
-            for (int i = 1; i <= W; ++i) {
-                sum[i] = s[W + i] + s[W - i];
-                dif[i] = s[W + i] - s[W - i];
-            }
+            for (int i = 1; i <= W; ++i) SD[i] = pk_sumdif<PK>(P[i]);
 #pragma unroll
-            for (int r = 0; r < NE; ++r) {
-                float acc = t.ev[r][W] * sum[W];
+            for (int k = 0; k < B::NRP; ++k) {
+                f2 acc = pk_mul<PK, false>(t.tp[k][W], SD[W]);
 #pragma unroll
-                for (int i = W - 1; i >= 1; --i) acc = fmaf(t.ev[r][i], sum[i], acc);
-                win[r][j] = fmaf(t.ev[r][0], s[W], acc);
-            }
-#pragma unroll
-            for (int r = 0; r < NO; ++r) {
-                float acc = t.od[r][W - 1] * dif[W];
-#pragma unroll
-                for (int i = W - 1; i >= 1; --i) acc = fmaf(t.od[r][i - 1], dif[i], acc);
-                // the centre tap of an odd kernel is +0.0: the CPU row filter still multiplies it in, which
+                for (int i = W - 1; i >= 1; --i) acc = pk_fma<PK, false>(t.tp[k][i], SD[i], acc);
+                // the centre tap of an odd kernel is +0.0 (tp[k][0].y): the CPU row filter still multiplies it in, which
                 // matters only for non-finite pixels (0 * Inf = NaN) -- keep that footprint identical
-                win[NE + r][j] = fmaf(0.0f, s[W], acc);
+                acc = pk_fma<PK, false>(t.tp[k][0], P[0], acc);
+                // (pinned here: the compiler would otherwise sink the row pass of the priming steps into the conditional column-pass blocks
+                // that use it, and keep the thirteen samples of every such step alive instead of its results)
+                asm volatile("" : "+v"(acc));
+                win2[k][j] = acc;
+            }
+#pragma unroll
+            for (int q = 0; q < B::NS; ++q) {
+                float acc = t.ts[q][W] * SD[W].x;
+#pragma unroll
+                for (int i = W - 1; i >= 1; --i) acc = fmaf(t.ts[q][i], SD[i].x, acc);
+                acc = fmaf(t.ts[q][0], P[0].x, acc);
+                asm volatile("" : "+v"(acc));
+                win1[q][j] = acc;
             }
 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----
@@ -610,24 +749,39 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #endif
 #endif
                 float b[NB];
+                // window slots: the newest row is slot j, the centre row W back = slot (j + 1 + W) % NT
 #pragma unroll
-                for (int p = 0; p < NB; ++p) {
-                    const int rp = B::rx(p), ck = B::cy(p);
-                    const int c = (j + 1 + W) % NT;
-                    float acc;
-                    if (ck < NE) {
-                        acc = t.ev[ck][W] * (win[rp][(j + 1 + 2 * W) % NT] + win[rp][(j + 1) % NT]);
+                for (int q = 0; q < B::NPP; ++q) {
+                    constexpr auto slot = [](int jj, int d) constexpr { return (jj + 1 + W + d + NT) % NT; };
+                    const PairOp o = B::pp(q);
+                    f2 acc;
+                    // lo half: column kernel odd when o.swap, hi half: odd when not
+                    if (o.swap) {
+                        acc = pk_mul<PK, true>(t.tp[o.t][W], pk_addsub<PK, true, false>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
 #pragma unroll
                         for (int i = W - 1; i >= 1; --i)
-                            acc = fmaf(t.ev[ck][i], win[rp][(j + 1 + W + i) % NT] + win[rp][(j + 1 + W - i) % NT], acc);
-                        acc = fmaf(t.ev[ck][0], win[rp][c], acc);
+                            acc = pk_fma<PK, true>(t.tp[o.t][i], pk_addsub<PK, true, false>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
+                        acc.y = fmaf(t.tp[o.t][0].x, win2[o.w][slot(j, 0)].y, acc.y);
                     } else {
-                        acc = t.od[ck - NE][W - 1] * (win[rp][(j + 1 + 2 * W) % NT] - win[rp][(j + 1) % NT]);
+                        acc = pk_mul<PK, false>(t.tp[o.t][W], pk_addsub<PK, false, true>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
 #pragma unroll
                         for (int i = W - 1; i >= 1; --i)
-                            acc = fmaf(t.od[ck - NE][i - 1], win[rp][(j + 1 + W + i) % NT] - win[rp][(j + 1 + W - i) % NT], acc);
+                            acc = pk_fma<PK, false>(t.tp[o.t][i], pk_addsub<PK, false, true>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
+                        acc.x = fmaf(t.tp[o.t][0].x, win2[o.w][slot(j, 0)].x, acc.x);
                     }
-                    b[p] = acc;
+                    b[o.lo] = acc.x;
+                    b[o.hi] = acc.y;
+                }
+#pragma unroll
+                for (int q = 0; q < B::NSP; ++q) {   // planes outside the pairs: an even row kernel, an even column kernel, plain instructions
+                    constexpr auto slot = [](int jj, int d) constexpr { return (jj + 1 + W + d + NT) % NT; };
+                    const SingleOp o = B::sp(q);
+                    auto wv = [&](int sl) { return o.w >= 0 ? win2[o.w >= 0 ? o.w : 0][sl].x : win1[o.w >= 0 ? 0 : -1 - o.w][sl]; };
+                    auto tap = [&](int i) { return o.t >= 0 ? t.tp[o.t >= 0 ? o.t : 0][i].x : t.ts[o.t >= 0 ? 0 : -1 - o.t][i]; };
+                    float acc = tap(W) * (wv(slot(j, W)) + wv(slot(j, -W)));
+#pragma unroll
+                    for (int i = W - 1; i >= 1; --i) acc = fmaf(tap(i), wv(slot(j, i)) + wv(slot(j, -i)), acc);
+                    b[o.plane] = fmaf(tap(0), wv(slot(j, 0)), acc);
                 }
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
                 // output row relative to the plane pointers, and its byte offset in a state plane
@@ -659,7 +813,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
                     // stateless pipeline: the oriented energy (and with it C1) is evaluated only when asked for
                     constexpr bool FEAT3 = (FLAGS & F_FEAT3) != 0;
-                    const bool want_e = FEAT3 ? false : (BATCH == 2 ? (a.out_mask & 4u) != 0 : pipe_out[2].p != nullptr);
+                    const bool want_e = FEAT3 ? false : (BATCH == 2 ? (a.out_mask & 4u) != 0 : BATCH == 0 ? a.pipe_out[2].p != nullptr : pipe_out[2].p != nullptr);
                     const bool need_e = FEAT3 ? false : ((FLAGS & F_NOSTATE) == 0 || want_e || a.find_on_e != 0);  // wave-uniform
                     const int amode = FEAT3 ? 0 : a.atan_mode;   // FEAT3: a compile-time constant, the atan2f path is not even compiled in
                     float c1, c2, c3, th, st;
@@ -697,10 +851,20 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                                 if (FEAT3 || (a.out_mask & (1u << k))) bst<STREAM>(r_out, xbr, orow_out + a.out_off[k], q[k]);
                         } else {
 #pragma unroll
-                            for (int k = FEAT3 ? 5 : 0; k < 8; ++k)
-                                if (FEAT3 || pipe_out[k].p)
-                                    bst<STREAM>(plane_rsrc(pipe_out[k].p, (size_t)(a.rows - rbase) * pipe_out[k].pitch * sizeof(float)), xbr,
-                                                yo * (unsigned)(pipe_out[k].pitch * sizeof(float)), q[k]);
+                            for (int k = FEAT3 ? 5 : 0; k < 8; ++k) {
+                                // One image: the eight output planes are the caller's own (pointer + pitch each: 32 SGPRs that the row loop has
+                                // not got; kept across it they are spilled to vector-register lanes, and every v_readlane_b32 costs the SIMD as
+                                // much as a packed multiply-add -- 180 of them per output row were 38 % of this variant's vector time).  They are
+                                // read from the kernel-argument segment again in every row instead (scalar cache); the record count of the
+                                // resource is the constant maximum -- the range check is only there to drop the lanes right of the image.
+                                PlaneRef po = pipe_out[k];
+                                if constexpr (BATCH == 0) {
+                                    const kernarg_ptr_t ka = kernarg_fresh();
+                                    po.p = ka->pipe_out[k].p;
+                                    po.pitch = ka->pipe_out[k].pitch;
+                                }
+                                if (FEAT3 || po.p) bst<STREAM>(plane_rsrc(po.p, kMaxPlaneBytes), xbr, yo * (unsigned)(po.pitch * sizeof(float)), q[k]);
+                            }
                         }
                     }
                 }
@@ -843,23 +1007,30 @@ template <class B>
 static bool fold_taps(const float (*taps)[kMaxTaps], Folded<B>& f)
 {
     constexpr int W = B::W;
+    float ev[B::NE][W + 1];   // ev[r][i] = tap at offset +/-i (i = 0..W)
+    float od[B::NO][W + 1];   // od[r][i] = tap at offset +i (i = 1..W); od[r][0] = +0.0f, the centre
     for (int r = 0; r < B::NE; ++r) {
         const float* k = taps[B::even_member(r)];
         for (int i = 0; i <= W; ++i) {
             if (k[W + i] != k[W - i]) return false;
-            f.ev[r][i] = k[W + i];
+            ev[r][i] = k[W + i];
         }
     }
     for (int r = 0; r < B::NO; ++r) {
         const float* k = taps[B::odd_member(r)];
         if (k[W] != 0.0f) return false;
+        od[r][0] = 0.0f;
         for (int i = 1; i <= W; ++i) {
             if (k[W + i] != -k[W - i]) return false;
-            f.od[r][i - 1] = k[W + i];
+            od[r][i] = k[W + i];
         }
     }
     for (int i = 0; i < 2 * W + 1; ++i)
         if (taps[B::dup_a][i] != taps[B::dup_b][i]) return false;
+    for (int m = 0; m < B::NTP; ++m)
+        for (int i = 0; i <= W; ++i) f.tp[m][i] = f2{ev[B::te(m)][i], od[B::to(m)][i]};
+    for (int q = 0; q < (B::NS ? B::NS : 1); ++q)
+        for (int i = 0; i <= W; ++i) f.ts[q][i] = B::NS ? ev[B::se(q)][i] : 0.0f;
     return true;
 }
 

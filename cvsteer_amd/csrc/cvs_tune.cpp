@@ -241,17 +241,22 @@ static hipEvent_t take_event(int device)   // the caller has made `device` curre
 // the engine's default configuration for this launch; true = the launch is of a kind whose alternatives are worth comparing
 static bool default_config(cvs_handle h, BasisArgs& a, int variant)
 {
-    // Workgroups per CU.  Since the input rows go straight into LDS (round 5) the G2 kernels need 80-93 VGPRs and five to six
-    // workgroups share a CU; every resident wave is one more write front in HBM, and two launches stream faster with fewer
-    // (three processes on one box, profiles/r05_occupancy_cap.txt): the fused steer at three per CU (0.798 -> 0.842 on a resident
-    // 4096^2 image, 0.72 -> 0.758 on new ones, in every process; level at 8192^2) and the 20-plane pipeline at four (+1-4 %).
-    // The basis pass loses with any cap, the full setup gains 6 % or loses 3 % depending on where its plane groups lie (left
-    // alone), G4 does not care.  CVS_OPTS wgcap=N overrides (0 = none).
+    // Workgroups per CU.  With the input rows going straight into LDS and the packed arithmetic (round 5) the G2 kernels need 75-90
+    // VGPRs and six workgroups would share a CU; every resident wave is one more write front in HBM, and the launches stream faster
+    // with fewer (two processes on one box after the packed arithmetic, profiles/r05_occupancy_cap.txt, fraction of the HBM roofline):
+    //   basis pass          four per CU   0.821 -> 0.845 resident, 0.722 -> 0.741 new images (4096^2); 8192^2 left alone (0.86-0.88)
+    //   full setup          three         0.74 -> 0.797, new images 0.70 -> 0.745
+    //   fused steer         three         0.81-0.82 (four, five) -> 0.833; 8192^2 left alone (four: +2 % on one box, -2.5 % on the next)
+    //   caller pipeline     three         0.71 -> 0.73
+    //   pyramid level that also emits the next level: three at any size (five-level pyramid of 8192^2: 0.607 -> 0.67)
+    // G4 does not care (0.70-0.71 at two to five), frame batches are left alone (+-1.5 %).  CVS_OPTS wgcap=N overrides (0 = none).
     const size_t npix_cfg = (size_t)a.rows * a.cols;
     a.wg_per_cu = 0;
-    if (h->kind == CVS_KIND_G2 && a.batch == 0 && npix_cfg >= ((size_t)2 << 20) && npix_cfg < ((size_t)32 << 20)) {
-        if (variant == 2) a.wg_per_cu = 3;
-        else if (variant == 5) a.wg_per_cu = 4;
+    if (h->kind == CVS_KIND_G2 && a.batch == 0 && npix_cfg >= ((size_t)2 << 20)) {
+        const bool mid = npix_cfg < ((size_t)32 << 20);
+        if (a.pyr_out) a.wg_per_cu = 3;
+        else if (variant == 0) a.wg_per_cu = mid ? 4 : 0;
+        else if (variant == 1 || variant == 2 || variant == 5) a.wg_per_cu = mid ? 3 : 0;
     }
     if (const int forced = env_opts().wgcap; forced >= 0) a.wg_per_cu = forced;
     // CVS_OPT_STATE_LAYOUT = 2 pins the grouping: launches that write orientation planes use ONE group of twelve planes

@@ -1,4 +1,4 @@
-"""round 5: workgroups per CU (dynamic LDS nobody touches, CVS_OPTS wgcap=N) per entry point, after the LDS-DMA input path (fewer VGPRs:
+"""round 5 (repeated after the packed arithmetic, which needs fewer VGPRs again): workgroups per CU (dynamic LDS nobody touches, CVS_OPTS wgcap=N) per entry point, after the LDS-DMA input path (fewer VGPRs:
 5-6 workgroups per CU fit where 4-5 did).  Tuner off, same handle, alternating settings, 3 rounds; run it in several processes."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ def timeit(fn, steps, lead=40):
     for _ in range(steps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
-caps = ["", "wgcap=4", "wgcap=3", "wgcap=2"]
+caps = ["", "wgcap=5", "wgcap=4", "wgcap=3", "wgcap=2"]
 def ab(name, fn, nbytes, steps=24):
     res = {}
     for rnd in range(3):
@@ -52,3 +52,22 @@ ab("M1 8192 resident", lambda: fb.setup(big[0], flags=cv.SETUP_BASIS), 32 * 8192
 ab("M2 8192 resident", lambda: fb.setup_steer(big[0], 0.3, flags=cv.SETUP_BASIS, out=(gb, hb)), 40 * 8192 * 8192, 8)
 ab("M2 8192 new images", lambda: fb.setup_steer(nb(), 0.3, flags=cv.SETUP_BASIS, out=(gb, hb)), 40 * 8192 * 8192, 8)
 ab("M1 8192 new images", lambda: fb.setup(nb(), flags=cv.SETUP_BASIS), 32 * 8192 * 8192, 8)
+del big, gb, hb, fb
+frames = torch.rand((32, 1080, 1920), device="cuda")
+ff = cv.SteerableFiltersG2(None, 4, 0.67)
+fo8 = torch.empty((32, 8, 1080, 1920), device="cuda")
+fo3 = torch.empty((32, 3, 1080, 1920), device="cuda")
+fpix = 32 * 1080 * 1920
+ab("C4 32x1080p state kept", lambda: ff.pipeline_batch(frames, out=fo8), 84 * fpix, 8)
+ff.set_persist(False)
+ab("C4 32x1080p three maps", lambda: ff.pipeline_batch(frames, out=fo3, outputs=(5, 6, 7)), 16 * fpix, 8)
+del frames, fo8, fo3, ff
+bigs = [torch.rand((8192, 8192), device="cuda") for _ in range(2)]
+fp3 = cv.SteerableFiltersG2(None, 4, 0.67)
+lv = fp3.pyramid(bigs[0], 5)
+ppix = sum(l.shape[0] * l.shape[1] for l in lv)
+hp = [cv.SteerableFiltersG2(None, 4, 0.67) for _ in lv]
+def pyr():
+    fl[0] ^= 1
+    cv.pyramid_setup(hp, bigs[fl[0]], level_images=lv[1:], flags=cv.SETUP_BASIS)
+ab("C3 pyramid 8192 5 levels", pyr, 32 * ppix + 4 * (ppix - 8192 * 8192), 8)
