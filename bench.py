@@ -16,8 +16,8 @@ The ONE JSON line (round 5: <= 6 KB, so that it survives the driver's 8 KB tail)
     fresh_frac (a new image every call), one_object_frac / first_call_frac (the reference's one object per image), after_idle_frac,
     m4 / m5 / g4 / c3 / c4, and what RCCL saw (rccl_ranks, transport, scatter / compute / gather ms);
   * `legs`: name -> [frac_hbm, ms, ms_min, ms_max, config index, frac_valu] with the launch configurations listed once in
-    `launch_configs`; frac_valu = the leg's VALU roof (vector instructions per pixel from profiles/valu_insts.json, two cycles
-    per wave64 instruction on a SIMD32, 1024 SIMDs, the sustained shader clock of this run) so that `bound` can be min(hbm, valu);
+    `launch_configs`; frac_valu = the leg's VALU roof (vector instructions per pixel and the cycles per instruction of the kernel's
+    instruction mix from profiles/valu_insts.json, 1024 SIMDs, the sustained shader clock of this run) so that `bound` can be min(hbm, valu);
   * probe-only legs (8-bit inputs, untuned twin, host planes, two streams, tuner-off twins, separate outputs, pyramid parts)
     run with --all-legs.
 
@@ -43,8 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-N_SIMD = 1024              # 256 CUs x 4 SIMD32
-VALU_CYCLES_PER_INST = 2.0 # a wave64 vector instruction occupies its SIMD32 for two cycles (MI355X_MICROARCH.md, tools/valu_rate.hip)
+N_SIMD = 1024              # 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_INST = 4.4 # default when profiles/valu_insts.json has no figure for a kernel: a wave64 vector instruction with a scalar-register operand
+                           # (or a packed one) takes a SIMD for ~4.4 cycles, two tap-free simple ones share that time (tools/valu_rate.hip, profiles/r05_valu_rate.txt)
 NOMINAL_SCLK_MHZ = 2000.0  # used for the VALU roof only when the card's clock cannot be read
 ROWS = COLS = 4096
 THETA = 0.3
@@ -229,7 +230,9 @@ def _valu_table():
     """vector instructions per OUTPUT pixel of every timed kernel (halo rows included), measured with rocprofv3 --pmc
     SQ_INSTS_VALU on this code (tools/collect_valu.py -> profiles/valu_insts.json); {} when the file is missing"""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json"))).get("per_pixel", {})
+        d = json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))
+        cpi = d.get("cycles_per_inst", {})
+        return {k: (v, cpi.get(k, VALU_CYCLES_PER_INST)) for k, v in d.get("per_pixel", {}).items()}
     except Exception:
         return {}
 
@@ -597,12 +600,13 @@ def main():
     clock = {"mhz": None}
 
     def frac_valu(key, pix, ms):
-        """fraction of the VALU roof: vector instructions of the launch x 2 cycles / (1024 SIMDs x shader clock) / measured time"""
+        """fraction of the VALU roof: vector instructions of the launch (counted: SQ_INSTS_VALU) x the cycles per instruction of the kernel's
+        instruction mix (tools/valu_model.py) / (1024 SIMDs x shader clock) / measured time"""
         per = valu_tab.get(key)
         if not per:
             return None
         mhz = clock["mhz"] or NOMINAL_SCLK_MHZ
-        return round(per * pix * VALU_CYCLES_PER_INST / N_SIMD / (mhz * 1e6) / (ms * 1e-3), 4)
+        return round(per[0] * pix * per[1] / N_SIMD / (mhz * 1e6) / (ms * 1e-3), 4)
 
     out.update({
         "value": round(value, 1), "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
@@ -799,12 +803,15 @@ def main():
             rf["g4_steer_frac"] = leg("M6_g4_filter_steer", lambda: f4.setup_steer(img, THETA, out=(g, h)), BYTES_PER_PIX["M6s"], handle=f4, valu_key="M6s")
             rf["g4_after_idle_frac"] = leg("M6_g4_basis_after_idle", lambda: f4.setup(img), BYTES_PER_PIX["M6"], handle=f4, settle_calls=4, valu_key="M6", idle_s=0.03)
             rf["g4_valu_frac"] = legs["M6_g4_basis"][5]
-            rf["g4_bound"] = "valu" if (rf["g4_valu_frac"] or 0) > rf["g4_frac"] else "hbm"
-            if fs:   # what these two run at when sustained (they follow the shader clock)
-                for nm, fn_ in (("m5", lambda: f.pipeline(img, out=outs8)), ("g4", lambda: f4.setup(img))):
+            rf["m5_valu_frac"] = legs["M5_pipeline"][5]
+            if fs:   # what these two run at when sustained (they follow the shader clock): their VALU roofs are taken at their OWN clock
+                for nm, fn_, lg in (("m5", lambda: f.pipeline(img, out=outs8), "M5_pipeline"), ("g4", lambda: f4.setup(img), "M6_g4_basis")):
                     s_ = _sustained(torch, fs, fn_, 0.4)
                     rf[nm + "_sclk_mhz"] = s_["sclk_mhz"]
+                    if s_["sclk_mhz"] and legs[lg][5]:
+                        legs[lg][5] = rf[nm + "_valu_frac"] = round(legs[lg][5] * (clock["mhz"] or NOMINAL_SCLK_MHZ) / s_["sclk_mhz"], 4)
                 step()
+            rf["g4_bound"] = "valu" if (rf["g4_valu_frac"] or 0) > rf["g4_frac"] else "hbm"
             del outs8, f4
             # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed start-up cost of
             # a launch (every wave primes its 8-row window before its first store) amortises -- and with two images taking turns

@@ -845,10 +845,20 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         q[6] = __fmul_rn(en, ld);
                         q[7] = __fmul_rn(en, lb);
                         if constexpr (BATCH == 2) {
-                            const unsigned orow_out = yo * (unsigned)(a.out_pitch * sizeof(float));
+                            if constexpr ((FLAGS & F_NOSTATE) != 0) {   // outputs only: the eight plane offsets are read per row, not kept (see the one-image
+                                                                        // form below; with the state planes written too that costs more scalar work than it saves)
+                                const kernarg_ptr_t ka = kernarg_fresh();
+                                const unsigned orow_out = yo * (unsigned)(ka->out_pitch * sizeof(float));
+                                const unsigned mask = FEAT3 ? 0xE0u : ka->out_mask;
 #pragma unroll
-                            for (int k = FEAT3 ? 5 : 0; k < 8; ++k)
-                                if (FEAT3 || (a.out_mask & (1u << k))) bst<STREAM>(r_out, xbr, orow_out + a.out_off[k], q[k]);
+                                for (int k = FEAT3 ? 5 : 0; k < 8; ++k)
+                                    if (FEAT3 || (mask & (1u << k))) bst<STREAM>(r_out, xbr, orow_out + ka->out_off[k], q[k]);
+                            } else {
+                                const unsigned orow_out = yo * (unsigned)(a.out_pitch * sizeof(float));
+#pragma unroll
+                                for (int k = 0; k < 8; ++k)
+                                    if (a.out_mask & (1u << k)) bst<STREAM>(r_out, xbr, orow_out + a.out_off[k], q[k]);
+                            }
                         } else {
 #pragma unroll
                             for (int k = FEAT3 ? 5 : 0; k < 8; ++k) {
@@ -869,10 +879,12 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     }
                 }
                 if constexpr ((FLAGS & F_STEER) != 0) {
-                    const rsrc_t rg = plane_rsrc(a.steer_g, (size_t)(a.rows - rbase) * a.steer_g_pitch * sizeof(float));
-                    const rsrc_t rh = plane_rsrc(a.steer_h, (size_t)(a.rows - rbase) * a.steer_h_pitch * sizeof(float));
-                    const unsigned og = yo * (unsigned)(a.steer_g_pitch * sizeof(float));
-                    const unsigned oh = yo * (unsigned)(a.steer_h_pitch * sizeof(float));
+                    // the two steered planes are the caller's own: pointer and pitch read from the kernel arguments per row (see F_PIPE above)
+                    const kernarg_ptr_t ks = kernarg_fresh();
+                    const rsrc_t rg = plane_rsrc(ks->steer_g, kMaxPlaneBytes);
+                    const rsrc_t rh = plane_rsrc(ks->steer_h, kMaxPlaneBytes);
+                    const unsigned og = yo * (unsigned)(ks->steer_g_pitch * sizeof(float));
+                    const unsigned oh = yo * (unsigned)(ks->steer_h_pitch * sizeof(float));
                     if constexpr (B::HALF == 0) {
                         static_assert(B::KIND == 2, "the whole-bank form exists for G2 only");
                         float gq, hq;

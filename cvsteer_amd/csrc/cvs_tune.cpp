@@ -246,7 +246,8 @@ static bool default_config(cvs_handle h, BasisArgs& a, int variant)
     // with fewer (two processes on one box after the packed arithmetic, profiles/r05_occupancy_cap.txt, fraction of the HBM roofline):
     //   basis pass          four per CU   0.821 -> 0.845 resident, 0.722 -> 0.741 new images (4096^2); 8192^2 left alone (0.86-0.88)
     //   full setup          three         0.74 -> 0.797, new images 0.70 -> 0.745
-    //   fused steer         three         0.81-0.82 (four, five) -> 0.833; 8192^2 left alone (four: +2 % on one box, -2.5 % on the next)
+    //   fused steer         three         0.81-0.82 (four, five) -> 0.833; 8192^2: four (new images 0.732 -> 0.757 and 0.728 -> 0.75 on two boxes;
+    //                                     resident +2 % on one box, -2.5 % on the next)
     //   caller pipeline     three         0.71 -> 0.73
     //   pyramid level that also emits the next level: three at any size (five-level pyramid of 8192^2: 0.607 -> 0.67)
     // G4 does not care (0.70-0.71 at two to five), frame batches are left alone (+-1.5 %).  CVS_OPTS wgcap=N overrides (0 = none).
@@ -256,7 +257,8 @@ static bool default_config(cvs_handle h, BasisArgs& a, int variant)
         const bool mid = npix_cfg < ((size_t)32 << 20);
         if (a.pyr_out) a.wg_per_cu = 3;
         else if (variant == 0) a.wg_per_cu = mid ? 4 : 0;
-        else if (variant == 1 || variant == 2 || variant == 5) a.wg_per_cu = mid ? 3 : 0;
+        else if (variant == 2) a.wg_per_cu = mid ? 3 : 4;
+        else if (variant == 1 || variant == 5) a.wg_per_cu = mid ? 3 : 0;
     }
     if (const int forced = env_opts().wgcap; forced >= 0) a.wg_per_cu = forced;
     // CVS_OPT_STATE_LAYOUT = 2 pins the grouping: launches that write orientation planes use ONE group of twelve planes

@@ -379,6 +379,33 @@ def test_small_shape_fuzz_with_streaming_stores_forced(cv, ora, monkeypatch):
         assert np.abs(g4.cpu().numpy() - og).max() <= 1e-6 and np.abs(h4.cpu().numpy() - oh).max() <= 1e-6
 
 
+def test_8bit_inputs_with_streaming_stores_forced_equal_widened(cv, monkeypatch):
+    """The 8-bit legs of bench.py (M2 from 8-bit images; 32 x 1080p three maps from 8-bit frames) run the byte-reading instances
+    with streaming stores -- cvs::k_basis<BankG2, 2, true, 0, true, 4, true> and cvs::k_basis<BankG2, 77, true, 2, true, 4, true>.
+    CVS_OPTS nt_stores=1 on small and medium shapes: bit-identical to the same pixels widened to f32 first (whose instances meet
+    the oracle in the test above)."""
+    import torch
+    monkeypatch.setenv("CVS_OPTS", "nt_stores=1")
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    for rows, cols in ((185, 256), (131, 1021), (540, 960)):
+        u8 = (torch.rand((rows, cols), device="cuda", generator=gen) * 256).to(torch.uint8)
+        f32 = u8.to(torch.float32)
+        a, b = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
+        ga, ha = a.setup_steer(u8, 0.3, flags=cv.SETUP_BASIS)
+        assert a.launch_info()["nt_stores"] == 1
+        gb, hb = b.setup_steer(f32, 0.3, flags=cv.SETUP_BASIS)
+        assert torch.equal(ga, gb) and torch.equal(ha, hb)
+        for p in range(7):
+            assert torch.equal(a._state(p), b._state(p)), ("basis", p)
+        block = (torch.rand((5, rows, cols), device="cuda", generator=gen) * 256).to(torch.uint8)
+        fa_, fb_ = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
+        fa_.set_persist(False)
+        fb_.set_persist(False)
+        oa = fa_.pipeline_batch(block, outputs=(5, 6, 7))
+        ob = fb_.pipeline_batch(block.to(torch.float32), outputs=(5, 6, 7))
+        assert torch.equal(oa, ob), (rows, cols)
+
+
 def test_overlapped_host_path_against_the_oracle(cv, ora):
     """the band-wise upload / filter / download path (host_pipeline in cvs_host.cpp; a 1-Mpix-and-more host image with host
     outputs: cvs::k_basis<BankG2, 2 / 3, STREAM, 0, false, 4> per band) directly against the oracle, not only against the

@@ -12,10 +12,10 @@ def rows(sub):
     for fn in fs[-1:]:
         out += [r for r in csv.DictReader(open(fn)) if r["Counter_Name"] == "SQ_INSTS_VALU"]
     return out
-cal = [float(r["Counter_Value"]) for r in rows("pmc_valu_cal") if "k<false>" in r["Kernel_Name"] or "ILb0E" in r["Kernel_Name"]]
-# tools/valu_rate.hip k<false> as tools/profile_all_r05.sh builds it (-O3 without -fno-slp-vectorize): the 16 fmaf of an iteration are packed
-# into 8 v_pk_fma_f32 (checked in the ISA): 2048 workgroups x 4 waves, 4096 iterations x 8 vector instructions per wave (+ ~60 of set-up / final sum)
-known = 2048 * 4 * (4096 * 8 + 60)
+cal = [float(r["Counter_Value"]) for r in rows("pmc_valu_cal") if "k<0>" in r["Kernel_Name"]]
+# tools/valu_rate.hip k<0> (inline-asm v_fma_f32, nothing for the compiler to pack) as tools/profile_all_r05.sh runs it (4096 iterations):
+# 2048 workgroups x 4 waves, 4096 iterations x 16 vector instructions per wave (+ ~50 of set-up / final sum)
+known = 2048 * 4 * (4096 * 16 + 50)
 factor = known / (sum(cal) / len(cal)) if cal else 1.0
 pix4096, pixc4 = 4096 * 4096, 32 * 1080 * 1920
 legs = {"M1": ("k_basis<cvs::BankG2, 0, true, 0, true", pix4096), "M2": ("k_basis<cvs::BankG2, 2, true, 0, true", pix4096),
@@ -25,13 +25,23 @@ legs = {"M1": ("k_basis<cvs::BankG2, 0, true, 0, true", pix4096), "M2": ("k_basi
 agg = collections.defaultdict(list)
 for r in rows("pmc_valu"):
     agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+# cycles per instruction of each kernel's instruction mix (tools/valu_model.py --json on the current ISA; see its header for the model)
+try:
+    cpi_tab = json.load(open(os.path.join(G, "valu_cpi.json")))
+except Exception:
+    cpi_tab = {}
 out = {"source": "rocprofv3 --pmc SQ_INSTS_VALU -- python3 tools/valu_child.py (counter-only pass), %s; calibration on tools/valu_rate (known %d wave instructions): counter x %.4f" % (rnd, known, factor),
-       "unit": "wave64 vector instructions per output pixel (halo rows and window priming included)", "calibration_factor": round(factor, 4), "per_pixel": {}, "per_launch": {}}
+       "unit": "wave64 vector instructions per output pixel (halo rows and window priming included)", "calibration_factor": round(factor, 4), "per_pixel": {}, "per_launch": {},
+       "cycles_per_inst_model": "4.4 cycles x max(packed + other, (2 packed + other + simple) / 2) / instructions, classes and costs in tools/valu_model.py / profiles/r05_valu_rate.txt",
+       "cycles_per_inst": {}}
 for leg, (pat, pix) in legs.items():
     vals = [v for k, vs in agg.items() if pat in k for v in vs]
     if vals:
         v = sorted(vals)[len(vals) // 2] * factor     # the median launch (a handle's first call also requests the image ahead)
         out["per_launch"][leg] = round(v)
         out["per_pixel"][leg] = round(v / pix, 5)
+        cp = [c for k, c in cpi_tab.items() if pat in k]
+        if cp:
+            out["cycles_per_inst"][leg] = cp[0]
 json.dump(out, open(os.path.join(P, "valu_insts.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

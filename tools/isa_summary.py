@@ -2,7 +2,7 @@
 """tools/isa_summary.py -- compile the kernel translation units to gfx950 assembly (no GPU needed) and
 tabulate, per kernel: VGPRs, SGPRs, scratch, LDS, waves/SIMD, and the instruction mix of the body
 (VALU / SALU / LDS / buffer loads / buffer stores / v_pk_* / v_readlane+v_writelane SGPR-spill traffic).
-Writes profiles/<round>_isa_summary.csv."""
+Writes profiles/<round>_isa_summary.csv, and gpurun_out/valu_cpi.json (tools/valu_model.py: model cycles per vector instruction per kernel)."""
 import csv, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +26,10 @@ for src, extra in UNITS:
         subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + [os.path.join(ROOT, "cvsteer_amd", "csrc", src), "-o", tmp.name],
                        check=True, stderr=subprocess.DEVNULL)
         text = open(tmp.name).read()
+        if src == "cvs_kernels_basis.hip":   # cycles per vector instruction of every strip kernel's mix, for tools/collect_valu.py
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_model.py"), tmp.name, "--json", os.path.join(ROOT, "gpurun_out", "valu_cpi.json")],
+                           check=True, stdout=subprocess.DEVNULL)
     meta = {}
     for blk in text.split("  - .agpr_count:")[1:]:   # one chunk of the amdhsa.kernels metadata per kernel
         nm = re.search(r"\.name:\s+(\S+)", blk)

@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""tools/valu_model.py FILE.s [pattern ...] -- vector-ALU cycles of the strip kernels from their ISA, with the issue costs measured by
-tools/valu_rate.hip on MI355X (profiles/r05_valu_rate.txt), per wave64 instruction and SIMD:
-  2 cycles   v_fma / v_fmac / v_add / v_sub / v_mul (f32), v_mov_b32, v_add_u32 / v_sub_u32, v_and / v_or / v_xor, v_fmaak / v_fmamk -- when no
-             operand is a scalar register (literals and inline constants are free)
-  8 cycles   v_rcp / v_sqrt / v_rsq / v_exp / v_log / v_sin / v_cos
-  4 cycles   everything else: any scalar-register operand (taps!), v_pk_*, v_cmp*, v_cndmask, v_cvt*, v_min / v_max, v_rndne, v_ldexp, v_bfi,
-             v_div_*, shifts, v_readlane / v_writelane
-Prints per kernel: instructions and model cycles of the whole body (window priming group + one steady group), split by class."""
+"""tools/valu_model.py FILE.s [pattern ...] -- vector-ALU time of the strip kernels from their ISA, with the issue costs measured by
+tools/valu_rate.hip on MI355X (profiles/r05_valu_rate.txt).  A SIMD behaves like two 16-lane pipes that take one wave64 instruction
+every ~4.4 cycles each:
+  simple     v_fma / v_fmac / v_add / v_sub / v_mul (f32), v_mov_b32, v_add_u32 / v_sub_u32, v_and / v_or / v_xor, v_fmaak / v_fmamk with no
+             scalar-register operand (literals and inline constants are free): either pipe -- two of them go through per ~4.6 cycles
+  other      any scalar-register operand (the filter taps!), v_cmp*, v_cndmask, v_cvt*, v_min / v_max, v_rndne, v_ldexp, v_bfi, v_div_*,
+             shifts, v_readlane / v_writelane: one per ~4.4 cycles, the second pipe stays free for another wave's simple instructions
+  packed     v_pk_fma / v_pk_mul / v_pk_add (f32): two results per lane, both pipes for ~4.4 cycles
+  trans      v_rcp / v_sqrt / v_rsq / ...: ~8.2 cycles (counted as two `other`)
+Lower bound of the vector time of a mix: 4.4 cycles x max(packed + other, (2 packed + other + simple) / 2).
+Prints per kernel: instructions by class (whole body = window priming group + one steady group), that bound, and the bound per instruction;
+with --json FILE writes {kernel: cycles per instruction} for tools/collect_valu.py."""
 import re, subprocess, sys, collections
 TWO = {"v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32",
        "v_and_b32", "v_or_b32", "v_xor_b32", "v_fmaak_f32", "v_fmamk_f32"}
@@ -21,8 +25,13 @@ def classify(op, args):
     if base in TWO: return "simple+sgpr", 4
     return "other", 4
 def main():
-    text = open(sys.argv[1]).read()
-    pats = sys.argv[2:]
+    argv = sys.argv[1:]
+    jpath = None
+    if "--json" in argv:
+        k = argv.index("--json"); jpath = argv[k + 1]; del argv[k:k + 2]
+    text = open(argv[0]).read()
+    pats = argv[1:]
+    table = {}
     names = re.findall(r"^(_ZN3cvs\S+):", text, re.M)
     dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
     for n, d in zip(names, dem):
@@ -36,5 +45,12 @@ def main():
             if not mm: continue
             c, k = classify(mm.group(1), mm.group(2))
             cyc[c] += k; cnt[c] += 1
-        print("%-70s instr %5d cycles %6d | %s" % (d[:70], sum(cnt.values()), sum(cyc.values()), "  ".join("%s %d/%d" % (c, cnt[c], cyc[c]) for c in sorted(cyc))))
+        P = cnt["packed"]; S = cnt["simple"]; N = sum(cnt.values()) - P - S + cnt["trans"]
+        bound = 4.4 * max(P + N, (2 * P + N + S) / 2.0)
+        cpi = bound / max(1, sum(cnt.values()))
+        table[d] = round(cpi, 3)
+        print("%-70s instr %5d  bound %6.0f cycles  %.2f cycles/instr | %s" % (d[:70], sum(cnt.values()), bound, cpi, "  ".join("%s %d" % (c, cnt[c]) for c in sorted(cnt))))
+    if jpath:
+        import json
+        json.dump(table, open(jpath, "w"), indent=0, sort_keys=True)
 main()
