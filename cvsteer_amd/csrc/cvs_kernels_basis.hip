@@ -340,6 +340,9 @@ __device__ __forceinline__ void dma_warm(i4_t rsrc, unsigned voff, unsigned soff
 #define CVS_VMW8(a, b, c, d, e, f, g, h) CVS_VMW(a) CVS_VMW(b) CVS_VMW(c) CVS_VMW(d) CVS_VMW(e) CVS_VMW(f) CVS_VMW(g) CVS_VMW(h)
 __device__ __forceinline__ void wait_vmcnt(int n)
 {
+#ifdef CVS_DIAG_NOWAIT   // diagnostic twin only (WRONG results: rows are read before they have landed): what the launches would run at if a wave never had to wait for its
+    n = 63;              // older stores in order to see its row -- an upper bound for any scheme that decouples the input stream from vmcnt
+#endif
     switch (n < 63 ? n : 63) {
         CVS_VMW8(0, 1, 2, 3, 4, 5, 6, 7) CVS_VMW8(8, 9, 10, 11, 12, 13, 14, 15) CVS_VMW8(16, 17, 18, 19, 20, 21, 22, 23)
         CVS_VMW8(24, 25, 26, 27, 28, 29, 30, 31) CVS_VMW8(32, 33, 34, 35, 36, 37, 38, 39) CVS_VMW8(40, 41, 42, 43, 44, 45, 46, 47)

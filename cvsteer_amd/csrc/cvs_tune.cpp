@@ -77,7 +77,8 @@ int use_nt_stores(cvs_handle h, size_t npix)
 struct Cand {
     int order, strip;
     int merge = 0;   // G2 launches that write orientation planes: one 12-plane group instead of basis | orientation (cvs_handle.cpp layout_state)
-    bool operator==(const Cand& o) const { return order == o.order && strip == o.strip && merge == o.merge; }
+    int wg = -1;     // workgroups per CU; -1 = what default_config's rule says
+    bool operator==(const Cand& o) const { return order == o.order && strip == o.strip && merge == o.merge && wg == o.wg; }
 };
 
 struct TuneEntry {
@@ -113,6 +114,7 @@ static void apply(BasisArgs& a, const Cand& c)
     a.block_order = c.order;
     a.strip_rows = c.strip;
     a.merge_orient = c.merge;
+    if (c.wg >= 0) a.wg_per_cu = c.wg;
 }
 
 // a configuration decided for the bucket must fit THIS launch
@@ -290,6 +292,15 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     };
     const int nt = 2 * h->width + 1, halo = 2 * h->width;
     const int sr_short = 2 * nt - halo, sr_tall = 3 * nt - halo;
+    // Launches that write the orientation planes too (full setup, caller pipeline) and run capped at three workgroups per CU by the
+    // rule: whether three or five is faster flips from box to box (0.795 / 0.748 on one, 0.813 / 0.854 on the next; the pipeline
+    // 0.737 / 0.711 and 0.820 / 0.868; profiles/r05_occupancy_cap.txt) -- so five is the first challenger.  The basis pass and the
+    // fused steer keep their rule on every box measured.
+    if (h->kind == CVS_KIND_G2 && a.batch == 0 && a.wg_per_cu == 3 && a.orient != nullptr && env_opts().wgcap < 0) {
+        Cand c = def;
+        c.wg = 5;
+        e.cand.push_back(c);
+    }
     if (h->kind == CVS_KIND_G2) {
         if (fresh_input) {
             // a stream of new images: short strips are a must (the halo rows of vertically adjacent strips only hit in cache when

@@ -51,6 +51,6 @@ for hi in range(int(os.environ.get("PROBE_HANDLES", "3"))):
                 fn(); fn()
                 res[mode].append(timeit(fn))
         a, b = (bpp * npx / (statistics.median(res[m]) * 1e-3) / 8e12 for m in (1, 0))
-        print("handle %d %-13s tuned %.3f | default %.3f  (%+.1f %%)  decided after %3d calls (state %d): challenger kept %d -- order %d strip %d layout %d" %
-              (hi, name, a, b, 100 * (a / b - 1), calls, li["tune_state"], li["tuned"], li["block_order"], li["strip_rows"], li["state_layout"]), flush=True)
+        print("handle %d %-13s tuned %.3f | default %.3f  (%+.1f %%)  decided after %3d calls (state %d): challenger kept %d -- order %d strip %d layout %d wg %d" %
+              (hi, name, a, b, 100 * (a / b - 1), calls, li["tune_state"], li["tuned"], li["block_order"], li["strip_rows"], li["state_layout"], li["wg_per_cu"]), flush=True)
     del f, f4
