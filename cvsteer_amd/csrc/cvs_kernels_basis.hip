@@ -264,7 +264,7 @@ __device__ __forceinline__ rsrc_t plane_rsrc(const float* base, size_t bytes)
                                              (int)(bytes > kMaxPlaneBytes ? kMaxPlaneBytes : bytes), 0x00020000);
 }
 // cache policy of the streaming stores (aux bits of the buffer store on gfx94x / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt alone is the
-// product's; `make storepolicy` builds twins with other policies for tools/store_policy_probe.sh
+// product's (the other policies were measured in round 4: profiles/HISTORY_round_4.md); -DCVS_STREAM_AUX=n builds a twin with another one
 #ifndef CVS_STREAM_AUX
 #define CVS_STREAM_AUX 2
 #endif
