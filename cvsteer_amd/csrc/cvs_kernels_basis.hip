@@ -751,6 +751,16 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 if (stamp && !stamped_first) { stamped_first = true; if (lane == 0) stamp[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 #endif
+                // outputs-only batch: pitch, mask and plane offsets of the outputs are read from the kernel arguments HERE, a column pass and an
+                // epilogue ahead of the stores that use them (read at the stores, every row waited for the scalar cache), and not kept across rows
+                [[maybe_unused]] unsigned b2_pitch_b = 0, b2_mask = 0, b2_off[8] = {};
+                if constexpr (BATCH == 2 && (FLAGS & F_NOSTATE) != 0 && (FLAGS & F_PIPE) != 0) {
+                    const kernarg_ptr_t ka = kernarg_fresh();
+                    b2_pitch_b = (unsigned)(ka->out_pitch * sizeof(float));
+                    b2_mask = (FLAGS & F_FEAT3) != 0 ? 0xE0u : ka->out_mask;
+#pragma unroll
+                    for (int k = (FLAGS & F_FEAT3) != 0 ? 5 : 0; k < 8; ++k) b2_off[k] = ka->out_off[k];
+                }
                 float b[NB];
                 // window slots: the newest row is slot j, the centre row W back = slot (j + 1 + W) % NT
 #pragma unroll
@@ -848,14 +858,12 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         q[6] = __fmul_rn(en, ld);
                         q[7] = __fmul_rn(en, lb);
                         if constexpr (BATCH == 2) {
-                            if constexpr ((FLAGS & F_NOSTATE) != 0) {   // outputs only: the eight plane offsets are read per row, not kept (see the one-image
-                                                                        // form below; with the state planes written too that costs more scalar work than it saves)
-                                const kernarg_ptr_t ka = kernarg_fresh();
-                                const unsigned orow_out = yo * (unsigned)(ka->out_pitch * sizeof(float));
-                                const unsigned mask = FEAT3 ? 0xE0u : ka->out_mask;
+                            if constexpr ((FLAGS & F_NOSTATE) != 0) {   // outputs only: pitch and plane offsets were read at the top of this row's block (not kept across
+                                                                        // rows; with the state planes written too that costs more scalar work than it saves)
+                                const unsigned orow_out = yo * b2_pitch_b;
 #pragma unroll
                                 for (int k = FEAT3 ? 5 : 0; k < 8; ++k)
-                                    if (FEAT3 || (mask & (1u << k))) bst<STREAM>(r_out, xbr, orow_out + ka->out_off[k], q[k]);
+                                    if (FEAT3 || (b2_mask & (1u << k))) bst<STREAM>(r_out, xbr, orow_out + b2_off[k], q[k]);
                             } else {
                                 const unsigned orow_out = yo * (unsigned)(a.out_pitch * sizeof(float));
 #pragma unroll
