@@ -871,8 +871,7 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     a.z_ways = (!a.no_state && n >= 4) ? 2 : 1;
     // ... and on 10-row strips: round 3 sweep (profiles/r03_c4_strip_probe.txt), 32 x 1080p, five state blocks of the allocation lottery, one handle
     // each: against 19 rows in the plain order 0.634 / 0.70 / 0.70 / 0.796 / 0.795 for 0.644 / 0.70 / 0.70 / 0.762 / 0.764 --
-    // level on the slow and middle blocks, +4.5 % on the fast ones; the launch tuner then times the 19-row family and the
-    // weighted order (which wins another 3 % on the slow blocks)
+    // level on the slow and middle blocks, +4.5 % on the fast ones
     if (!a.no_state && n >= 4 && h->strip_rows <= 0) a.strip_rows = 2 * (2 * h->width + 1) - 2 * h->width;
     if (const int ways = env_opts().batch_ways; ways > 0) a.z_ways = std::max(1, std::min(n, ways));
     a.frame_stride = h->frame_stride;

@@ -6,7 +6,7 @@
 // and, in the fused epilogues, G2.cpp:70-99 (C1..C3, theta, strength), G2.cpp:137-145 /
 // G4.cpp:114-122 (scalar steer) and the callers' whole sequence test/test.cpp:86-90 (F_PIPE).
 //
-// Design (HBM-bound: 4 B read + 28/44 B written per pixel, ~102/290 VALU instructions per row):
+// Design (HBM-bound: 4 B read + 28/44 B written per pixel; ~46 / ~109 vector instructions per output row and wave, most of them packed):
 //  * one WAVE owns a strip 64 columns wide and `strip_rows` tall and marches down it; the four
 //    waves of a workgroup own four adjacent strips and never synchronise with each other.
 //  * per input row the wave issues one 256-B row load (+ one 2W-lane halo load) that lands DIRECTLY in the wave's ring of
@@ -16,6 +16,8 @@
 //  * the 6 (10) distinct row-filtered values enter a (2W+1)-deep sliding window held in
 //    VGPRs (the row loop is unrolled 2W+1 times so every window slot is a fixed register);
 //    the column pass runs on that window, also in folded symmetric / antisymmetric form.
+//  * both passes work on PAIRS -- a mirror and an anti-mirror kernel in the two halves of a register pair, v_pk_fma_f32 with
+//    tap pairs from SGPR pairs ("Packed f32" below): a tap multiply with a scalar operand costs the SIMD as much as a packed one.
 //  * the input is read once and every output plane is written once with 256-B row segments,
 //    nontemporal once the planes outgrow the Infinity Cache.
 //  * loads for the next 2W+1 rows are in flight while the current ones are filtered (the line
@@ -375,7 +377,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 // (~1 us) and one barrier at the START of a tail workgroup; the body is the same code as for the static orders.  Handing out
 // ALL tiles this way was measured too: 20-40 % slower (every workgroup then starts with that microsecond).
 // Measured (profiles/r04_order_probe.txt, six processes on one box): level with the plain order where that is at its best,
-// +3 % for the 12- and 20-plane launches in processes where the weighted order gains 5 %, +2 % for the G4 pair launch.
+// +3 % for the 12- and 20-plane launches in some processes, +2 % for the G4 pair launch.
 // Two sets of queues per handle, used alternately: a launch takes its tickets from one set and zeroes the OTHER one (which
 // the previous launch of the handle used; launches of a handle are ordered on its stream), so every launch finds its set at
 // zero without a host-side step, a reset kernel or a "last one out" protocol inside the launch.  (Under stream capture the
@@ -581,7 +583,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // G2: the plain basis / orientation / fused-steer variants (FLAGS 0..3) take the strength-reduced scalar bookkeeping and
     // the per-lane plane offsets as well (late round 3; ISA per nine rows, single-resource form: M1 995 -> 975 vector and
     // 655 -> 515 scalar instructions, no SGPR spills left; the headline's fused steer 1181 -> 1113 / 734 -> 583, spill moves
-    // 102 -> 28, 97 VGPRs = four waves per SIMD instead of five; headline loop +1 % on a placement window, +2-3 % on a plain
+    // 102 -> 28, 97 VGPRs = four waves per SIMD instead of five; headline loop +1-3 % on a plain
     // block, `profiles/r03_g2_sred_probe.txt`).  The pipeline variants keep the old bookkeeping: with the new one they spill.
     constexpr bool SRED = B::SRED || (B::KIND == 2 && FLAGS < 4);
     constexpr bool VOFF = B::VOFF || (B::KIND == 2 && FLAGS < 4);
@@ -946,9 +948,8 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
     __shared__ int s_tile;
     // Frame batches with state kept: the frames are dispatched dealt from z_ways equal parts of the batch in turn (0, n/2, 1,
     // n/2 + 1, ... for two), so that the frames in flight together -- about ten of 1080p -- have their state planes, inputs and
-    // outputs in DISTANT parts of the batch's blocks.  Same reason as the placement windows of cvs_state.cpp: planes written
-    // together stream faster when they come from two runs of the VRAM allocator than from one, and a 3 GB batch block spans
-    // more than one run.  profiles/r03_batch_ways_probe.txt, 32 x 1080p, same handles and buffers: a "slow" block 0.677 -> 0.752 of the HBM
+    // outputs in DISTANT parts of the batch's blocks: planes written together stream faster when they come from two runs of the
+    // VRAM allocator than from one, and a 3 GB batch block spans more than one run.  profiles/r03_batch_ways_probe.txt, 32 x 1080p, same handles and buffers: a "slow" block 0.677 -> 0.752 of the HBM
     // roofline, a "fast" one 0.717 -> 0.725; four / eight / sixteen parts give less (0.72 / 0.71 / 0.70).
     int bx = 0, by = 0;
     unsigned z = 0;

@@ -182,8 +182,8 @@ typedef struct cvs_launch_info {
     int32_t tuned;            /* 1 = the configuration above is a challenger the online tuner decided for; 0 = the engine's default */
     int32_t tune_state;       /* the online tuner for this launch's key: 0 = off / not a tunable launch, 1 = still comparing on the
                                  caller's launches, 2 = decided */
-    int32_t wg_per_cu;        /* last basis launch: workgroups per CU it was held to (the fused steer 3, the caller pipeline 4 on single G2
-                                 images of 2-32 Mpix: fewer write fronts); 0 = no cap */
+    int32_t wg_per_cu;        /* last basis launch: workgroups per CU it was held to (single G2 images of 2 Mpix and more: three or four
+                                 instead of the six the registers allow -- fewer write fronts); 0 = no cap */
 } cvs_launch_info;
 int cvs_get_launch_info(cvs_handle h, cvs_launch_info* out);
 /* the handle's idx-th tap vector (m_g1.. members), 2*width+1 floats */
