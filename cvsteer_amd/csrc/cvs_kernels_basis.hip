@@ -941,6 +941,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #endif
 }
 
+// (BasisArgs must stay the FIRST parameter of both strip kernels: kernarg_fresh() reads it at offset 0 of the kernel-argument segment)
 template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int WPB = 4, bool U8 = false>
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
 {
