@@ -499,6 +499,16 @@ def main():
                 for _try in range(5):   # the main thread may be adding a leg at this very moment (watchdog / SIGTERM path)
                     try:
                         snap = dict(out)
+                        # the same figures once more in the nested form the round-4 verdict named (roofline.m1.frac, roofline.fresh.frac ...);
+                        # the flat keys stay: whoever keeps only scalars of `roofline` still has them
+                        rfn = dict(snap.get("roofline") or {})
+                        if "m1_frac" in rfn:
+                            rfn["m1"] = {"frac": rfn["m1_frac"], "avg_launch_ms": rfn.get("m1_ms"), "ms_min": rfn.get("m1_ms_min"), "ms_max": rfn.get("m1_ms_max")}
+                        for nm in ("fresh", "one_object", "first_call", "after_idle"):
+                            if nm + "_frac" in rfn:
+                                rfn[nm] = {"frac": rfn[nm + "_frac"]}
+                        if rfn:
+                            snap["roofline"] = rfn
                         if legs:
                             snap["legs_fmt"] = "[frac_hbm, ms, ms_min, ms_max, launch_configs index, frac_valu]"
                             snap["legs"] = dict(legs)
