@@ -22,8 +22,8 @@ The ONE JSON line (round 5: <= 6 KB, so that it survives the driver's 8 KB tail)
     run with --all-legs.
 
 Multi-GPU: the image/batch axis shards with no data-path collective -- every rank filters its own images (weak scaling); RCCL
-is used for the barrier and the max-over-ranks reduction, for a start-up self-test (one 1080p frame per rank through
-ncclSend/ncclRecv, bytes compared) and in the `C4_e2e` leg for the scatter of frames from rank 0 and the gather of results.
+is used for the barrier and the max-over-ranks reduction, for a self-test of the transport (one 1080p frame per rank through
+ncclSend/ncclRecv, bytes compared; after the headline and M1, which use no transport, and before every leg that does) and in the `C4_e2e` leg for the scatter of frames from rank 0 and the gather of results.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
         N > 1 without WORLD_SIZE in the environment: this process starts N rank processes
@@ -553,38 +553,10 @@ def main():
                     break
         torch.cuda.synchronize()
 
-    # ---- start-up self-test of the transport (runs of several ranks on distinct GPUs): one 1080p frame per rank through the
-    # native batch layer's ncclSend / ncclRecv, results compared bit for bit with rank 0's own single-GPU run ----
+    # (the transport self-test runs right after the headline and M1 -- which touch no transport: images per rank, no collective on the data
+    # path -- and BEFORE every leg that uses the batch layer, under the watchdog that guards those legs: a transport that hangs must not
+    # take the headline with it)
     mg = {"rccl_ranks": ws if (ws > 1 and not test_backend) else 0, "transport": "none", "selftest": "n/a"}
-    if ws > 1 and not test_backend:
-        try:
-            nb0 = batch.NativeBatch.from_torch_distributed(local_rank)
-            mg["transport"] = nb0.transport
-            if distinct and nb0.transport != "rccl":
-                raise RuntimeError("ranks on distinct GPUs but transport %r" % nb0.transport)
-            nb0.set_persist(False)
-            frames = torch.rand((ws, 1080, 1920), generator=torch.Generator(device=dev).manual_seed(77), device=dev) if rank == 0 else None
-            res = torch.empty((ws, 3, 1080, 1920), device=dev) if rank == 0 else None
-            nb0.run(frames, ws, (1080, 1920), outputs=(5, 6, 7), out=res)
-            ok = 1.0
-            if rank == 0:
-                fr_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
-                fr_.set_persist(False)
-                want = fr_.pipeline_batch(frames, outputs=(5, 6, 7))
-                torch.cuda.synchronize()
-                ok = 1.0 if torch.equal(want, res) else 0.0
-                del fr_, want
-            (bad,) = max_over_ranks(1.0 - ok)
-            mg["selftest"] = "ok" if bad == 0.0 else "MISMATCH"
-            nb0.close()
-            del frames, res
-            if bad != 0.0:
-                raise SystemExit("bench.py: frames sent through ncclSend/ncclRecv came back different from the single-GPU run")
-        except SystemExit:
-            raise
-        except Exception as ex:
-            mg["selftest"] = "error: %s: %s" % (type(ex).__name__, str(ex)[:80])
-
     settle(step, f)
     R = max(1, args.repeats)
     walls, evs = _time_steps(torch, step, args.steps, args.warmup, barrier, repeats=R)
@@ -670,6 +642,36 @@ def main():
     def run_extras():
         if os.environ.get("CVS_BENCH_TEST_CRASH_RANK") == str(rank):   # tests only: a rank that dies inside the secondary legs
             os._exit(17)
+        # ---- self-test of the transport before any leg uses it (runs of several ranks on distinct GPUs): one 1080p frame per rank
+        # through the native batch layer's ncclSend / ncclRecv, results compared bit for bit with rank 0's own single-GPU run.  Every rank
+        # reaches the agreement collective below exactly once, whatever happened to it before.
+        if ws > 1 and not test_backend:
+            ok, err = 1.0, None
+            try:
+                nb0 = batch.NativeBatch.from_torch_distributed(local_rank)
+                mg["transport"] = nb0.transport
+                if distinct and nb0.transport != "rccl":
+                    raise RuntimeError("ranks on distinct GPUs but transport %r" % nb0.transport)
+                nb0.set_persist(False)
+                frames = torch.rand((ws, 1080, 1920), generator=torch.Generator(device=dev).manual_seed(77), device=dev) if rank == 0 else None
+                res = torch.empty((ws, 3, 1080, 1920), device=dev) if rank == 0 else None
+                nb0.run(frames, ws, (1080, 1920), outputs=(5, 6, 7), out=res)
+                if rank == 0:
+                    fr_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
+                    fr_.set_persist(False)
+                    want = fr_.pipeline_batch(frames, outputs=(5, 6, 7))
+                    torch.cuda.synchronize()
+                    ok = 1.0 if torch.equal(want, res) else 0.0
+                    del fr_, want
+                nb0.close()
+                del frames, res
+            except Exception as ex:
+                err = "error: %s: %s" % (type(ex).__name__, str(ex)[:80])
+            (bad, failed) = max_over_ranks(1.0 - ok, 1.0 if err else 0.0)
+            mg["selftest"] = err or ("error on another rank" if failed else ("ok" if bad == 0.0 else "MISMATCH"))
+            rf.update({"transport": mg["transport"], "rccl_selftest": mg["selftest"]})
+            if bad != 0.0:
+                raise RuntimeError("frames sent through ncclSend/ncclRecv came back different from the single-GPU run")
         ksteps, kwarm = args.steps, max(5, args.warmup)
         LR = max(1, args.leg_repeats)
 
