@@ -1090,7 +1090,11 @@ bool basis_may_need_scratch(int kind, int width, const float (*taps)[kMaxTaps], 
 // that every XCD gets the same number
 static unsigned dynamic_blocks(size_t ntiles, int* dyn_static)
 {
-    constexpr int pct = 25, tail_pct = 10;
+    constexpr int pct = 25;
+    int tail_pct = 10;
+#ifdef CVS_DIAG_STAMPS   // diagnostic twin only (tools/k1_timeline.py): how long a tail balances the XCDs, and what that is worth
+    if (const char* e = std::getenv("CVS_DIAG_TAIL_PCT")) tail_pct = std::max(1, std::min(100, std::atoi(e)));
+#endif
     const size_t tail = std::max<size_t>(8, ntiles * tail_pct / 100);
     const size_t stat = ntiles > tail ? (ntiles - tail) / 8 * 8 : 0;
     *dyn_static = (int)stat;
