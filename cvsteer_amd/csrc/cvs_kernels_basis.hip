@@ -461,9 +461,12 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 {
     constexpr unsigned EB = U8 ? 1u : 4u;   // bytes per input sample
     constexpr int W = B::W, NT = 2 * W + 1, NB = B::NB;
-    // packed arithmetic everywhere but in the three-maps-only pipeline: packed instructions take the whole SIMD, plain ones with a scalar tap leave
-    // its second half to another wave's tap-free instructions, and that variant's long epilogue is made of those (see "Packed f32")
-    constexpr bool PK = (FLAGS & F_FEAT3) == 0;
+    // packed arithmetic everywhere but in the pipeline variants (F_PIPE): a packed instruction takes the whole SIMD, a plain one with a scalar tap
+    // leaves its second half to another wave's tap-free instructions, and the pipeline's long epilogue is made of those (see "Packed f32").
+    // Measured: the three-maps-only batch 9 % slower packed; the single-image pipeline level on two boxes and 11 % slower packed on a third,
+    // the eight-outputs-only batch 4 % slower packed (profiles/r05_packed_ab.txt, table 7).  The orientation-only epilogue (full setup) is
+    // level to 1 % ahead packed and stays packed.
+    constexpr bool PK = (FLAGS & F_PIPE) == 0;
     // vector-memory instructions per output row that EVERY launch of this variant issues (state planes, fused steer, the three
     // maps of FEAT3; outputs selected at run time are not counted): a lower bound is all the hand-counted waits need
     constexpr int S_ROW = (((FLAGS & F_NOSTATE) == 0 && (FLAGS & F_PYRONLY) == 0) ? NB : 0) +

@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 from helpers import EDGE_SHAPES, angle_diff, rand_image, smooth_image
+from cvsteer_amd import _lib as L_
 
 pytestmark = pytest.mark.gpu
 
@@ -1475,27 +1476,35 @@ def test_one_object_per_image_per_worker_thread(cv):
 
 @pytest.mark.parametrize("shape", [(64, 130), (185, 256), (540, 960)])
 def test_packed_and_plain_arithmetic_agree_bit_for_bit(cv, shape):
-    """The strip kernels filter with packed f32 pairs (v_pk_fma_f32: a mirror and an anti-mirror kernel in the halves of a register
-    pair); the three-maps-only batch variant keeps plain instructions (cvs_kernels_basis.hip, "Packed f32").  Same operations in the
-    same order per result, so the two must agree BIT FOR BIT: the three feature maps of an outputs-only batch asking for exactly those
-    (plain arithmetic) against the same maps of a batch asking for all eight outputs (packed arithmetic) and against the single-image
-    pipeline (packed, state kept), on random frames with a few non-finite pixels."""
+    """The basis, fused-steer and full-setup launches filter with packed f32 pairs (v_pk_fma_f32: a mirror and an anti-mirror kernel in
+    the halves of a register pair); the pipeline variants keep plain instructions (cvs_kernels_basis.hip, "Packed f32").  Same
+    operations in the same order per result, so the two must agree BIT FOR BIT: the twelve state planes a full setup writes (packed)
+    against the ones the caller pipeline leaves behind (plain), and the feature maps of the three pipeline forms among themselves,
+    on random frames with a few non-finite pixels."""
     import torch
     rows, cols = shape
     gen = torch.Generator(device="cuda").manual_seed(rows * 7 + cols)
     frames = torch.rand((3, rows, cols), device="cuda", generator=gen) * 255.0
     frames[1, rows // 2, cols // 3] = float("inf")
     frames[2, 5, 7] = float("nan")
-    plain, packed = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
-    plain.set_persist(False)
-    packed.set_persist(False)
-    three = plain.pipeline_batch(frames, outputs=(5, 6, 7))
-    eight = packed.pipeline_batch(frames)
-    single = cv.SteerableFiltersG2(None)
+
+    def same(a, b):
+        return torch.equal(a.isnan(), b.isnan()) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+    three_h, eight_h = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
+    three_h.set_persist(False)
+    eight_h.set_persist(False)
+    three = three_h.pipeline_batch(frames, outputs=(5, 6, 7))
+    eight = eight_h.pipeline_batch(frames)
+    packed, plain = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
     for i in range(3):
-        one = single.pipeline(frames[i].contiguous())
+        img = frames[i].contiguous()
+        packed.setup(img, flags=cv.SETUP_FULL)                    # FLAGS 1: packed arithmetic
+        one = plain.pipeline(img)                                  # FLAGS 5: plain arithmetic, state kept
+        for p in list(range(7)) + [L_.PLANE_C1, L_.PLANE_C2, L_.PLANE_C3, L_.PLANE_THETA, L_.PLANE_STRENGTH]:
+            assert same(packed._state(p), plain._state(p)), (i, "state plane", p)
+        g, h = packed.setup_steer(img, 0.3, flags=cv.SETUP_BASIS)  # FLAGS 2: packed, fused scalar steer
+        for p in range(7):
+            assert same(packed._state(p), plain._state(p)), (i, "state plane after the fused steer", p)
         for k in range(3):
-            a, b, c = three[i, k], eight[i, 5 + k], one[5 + k]
-            assert torch.equal(a.isnan(), b.isnan()) and torch.equal(a.isnan(), c.isnan()), (i, k)
-            assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (i, k, "outputs-only batches")
-            assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(c)), (i, k, "single image")
+            assert same(three[i, k], eight[i, 5 + k]) and same(three[i, k], one[5 + k]), (i, k)
