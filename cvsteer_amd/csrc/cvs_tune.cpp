@@ -292,11 +292,13 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
     };
     const int nt = 2 * h->width + 1, halo = 2 * h->width;
     const int sr_short = 2 * nt - halo, sr_tall = 3 * nt - halo;
-    // Launches that write the orientation planes too (full setup, caller pipeline) and run capped at three workgroups per CU by the
-    // rule: whether three or five is faster flips from box to box (0.795 / 0.748 on one, 0.813 / 0.854 on the next; the pipeline
-    // 0.737 / 0.711 and 0.820 / 0.868; profiles/r05_occupancy_cap.txt) -- so five is the first challenger.  The basis pass and the
-    // fused steer keep their rule on every box measured.
-    if (h->kind == CVS_KIND_G2 && a.batch == 0 && a.wg_per_cu == 3 && a.orient != nullptr && env_opts().wgcap < 0) {
+    // The caller pipeline runs capped at three workgroups per CU by the rule; whether three or five is faster flips from box to box
+    // (0.737 / 0.711 on one, 0.820 / 0.868 on the next; profiles/r05_occupancy_cap.txt) -- so five is its first challenger, kept in 4 of
+    // 13 bench processes at 0.80-0.82 where the others sit at 0.76-0.77.  NOT for the full setup: there the challenger won the
+    // interleaved samples in 13 of 13 bench processes and then ran 3 % behind the rule in the 8 of them whose plane groups lie badly
+    // (0.74 against 0.765; profiles/r05_bench_lines*.jsonl), although it is 5-6 % ahead sustained in processes with nothing else
+    // allocated (profiles/r05_tuner_value_probe.txt).  The basis pass and the fused steer keep their rule on every box measured.
+    if (h->kind == CVS_KIND_G2 && a.batch == 0 && a.wg_per_cu == 3 && a.pipe && env_opts().wgcap < 0) {
         Cand c = def;
         c.wg = 5;
         e.cand.push_back(c);
