@@ -109,7 +109,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     // the pipeline variants keep the taller strips (round 1 shape sweep)
     // (a handle's FIRST call counts as a fresh image too: the reference's callers build one object per image,
     // example/steer.cpp:86 -- only a handle that is handed the same pointer again is re-filtering a resident image)
-    const bool fresh = h->last_image != (const void*)image->data && !pipe_outs;
+    const bool fresh = (h->last_image != (const void*)image->data || (env_opts().warm_any & 16)) && !pipe_outs;   // (16: experiment, every image counts as new)
     h->last_image = image->data;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols, fresh);
     // New G2 images of 24 MiB and more: the waves of the launch's first fifth of row bands also touch the rest of the image (four
@@ -124,7 +124,11 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     {
         const size_t in_bytes = (size_t)a.rows * a.cols * (a.in_u8 ? 1 : sizeof(float));
         const int wk = env_opts().warm;
-        a.warm_k = (fresh && h->kind == CVS_KIND_G2 && !pyr && in_bytes >= ((size_t)24 << 20)) ? (wk >= 0 ? wk : 4) : 0;
+        const int any = env_opts().warm_any;   // experiment: 1 = also launches that emit a pyramid level, 2 = G4, 4 = 8-bit images (by pixel count)
+        const bool big = (a.in_u8 && (any & 4)) ? (size_t)a.rows * a.cols >= ((size_t)6 << 20) : in_bytes >= ((size_t)24 << 20);
+        const bool pyr_fused = pyr && env_opts().pyr_split <= 0;
+        a.warm_k = (fresh && (h->kind == CVS_KIND_G2 || (any & 2)) && (!pyr_fused || (any & 1)) && big) ? (wk >= 0 ? wk : 4) : 0;
+        a.warm_exact = env_opts().warm_exact > 0 ? 1 : 0;
     }
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     a.diag = h->diag;
@@ -151,6 +155,7 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         if ((rc = out_ref(c, pyr, rp))) return rc;
         a.pyr_out = rp.p;
         a.pyr_pitch = rp.pitch;
+        a.pyr_nt = env_opts().pyr_nt > 0 ? 1 : 0;
     }
     float* scr = scratch ? arena_take(h, scratch) : nullptr;
     if (overlap) {
@@ -169,9 +174,18 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
             fill_state_args(h, a, orient_k);
         }
         note_launch(h, a);
+        // experiment (CVS_OPTS pyr_split=1): the level's image is made by a strip march of its own behind the filter launch
+        float* const pyr_later = (a.pyr_out && env_opts().pyr_split > 0) ? a.pyr_out : nullptr;
+        if (pyr_later) a.pyr_out = nullptr;
         const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, scr, h->stream);
         tune_end(h, tok);
         HIP_TRY(h, le);
+        if (pyr_later) {
+            hipError_t pe = hipSuccess;
+            if (!launch_pyr_strip(a.in, a.in_pitch, a.rows, a.cols, pyr_later, a.pyr_pitch, h->stream, &pe))
+                pe = launch_pyr_down(a.in, a.in_pitch, a.rows, a.cols, pyr_later, a.pyr_pitch, h->stream);
+            HIP_TRY(h, pe);
+        }
     }
     if ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G4) {  // extension: one per-pixel pass over the 11 planes
         PointArgs pa{};
@@ -401,7 +415,7 @@ int cvs_set_option(cvs_handle h, int option, int value)
             h->host_overlap = value;
             return CVS_OK;
         case CVS_OPT_STATE_LAYOUT:
-            if (value < 0 || value > 2) return fail(h, CVS_E_BADARG, "state layout");
+            if (value < 0 || value > 3) return fail(h, CVS_E_BADARG, "state layout");
             h->layout = value;
             return CVS_OK;
     }
@@ -875,6 +889,10 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     if (!a.no_state && n >= 4 && h->strip_rows <= 0) a.strip_rows = 2 * (2 * h->width + 1) - 2 * h->width;
     if (const int ways = env_opts().batch_ways; ways > 0) a.z_ways = std::max(1, std::min(n, ways));
     a.frame_stride = h->frame_stride;
+    if (env_opts().warm_any & 8) {   // experiment: every frame of the batch is a new image; its first bands request the rest of the FRAME ahead
+        a.warm_k = env_opts().warm >= 0 ? env_opts().warm : 4;
+        a.warm_exact = env_opts().warm_exact > 0 ? 1 : 0;
+    }
     TuneToken tok;
     if ((rc = tune_begin(h, a, 16 | 1 | 4 | (a.no_state ? 8 : 0), false, tok))) return rc;
     note_launch(h, a);

@@ -49,12 +49,16 @@ EnvOpts env_opts()
         const std::string name = item.substr(0, eq);
         const long val = std::atol(item.c_str() + eq + 1);
         if (name == "autotune") v.autotune = val != 0;
-        else if (name == "layout") v.layout = (int)std::max(0L, std::min(2L, val));
+        else if (name == "layout") v.layout = (int)std::max(0L, std::min(3L, val));
         else if (name == "pyr_strip") v.pyr_strip = val != 0;
         else if (name == "batch_ways") v.batch_ways = (int)std::max(1L, val);
         else if (name == "nt_stores") v.nt_stores = val != 0;
         else if (name == "warm") v.warm = (int)std::max(0L, std::min(16L, val));
         else if (name == "wgcap") v.wgcap = (int)std::max(0L, std::min(8L, val));
+        else if (name == "warm_exact") v.warm_exact = val != 0;
+        else if (name == "warm_any") v.warm_any = (int)val;
+        else if (name == "pyr_nt") v.pyr_nt = val != 0;
+        else if (name == "pyr_split") v.pyr_split = val != 0;
         else if (name == "verbose") v.verbose = val != 0;
         else if (name == "pool_mb") v.pool_mb = val;
         else std::fprintf(stderr, "[cvsteer] CVS_OPTS: unknown name '%s' ignored\n", name.c_str());

@@ -301,6 +301,10 @@ __device__ __forceinline__ i4_t raw_rsrc(const void* base, size_t bytes)
     r.w = 0x00020000;
     return r;
 }
+// (M0 is written here behind the compiler's back.  It cannot be declared: M0 is a reserved register for this target and clang ignores
+// -- and warns about -- a clobber of it.  The compiler itself writes M0 only right in front of an instruction that reads it (LDS-DMA
+// intrinsics, s_movrel, sendmsg, GWS), none of which these kernels contain; tests/test_isa_cpu.py disassembles the built object and
+// fails if any instruction other than the three below touches M0.)
 // both loads of one input row into the ring line at LDS byte address `lds_line` (s_nop: one wait state between an SALU write of
 // M0 and the LDS-DMA that reads it, which the assembler does not insert inside inline assembly).  8-bit images: the byte load
 // writes the zero-extended sample as a dword, and the lanes convert what they read back (cv::Mat1f(const Mat&), unscaled).
@@ -338,12 +342,29 @@ __device__ __forceinline__ void dma_warm(i4_t rsrc, unsigned voff, unsigned soff
 }
 // s_waitcnt vmcnt(n) for an n that is a constant once the row loop is unrolled (the instruction takes an immediate; the counter
 // has 6 bits, and a smaller n only waits longer)
+#ifdef CVS_DIAG_CANARY
+// Canary twin (make canary; tests/test_gpu_canary.py): a DIRECT check of the hand-counted waits.  Every ring line is filled with a
+// pattern no image contains before the load that refills it is issued; a lane that still reads the pattern behind the
+// s_waitcnt vmcnt(N) that is supposed to cover the row has caught a count that is too high (or an LDS-DMA load that retires from
+// the counter before its data is in the LDS).  The twin also tallies the vector-memory stores of every output row against S_ROW,
+// the compile-time lower bound the counts are built from.  g_canary: [0] stale words read, [1] output rows with fewer stores
+// than S_ROW, [2] row reads checked, [3] output rows tallied.  -DCVS_DIAG_CANARY_SLACK=k builds the twin's twin whose counts
+// are k too high: it MUST trip the canary.
+__device__ unsigned long long g_canary[4];
+constexpr unsigned kCanary = 0x7fc0dead;   // a quiet NaN with a payload; as an integer it is no 8-bit sample either
+#ifndef CVS_DIAG_CANARY_SLACK
+#define CVS_DIAG_CANARY_SLACK 0
+#endif
+#endif
 #define CVS_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 #define CVS_VMW8(a, b, c, d, e, f, g, h) CVS_VMW(a) CVS_VMW(b) CVS_VMW(c) CVS_VMW(d) CVS_VMW(e) CVS_VMW(f) CVS_VMW(g) CVS_VMW(h)
 __device__ __forceinline__ void wait_vmcnt(int n)
 {
 #ifdef CVS_DIAG_NOWAIT   // diagnostic twin only (WRONG results: rows are read before they have landed): what the launches would run at if a wave never had to wait for its
     n = 63;              // older stores in order to see its row -- an upper bound for any scheme that decouples the input stream from vmcnt
+#endif
+#ifdef CVS_DIAG_CANARY
+    n += CVS_DIAG_CANARY_SLACK;
 #endif
     switch (n < 63 ? n : 63) {
         CVS_VMW8(0, 1, 2, 3, 4, 5, 6, 7) CVS_VMW8(8, 9, 10, 11, 12, 13, 14, 15) CVS_VMW8(16, 17, 18, 19, 20, 21, 22, 23)
@@ -456,6 +477,11 @@ __device__ __forceinline__ bool pick_tile(const BasisArgs& a, int* s_tile, int& 
 // and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones; one- and
 // two-wave workgroups fill the wave slots better (no slot waits for the slowest of four) but lose 3-12 % on the G2 legs and
 // 7 % on fresh images (profiles/r03_wpb_probe.txt): the four strips of a workgroup write 1 KiB of every plane row from one CU.
+#ifdef CVS_DIAG_CANARY
+#define CVS_BST(ST, ...) (++st_tally, bst<ST>(__VA_ARGS__))
+#else
+#define CVS_BST(ST, ...) bst<ST>(__VA_ARGS__)
+#endif
 template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB, bool U8 = false>
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe, const int bx, const int by)
 {
@@ -583,6 +609,22 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 
     const int nrows_in = (yend - y0) + 2 * W;
     const int ngroups = (nrows_in + NT - 1) / NT;
+#ifdef CVS_DIAG_CANARY
+    [[maybe_unused]] unsigned st_tally = 0;
+    unsigned cn_stale = 0, cn_short = 0, cn_reads = 0, cn_rows = 0;
+    // a ring line filled with the pattern (before the load that refills it is issued; the pattern must be in the LDS before that load can land)
+    // (ds_write by hand: a store through the generic `line` pointer could become a FLAT store, which counts in vmcnt as well and would
+    // change the very counts under test)
+    auto poison = [&](int jl) {
+        const unsigned ad = lds_lane + (unsigned)(jl * kRingLine * 4), pat = kCanary;
+        asm volatile("ds_write_b32 %0, %1" : : "v"(ad), "v"(pat) : "memory");
+        const unsigned ad2 = lane < 2 * W ? ad + 256u : ad;   // (no branch: lanes without a halo word write their own word twice)
+        asm volatile("ds_write_b32 %0, %1" : : "v"(ad2), "v"(pat) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+#pragma unroll
+    for (int j = 0; j < NT; ++j) poison(j);
+#endif
     // G2: the plain basis / orientation / fused-steer variants (FLAGS 0..3) take the strength-reduced scalar bookkeeping and
     // the per-lane plane offsets as well (late round 3; ISA per nine rows, single-resource form: M1 995 -> 975 vector and
     // 655 -> 515 scalar instructions, no SGPR spills left; the headline's fused steer 1181 -> 1113 / 734 -> 583, spill moves
@@ -646,7 +688,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 // so none in group 0, j + 1 of them in group 1, NT from group 2 on.  (Steps past the strip's last row wait for a
                 // row nobody uses; their count may be short, which only lets them read a line that is still being written.)
                 if constexpr (PHASE == 0) {
-                    if (nwarm >= NT) wait_vmcnt(VM_ROWS + NT);   // (at least) that many warm loads were issued behind the first rows
+                    // window priming: behind row j's halo load lie the loads of the NT - 1 - j first rows that followed it, the nwarm
+                    // read-ahead loads and the j refills issued since -- VM_ROWS + nwarm at every step (56 at most: the counter has 6 bits)
+                    if (nwarm > 0 && a.warm_exact) wait_vmcnt(VM_ROWS + nwarm);
+                    else if (nwarm >= NT) wait_vmcnt(VM_ROWS + NT);
                     else wait_vmcnt(VM_ROWS);
                 }
                 else if (VM_ROWS + S_ROW * (j + 1) >= 63) wait_vmcnt(63);   // (a constant once the loop is unrolled)
@@ -664,6 +709,16 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int i = 0; i <= W; ++i) asm volatile("" : "+v"(P[i]));   // (the compiler does not know that the reads are asynchronous: nothing that uses them may move above the wait)
+#ifdef CVS_DIAG_CANARY
+                if (g * NT + j < nrows_in) {   // a row the strip really uses (steps past the last one read a line nobody needs)
+                    unsigned st = 0;
+#pragma unroll
+                    for (int i = 0; i <= W; ++i) st += (__float_as_uint(P[i].x) == kCanary ? 1u : 0u) + ((i && __float_as_uint(P[i].y) == kCanary) ? 1u : 0u);
+                    cn_stale += st;
+                    ++cn_reads;
+                }
+                poison(j);
+#endif
                 if constexpr (U8) {
 #pragma unroll
                     for (int i = 0; i <= W; ++i) {   // the line holds the samples as integers 0..255
@@ -694,7 +749,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 const int ci = g * NT + j - W - 2;  // centre row relative to y0, wave-uniform
                 if (ci >= 0 && ci < yend - y0 && ((y0 + ci) & 1) == 0) {
                     const float v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(hw2, 6.0f), __fmul_rn(__fadd_rn(hw1, hw3), 4.0f)), hw0), hw4);
-                    bst<false>(r_pyr, xpb, (unsigned)((y0 + ci) >> 1) * pyr_pitch_b, __fmul_rn(v, 1.0f / 256.0f));
+                    if (a.pyr_nt) CVS_BST(true, r_pyr, xpb, (unsigned)((y0 + ci) >> 1) * pyr_pitch_b, __fmul_rn(v, 1.0f / 256.0f));
+                    else CVS_BST(false, r_pyr, xpb, (unsigned)((y0 + ci) >> 1) * pyr_pitch_b, __fmul_rn(v, 1.0f / 256.0f));
                 }
             }
             if constexpr ((FLAGS & F_PYRONLY) == 0) {
@@ -751,6 +807,9 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
             if (PHASE == 0 && j < 2 * W) row_ok = false;   // window priming (what the run-time test says anyway): no column-pass code in these steps
             const unsigned xbr = xb;
             if (row_ok) {
+#ifdef CVS_DIAG_CANARY
+                const unsigned st_row0 = st_tally;
+#endif
 #ifdef CVS_DIAG_STAMPS
 #ifndef CVS_DIAG_CLOCK
                 if (stamp && !stamped_first) { stamped_first = true; if (lane == 0) stamp[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -821,11 +880,11 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     for (int p = 0; p < NB; ++p) {
                         const bool second = B::PLANE0 + p >= SPLIT;   // compile-time per plane
                         const unsigned orw = second ? orow2 : orow;
-                        if constexpr (ONE && VOFF) bst<STREAM>(r_state, xbp[p], orw, b[p]);
+                        if constexpr (ONE && VOFF) CVS_BST(STREAM, r_state, xbp[p], orw, b[p]);
                         else if constexpr (ONE)
-                            bst<STREAM>(r_state, xbr, orw + (second ? off2_b + (unsigned)(B::PLANE0 + p - SPLIT) * pstride2_b : (unsigned)(B::PLANE0 + p) * pstride_b), b[p]);
-                        else if (second) bst<STREAM>(plane_rsrc(basis2_p + (size_t)(B::PLANE0 + p - SPLIT) * a.plane_stride2, plane2_bytes), xbr, orw, b[p]);
-                        else bst<STREAM>(plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orw, b[p]);
+                            CVS_BST(STREAM, r_state, xbr, orw + (second ? off2_b + (unsigned)(B::PLANE0 + p - SPLIT) * pstride2_b : (unsigned)(B::PLANE0 + p) * pstride_b), b[p]);
+                        else if (second) CVS_BST(STREAM, plane_rsrc(basis2_p + (size_t)(B::PLANE0 + p - SPLIT) * a.plane_stride2, plane2_bytes), xbr, orw, b[p]);
+                        else CVS_BST(STREAM, plane_rsrc(basis_p + (size_t)(B::PLANE0 + p) * a.plane_stride, plane_bytes), xbr, orw, b[p]);
                     }
                 }
                 if constexpr ((FLAGS & F_ORIENT) != 0 && B::KIND == 2) {
@@ -840,8 +899,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         const float ov[5] = {c1, c2, c3, th, st};
 #pragma unroll
                         for (int k = 0; k < 5; ++k)
-                            if constexpr (ONE) bst<STREAM>(r_state, xbr, orow_o + ooff_b + (unsigned)k * ostride_b, ov[k]);
-                            else bst<STREAM>(plane_rsrc(orient_p + (size_t)k * a.orient_stride, oplane_bytes), xbr, orow_o, ov[k]);
+                            if constexpr (ONE) CVS_BST(STREAM, r_state, xbr, orow_o + ooff_b + (unsigned)k * ostride_b, ov[k]);
+                            else CVS_BST(STREAM, plane_rsrc(orient_p + (size_t)k * a.orient_stride, oplane_bytes), xbr, orow_o, ov[k]);
                     }
                     if constexpr ((FLAGS & F_PIPE) != 0) {
                         // the callers' sequence (test/test.cpp:86-90) on values still in registers:
@@ -868,12 +927,12 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                                 const unsigned orow_out = yo * b2_pitch_b;
 #pragma unroll
                                 for (int k = FEAT3 ? 5 : 0; k < 8; ++k)
-                                    if (FEAT3 || (b2_mask & (1u << k))) bst<STREAM>(r_out, xbr, orow_out + b2_off[k], q[k]);
+                                    if (FEAT3 || (b2_mask & (1u << k))) CVS_BST(STREAM, r_out, xbr, orow_out + b2_off[k], q[k]);
                             } else {
                                 const unsigned orow_out = yo * (unsigned)(a.out_pitch * sizeof(float));
 #pragma unroll
                                 for (int k = 0; k < 8; ++k)
-                                    if (a.out_mask & (1u << k)) bst<STREAM>(r_out, xbr, orow_out + a.out_off[k], q[k]);
+                                    if (a.out_mask & (1u << k)) CVS_BST(STREAM, r_out, xbr, orow_out + a.out_off[k], q[k]);
                             }
                         } else {
 #pragma unroll
@@ -889,7 +948,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                                     po.p = ka->pipe_out[k].p;
                                     po.pitch = ka->pipe_out[k].pitch;
                                 }
-                                if (FEAT3 || po.p) bst<STREAM>(plane_rsrc(po.p, kMaxPlaneBytes), xbr, yo * (unsigned)(po.pitch * sizeof(float)), q[k]);
+                                if (FEAT3 || po.p) CVS_BST(STREAM, plane_rsrc(po.p, kMaxPlaneBytes), xbr, yo * (unsigned)(po.pitch * sizeof(float)), q[k]);
                             }
                         }
                     }
@@ -905,20 +964,24 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                         static_assert(B::KIND == 2, "the whole-bank form exists for G2 only");
                         float gq, hq;
                         g2_steer_weights(b, a.steer_w, gq, hq);
-                        bst<STREAM>(rg, xbr, og, gq);
-                        bst<STREAM>(rh, xbr, oh, hq);
+                        CVS_BST(STREAM, rg, xbr, og, gq);
+                        CVS_BST(STREAM, rh, xbr, oh, hq);
                     } else if constexpr (B::HALF == 1) {  // the G sum of G2.cpp:143 / G4.cpp:120, left to right
                         float gq = __fadd_rn(__fmul_rn(a.steer_w[0], b[0]), __fmul_rn(a.steer_w[1], b[1]));
 #pragma unroll
                         for (int p = 2; p < NB; ++p) gq = __fadd_rn(gq, __fmul_rn(a.steer_w[p], b[p]));
-                        bst<STREAM>(rg, xbr, og, gq);
+                        CVS_BST(STREAM, rg, xbr, og, gq);
                     } else {  // the H sum of G2.cpp:144 / G4.cpp:121
                         float hq = __fadd_rn(__fmul_rn(a.steer_w[B::PLANE0], b[0]), __fmul_rn(a.steer_w[B::PLANE0 + 1], b[1]));
 #pragma unroll
                         for (int p = 2; p < NB; ++p) hq = __fadd_rn(hq, __fmul_rn(a.steer_w[B::PLANE0 + p], b[p]));
-                        bst<STREAM>(rh, xbr, oh, hq);
+                        CVS_BST(STREAM, rh, xbr, oh, hq);
                     }
                 }
+#ifdef CVS_DIAG_CANARY
+                ++cn_rows;
+                if (st_tally - st_row0 < (unsigned)S_ROW) ++cn_short;   // S_ROW must be a LOWER bound of the stores of every output row
+#endif
             }
             }  // !F_PYRONLY
         }
@@ -933,6 +996,14 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #pragma unroll
         for (int j = 0; j < NT; ++j) row_step(std::integral_constant<int, 1>{}, g, j, more);
     }
+#ifdef CVS_DIAG_CANARY
+    if (cn_stale) atomicAdd(&g_canary[0], (unsigned long long)cn_stale);
+    if (lane == 0) {
+        if (cn_short) atomicAdd(&g_canary[1], (unsigned long long)cn_short);
+        atomicAdd(&g_canary[2], (unsigned long long)cn_reads);
+        atomicAdd(&g_canary[3], (unsigned long long)cn_rows);
+    }
+#endif
 #ifdef CVS_DIAG_STAMPS
     if (stamp && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -944,6 +1015,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 #endif
 }
 
+#undef CVS_BST
 // (BasisArgs must stay the FIRST parameter of both strip kernels: kernarg_fresh() reads it at offset 0 of the kernel-argument segment)
 template <class B, int FLAGS, bool STREAM, int BATCH = 0, bool ONE = false, int WPB = 4, bool U8 = false>
 __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArgs a, const Folded<B> t)
@@ -1154,7 +1226,7 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
     a.grid_y = grid.y;
     a.dyn_nz = 1;
     a.warm_bands = a.warm_k > 0 ? (a.grid_y + a.warm_k) / (a.warm_k + 1) : 0;
-    if (a.grid_y < 10 || a.frames || a.batch_regular) a.warm_k = 0;   // (frame batches: every frame is a small image)
+    if (a.grid_y < 10 || a.frames) a.warm_k = 0;   // (frame batches: warm_k is set by the API layer only where it pays)
     if (a.block_order == kOrderDynamic && !a.tile_ctr) a.block_order = 0;   // no queue slot for this handle: the plain order
     if (a.block_order != kOrderDynamic && a.block_order != kOrderXcdColumns) a.block_order = 0;
     const bool dyn = a.block_order == kOrderDynamic;
@@ -1510,3 +1582,17 @@ hipError_t launch_basis(int kind, int width, const float (*taps)[kMaxTaps], cons
 }
 
 }  // namespace cvs
+
+#ifdef CVS_DIAG_CANARY
+// canary twin only (never in the product library, not declared in the public header): read -- and reset -- the counters
+extern "C" int cvs_diag_canary(unsigned long long out[4], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(cvs::g_canary), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cvs::g_canary), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

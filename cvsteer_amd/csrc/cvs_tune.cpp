@@ -53,25 +53,30 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // Launch configuration: defaults, and the ONLINE comparison of a few alternatives on the caller's own launches.
 //
 // What a basis launch leaves open is the order in which its tiles are dealt to the chip (plain row-major, the XCD-column
-// order, the dynamic tail), the strip height, and for full G2 setups the grouping of the state planes.  Which combination is fastest depends on the box and -- more -- on the PROCESS, i.e. on where
-// the allocator put the planes, so a short list (at most four) is compared where the code runs.  NOTHING extra is launched:
-// while a key is undecided each of the caller's own calls runs one candidate, bracketed by a pair of events on the caller's
-// stream; candidates take turns in blocks of kBlock consecutive calls (the first call of a block is not counted: a
-// configuration's first launch after a change runs slower than the ones that follow it), the default first in every round;
-// samples are read back later with hipEventQuery, never waited for.
+// order, the dynamic tail), the strip height, and for full G2 setups the grouping of the state planes.  Which combination is
+// fastest depends on the box and -- more -- on the PROCESS, i.e. on where the allocator put the planes, so a short list (at
+// most four) is compared where the code runs.  NOTHING extra is launched: while a key is undecided each of the caller's own
+// calls runs one candidate, bracketed by a pair of events on the caller's stream; samples are read back later with
+// hipEventQuery, never waited for.
 //
-// The decision (round 5) bounds its own error instead of trusting a fixed number of samples: after every complete round in
-// which each candidate has at least kMinSamples samples the best challenger (lowest median) is held against the default with
-// Welch's t on the samples (time per pixel): it is kept only if t >= kTmin AND its median is kGain better; the default is kept
-// once no challenger can reach that any more (best challenger not ahead at all with t <= -1, or kMaxSamples per candidate
-// reached); otherwise another round of the caller's launches is sampled.  Challengers that are significantly BEHIND the default
-// are dropped from the later rounds.  Round 4 decided on the medians of ~4 samples that scatter +-3 % at the power cap and kept
-// a 4 % slower configuration in one run of seven (profiles/r04_tuner_value_probe.txt).
+// Round 6: candidates are compared in SUSTAINED turns.  Rounds 4-5 let the candidates take turns in blocks of five calls and
+// decided with Welch's t on the pooled samples.  That was precise about the wrong quantity: a configuration that wins five-call
+// blocks interleaved with other configurations need not win when it runs for good -- the dynamic tail won the interleaved
+// samples of the 32 x 1080p batch in 8 of 22 bench processes and then ran 6 % behind the plain order, a five-workgroups-per-CU
+// challenger for the full setup won in 13 of 13 and ran 3 % behind (profiles/r05_bench_lines*.jsonl).  Now a candidate's
+// turn is a run of kTurnMin..kTurnMax consecutive calls (about kTurnMs of GPU time), the first kLead of which are not counted,
+// and what is compared are the MEDIANS OF WHOLE TURNS: a challenger replaces the default only if, after at least two rounds,
+// every one of its turns was at least kGain faster than every turn of the default; challengers whose turns are not ahead of the
+// default's by half that margin on the median are dropped after two rounds; after kMaxRounds the default stays.  The default leads every
+// round (a card coming out of an idle pause speeds up over tens of launches: whoever is sampled later looks faster -- that drift
+// can only work against a challenger).
 //
 // Keys are by pixel-count BUCKET (half octaves), not by exact shape: the reference's callers build one object per image of
-// whatever size comes along (example/steer.cpp:86), and such callers never made 40 calls of one shape.  Samples are kept as
-// time per pixel so that shapes of one bucket pool; a decision that does not fit a particular shape (the XCD-column order
-// needs the column blocks to divide by 8) falls back to the default for that launch.
+// whatever size comes along (example/steer.cpp:86).  Samples are kept as time per pixel so that shapes of one bucket pool.  A
+// candidate that does not fit the shape of the call whose turn it would be (the XCD-column order needs the column blocks to
+// divide by 8) passes its turn; after kMaxUnfit passed turns it is dropped, so that a bucket of mixed shapes still comes to a
+// decision (it used to stay undecided for ever).  Everything is bounded: at most kMaxRounds rounds of at most four
+// turns of at most kTurnMax calls.
 // Process-wide, keyed by device, kind, kernel variant, bucket, batch size, layout and what the caller pinned.
 // ---------------------------------------------------------------------------------------------------------------------
 struct Cand {
@@ -83,12 +88,16 @@ struct Cand {
 
 struct TuneEntry {
     std::vector<Cand> cand;        // cand[0] = the default
-    std::vector<std::vector<float>> samples;   // ns per pixel
-    std::vector<char> dropped;     // challengers that are significantly behind: no longer sampled
-    int cur = 0, in_block = 0, round = 0;
+    std::vector<std::vector<float>> turn;      // per candidate: samples (ns per pixel) of its turn of the round in progress
+    std::vector<std::vector<float>> medians;   // per candidate: the median of every completed turn
+    std::vector<char> dropped;     // challengers out of the race
+    std::vector<int> unfit;        // turns a candidate has passed because the call's shape did not fit it
+    int cur = 0, in_turn = 0, round = 0;
+    int turn_len = 0;              // calls per turn in this round
     int pending = 0;               // samples recorded but not read back yet
     int chosen = -1;               // index into cand once decided
     bool round_complete = false;   // a whole round has been issued since the last evaluation
+    double ms_per_call = 0;        // last sampled call of the default (sets the length of the next round's turns)
 };
 
 struct Sample {
@@ -105,16 +114,18 @@ static std::map<TuneKey, TuneEntry> g_tune;          // node-based: TuneEntry* s
 static std::vector<Sample> g_samples;                // in flight
 static std::map<int, std::vector<hipEvent_t>> g_free_events;   // per device: timing events are recycled, never destroyed while the process lives
 
-constexpr int kBlock = 5;          // calls per turn of a candidate (the first is not counted)
-constexpr int kMinSamples = 8, kMaxSamples = 24;
-constexpr float kTmin = 3.0f, kGain = 0.02f;
+constexpr int kLead = 5;                        // calls at the head of a turn that are not counted
+constexpr int kTurnMin = 20, kTurnMax = 100;    // calls per turn
+constexpr double kTurnMs = 12.0;                // ... about this much GPU time
+constexpr int kMinRounds = 2, kMaxRounds = 3, kMaxUnfit = 3;
+constexpr float kGain = 0.02f;
 
 static void apply(BasisArgs& a, const Cand& c)
 {
     a.block_order = c.order;
     a.strip_rows = c.strip;
     a.merge_orient = c.merge;
-    if (c.wg >= 0) a.wg_per_cu = c.wg;
+    if (c.wg >= 0 && env_opts().wgcap < 0) a.wg_per_cu = c.wg;   // (a cap forced through CVS_OPTS wins over a remembered challenger)
 }
 
 // a configuration decided for the bucket must fit THIS launch
@@ -132,66 +143,46 @@ static float median_of(std::vector<float> v)
     return v.size() % 2 ? v[v.size() / 2] : 0.5f * (v[v.size() / 2 - 1] + v[v.size() / 2]);
 }
 
-// Welch's t for "a is slower than b" (positive = b faster); samples with the largest value of each side set aside (a launch that
-// ran into another process's burst must not widen the spread of its side)
-static float welch_t(std::vector<float> a, std::vector<float> b)
-{
-    auto trim = [](std::vector<float>& v) {
-        std::sort(v.begin(), v.end());
-        if (v.size() > 4) v.pop_back();
-    };
-    trim(a);
-    trim(b);
-    auto stats = [](const std::vector<float>& v, double& m, double& var) {
-        m = 0;
-        for (float x : v) m += x;
-        m /= (double)v.size();
-        var = 0;
-        for (float x : v) var += (x - m) * (x - m);
-        var /= (double)std::max<size_t>(1, v.size() - 1);
-    };
-    double ma, va, mb, vb;
-    stats(a, ma, va);
-    stats(b, mb, vb);
-    const double se = std::sqrt(va / (double)a.size() + vb / (double)b.size());
-    if (se <= 0) return ma > mb ? 1e9f : (ma < mb ? -1e9f : 0.f);
-    return (float)((ma - mb) / se);
-}
-
-// every candidate still in the race has kMinSamples: decide, or ask for another round.  g_tune_mutex held.
+// a round is complete and all its samples are in: close the turns, then decide or ask for another round.  g_tune_mutex held.
 static void evaluate(TuneEntry& e)
 {
-    size_t nmin = std::numeric_limits<size_t>::max();
-    for (size_t c = 0; c < e.cand.size(); ++c)
-        if (!e.dropped[c]) nmin = std::min(nmin, e.samples[c].size());
-    if (e.samples[0].empty()) {   // every sample of the default failed to record: nothing to hold a challenger against
-        if (e.round >= 4) e.chosen = 0;
-        return;
+    for (size_t c = 0; c < e.cand.size(); ++c) {
+        if (e.turn[c].size() >= 4) e.medians[c].push_back(median_of(e.turn[c]));   // (a turn most of whose samples failed to record does not count)
+        e.turn[c].clear();
     }
-    if (nmin < (size_t)kMinSamples) return;
-    const float m0 = median_of(e.samples[0]);
-    int best = -1;
-    float mbest = std::numeric_limits<float>::max();
-    for (size_t c = 1; c < e.cand.size(); ++c) {
-        if (e.dropped[c]) continue;
-        const float m = median_of(e.samples[c]);
-        if (welch_t(e.samples[c], e.samples[0]) >= kTmin && m > m0) e.dropped[c] = 1;   // significantly behind: out of the later rounds
-        else if (m < mbest) { mbest = m; best = (int)c; }
-    }
+    auto lo = [](const std::vector<float>& v) { return *std::min_element(v.begin(), v.end()); };
+    auto hi = [](const std::vector<float>& v) { return *std::max_element(v.begin(), v.end()); };
     int decision = -1;
-    if (best < 0) decision = 0;
-    else {
-        const float t = welch_t(e.samples[0], e.samples[best]);   // positive = the challenger is faster
-        if (t >= kTmin && mbest <= m0 * (1.0f - kGain)) decision = best;
-        else if (t <= -1.0f || nmin >= (size_t)kMaxSamples) decision = 0;
+    if (e.medians[0].empty()) {   // every sample of the default failed to record: nothing to hold a challenger against
+        if (e.round >= kMaxRounds) decision = 0;
+    } else if (e.round >= kMinRounds) {
+        const float d_best = lo(e.medians[0]), d_mid = median_of(e.medians[0]);
+        int best = -1, live = 0;
+        float mbest = std::numeric_limits<float>::max();
+        for (size_t c = 1; c < e.cand.size(); ++c) {
+            if (e.dropped[c]) continue;
+            if ((int)e.medians[c].size() < kMinRounds) {   // passed or lost its turns
+                if (e.round >= kMaxRounds) e.dropped[c] = 1;
+                else ++live;
+                continue;
+            }
+            const float m = median_of(e.medians[c]);
+            if (m > d_mid * (1.0f - 0.5f * kGain)) { e.dropped[c] = 1; continue; }   // not ahead by even half the margin: out
+            ++live;
+            if (hi(e.medians[c]) <= d_best * (1.0f - kGain) && m < mbest) { mbest = m; best = (int)c; }   // every turn ahead of every turn of the default
+        }
+        if (best >= 0) decision = best;
+        else if (live == 0 || e.round >= kMaxRounds) decision = 0;
     }
     if (decision >= 0) {
         e.chosen = decision;
         if (env_opts().verbose) {
-            std::fprintf(stderr, "[cvsteer] tuned on the caller's launches (ns/pix median x samples):");
-            for (size_t c = 0; c < e.cand.size(); ++c)
-                std::fprintf(stderr, " (order %d, strip %d, merged %d%s) %.5f x%zu", e.cand[c].order, e.cand[c].strip, e.cand[c].merge, e.dropped[c] ? ", dropped" : "", e.samples[c].empty() ? 0.f : median_of(e.samples[c]), e.samples[c].size());
-            std::fprintf(stderr, " -> candidate %d after %d rounds\n", decision, e.round);
+            std::fprintf(stderr, "[cvsteer] tuned on the caller's launches (ns/pix, median of each sustained turn):");
+            for (size_t c = 0; c < e.cand.size(); ++c) {
+                std::fprintf(stderr, " (order %d, strip %d, merged %d, wg %d%s)", e.cand[c].order, e.cand[c].strip, e.cand[c].merge, e.cand[c].wg, e.dropped[c] ? ", dropped" : "");
+                for (float m : e.medians[c]) std::fprintf(stderr, " %.5f", m);
+            }
+            std::fprintf(stderr, " -> candidate %d after %d rounds of %d-call turns\n", decision, e.round, e.turn_len);
         }
     }
 }
@@ -210,7 +201,10 @@ static void harvest()
         }
         float ms = 0.f;
         TuneEntry& e = *sm.entry;
-        if (q == hipSuccess && hipEventElapsedTime(&ms, sm.e0, sm.e1) == hipSuccess && ms > 0.f) e.samples[sm.cand].push_back((float)(ms * 1e6 / sm.npix));
+        if (q == hipSuccess && hipEventElapsedTime(&ms, sm.e0, sm.e1) == hipSuccess && ms > 0.f) {
+            if (e.turn[sm.cand].size() < (size_t)kTurnMax) e.turn[sm.cand].push_back((float)(ms * 1e6 / sm.npix));
+            if (sm.cand == 0) e.ms_per_call = ms;
+        }
         (void)hipGetLastError();
         --e.pending;
         g_free_events[sm.device].push_back(sm.e0);
@@ -262,9 +256,17 @@ static bool default_config(cvs_handle h, BasisArgs& a, int variant)
         else if (variant == 2) a.wg_per_cu = mid ? 3 : 4;
         else if (variant == 1 || variant == 5) a.wg_per_cu = mid ? 3 : 0;
     }
+    // Grouping of the G2 state planes.  Single-image launches that write the orientation planes too (full setup, caller pipeline) put all
+    // TWELVE planes into one row-interleaved group -- one write sweep instead of two: round 6, six processes on one box, same handle,
+    // sustained (profiles/r06_m4_layout_ab.txt): full setup 0.765 (two groups, three workgroups per CU) -> 0.82 (one group, uncapped) in 6
+    // of 6, caller pipeline 0.744 -> 0.786 (one group, three per CU) in 6 of 6; round 5 over twelve processes on two boxes: +6-7 % in 7, never
+    // worse than -0.6 % (profiles/r05_tuner_value_probe.txt).  With one group the full setup wants no occupancy cap (0.768 at three, 0.81 at
+    // four, 0.82 at five = uncapped), the pipeline keeps three (0.786 against 0.745 / 0.738 at four / five).  CVS_OPT_STATE_LAYOUT = 3 pins
+    // the two-group form.  Basis-only launches, batches and G4 always use the groups of layout_state.
+    a.merge_orient = ((h->layout == 1 || h->layout == 2) && h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0 &&
+                      state_merge_fits(h, a.rows, round_up((size_t)a.cols, 64))) ? 1 : 0;
+    if (a.merge_orient && !a.pipe && a.wg_per_cu == 3 && !a.pyr_out) a.wg_per_cu = 0;
     if (const int forced = env_opts().wgcap; forced >= 0) a.wg_per_cu = forced;
-    // CVS_OPT_STATE_LAYOUT = 2 pins the grouping: launches that write orientation planes use ONE group of twelve planes
-    a.merge_orient = (h->layout == 2 && h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0) ? 1 : 0;
     const bool fast = basis_fast_path(h->kind, h->width, h->taps);
     const bool big = (size_t)a.rows * a.cols >= ((size_t)1 << 20);
     // the plain row-major order: with the row-interleaved state it is within a few per cent of the best order on every box
@@ -332,20 +334,11 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
         // G4: the dynamic tail (+6 % on one box, level on the others)
         add({kOrderDynamic, def.strip});
     }
-    // G2 launches that write the orientation planes too (full setup, pipeline), row-interleaved state, single image: the two
-    // leading configurations with ALL twelve planes in one group -- steadier (0.81-0.82 for the full setup in every process)
-    // where two groups are either faster (0.85) or slower (0.755) depending on where the block lies
-    if (h->kind == CVS_KIND_G2 && a.orient && !a.no_state && a.batch == 0 && h->last.state_layout != 0 && h->layout == 1 &&
-        state_merge_fits(h, a.rows, h->dense_pitch)) {
-        const size_t n0 = std::min<size_t>(e.cand.size(), 2);
-        for (size_t i = 0; i < n0 && e.cand.size() < 4; ++i) {
-            Cand m = e.cand[i];
-            m.merge = 1;
-            e.cand.push_back(m);
-        }
-    }
-    e.samples.assign(e.cand.size(), std::vector<float>());
+    e.turn.assign(e.cand.size(), std::vector<float>());
+    e.medians.assign(e.cand.size(), std::vector<float>());
     e.dropped.assign(e.cand.size(), 0);
+    e.unfit.assign(e.cand.size(), 0);
+    e.turn_len = kTurnMin;
 }
 
 // half-octave bucket of the pixel count
@@ -394,10 +387,30 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     if (e.cand.size() < 2) return CVS_OK;   // nothing to compare for this kind of launch: the default, tune_state 0
     h->last.tune_state = 1;
     if (capturing || e.round_complete) return CVS_OK;   // under capture / waiting for the round's last samples: the default runs
-    int c = e.cur;
-    if (!fits(a, e.cand[c])) c = 0;   // another shape of the bucket: this call is the default's (and counts for it)
-    apply(a, e.cand[c]);
-    const bool counted = e.in_block > 0;    // a configuration's first launch after a change is not representative
+    // whose turn is it?  A candidate that does not fit this call's shape passes (at the head of its turn only; in mid-turn the call
+    // runs the default uncounted); after kMaxUnfit passed turns it is out of the race.
+    auto next_cand = [&]() {
+        e.in_turn = 0;
+        do {
+            ++e.cur;
+        } while (e.cur < (int)e.cand.size() && e.dropped[e.cur]);
+        if (e.cur >= (int)e.cand.size()) {   // the round is complete; the default leads the next one
+            e.cur = 0;
+            ++e.round;
+            e.round_complete = true;
+        }
+    };
+    while (e.in_turn == 0 && e.cur > 0 && !fits(a, e.cand[e.cur])) {
+        if (++e.unfit[e.cur] >= kMaxUnfit) e.dropped[e.cur] = 1;
+        next_cand();
+        if (e.round_complete) return CVS_OK;
+    }
+    if (e.cur == 0 && e.in_turn == 0)   // a new round: its turns last about kTurnMs of GPU time each
+        e.turn_len = e.ms_per_call > 0 ? std::max(kTurnMin, std::min(kTurnMax, kLead + (int)std::ceil(kTurnMs / e.ms_per_call))) : kTurnMin;
+    const int c = e.cur;
+    const bool fit = fits(a, e.cand[c]);
+    if (fit) apply(a, e.cand[c]);
+    const bool counted = fit && e.in_turn >= kLead;    // a configuration's first launches after a change are not representative
     if (counted) {
         hipEvent_t e0 = take_event(h->device), e1 = take_event(h->device);
         if (e0 && e1 && hipEventRecord(e0, h->stream) == hipSuccess) {
@@ -412,20 +425,7 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
             (void)hipGetLastError();
         }
     }
-    if (++e.in_block == kBlock) {
-        e.in_block = 0;
-        // the next candidate still in the race; after the last one the round is complete and the default leads the next round
-        // (a card coming out of an idle pause speeds up over tens of launches: whoever is sampled later looks faster -- with the
-        // default sampled first in EVERY round that drift can only work against a challenger)
-        do {
-            ++e.cur;
-        } while (e.cur < (int)e.cand.size() && e.dropped[e.cur]);
-        if (e.cur >= (int)e.cand.size()) {
-            e.cur = 0;
-            ++e.round;
-            e.round_complete = true;
-        }
-    }
+    if (++e.in_turn >= e.turn_len) next_cand();
     return CVS_OK;
 }
 

@@ -104,10 +104,11 @@ enum {
                                   their own) -- a launch that writes 7..12 planes then streams ONE linear sweep per group instead of
                                   one stream per plane 64 MiB apart; every plane is still an ordinary strided
                                   image (cvs_state_plane: step = planes x row length).  0 = planar, plane after plane (also what
-                                  groups of 2 GiB and more use).  With 1 the engine may also put all twelve G2 planes into one
-                                  group for launches that write the orientation planes (its tuner compares both;
-                                  cvs_launch_info.state_layout = 2 when it does); 2 = always one group of twelve for those
-                                  launches.  Takes effect at the next cvs_setup*; results do not depend on it.
+                                  groups of 2 GiB and more use).  With 1 the engine puts all twelve G2 planes into ONE group for
+                                  single-image launches that write the orientation planes too (full setup, caller pipeline: one
+                                  write sweep instead of two; cvs_launch_info.state_layout = 2 then) and uses the two groups for
+                                  every other launch; 2 = the same, spelled out; 3 = always two groups.
+                                  Takes effect at the next cvs_setup*; results do not depend on it.
                                   NOTE: because the grouping may change from one setup to the next, a cvs_state_plane view is
                                   valid only until the handle's next cvs_setup* / cvs_pipeline* call. */
 };
@@ -173,10 +174,11 @@ typedef struct cvs_launch_info {
     int32_t strip_rows;       /* ... output rows per wave strip */
     int32_t nt_stores;        /* ... 1 = streaming (nontemporal) stores */
     int32_t state_layout;     /* layout of the current state block: 0 = planar, 1 = row-interleaved groups (CVS_OPT_STATE_LAYOUT),
-                                 2 = row-interleaved with the G2 orientation planes in the basis planes' group (the tuner's choice) */
+                                 2 = row-interleaved with the G2 orientation planes in the basis planes' group (what launches that write them use) */
     int32_t warm;             /* last basis launch: K > 0 = the launch took its image for a NEW one (another pointer than the handle's
                                  previous call) and the waves of its first row bands requested the rest of the image ahead of need,
-                                 K bands each (images of 8 MiB and more); 0 = not */
+                                 K bands each (f32 images of 24 MiB and more; not for 8-bit images, frame batches and launches that
+                                 also emit a pyramid level); 0 = not */
     int32_t tuning_launches;  /* launches the engine has issued on this handle's stream beyond the caller's own calls: always 0
                                  (configurations are compared on the caller's launches) */
     int32_t tuned;            /* 1 = the configuration above is a challenger the online tuner decided for; 0 = the engine's default */

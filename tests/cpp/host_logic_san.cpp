@@ -91,7 +91,7 @@ int main()
     for (const char* o : opts) {
         setenv("CVS_OPTS", o, 1);
         const EnvOpts e = env_opts();
-        REQUIRE(e.layout >= -1 && e.layout <= 2 && e.autotune >= -1 && e.autotune <= 1 && e.batch_ways >= -1);
+        REQUIRE(e.layout >= -1 && e.layout <= 3 && e.autotune >= -1 && e.autotune <= 1 && e.batch_ways >= -1);
     }
     for (int it = 0; it < 3000; ++it) {
         std::string s;

@@ -18,8 +18,8 @@ def cv():
 def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     """a new 4096^2 shape: the second call costs about what a settled call costs (rounds 2-3 ran ~250 timing launches inside
     it, 25-30 ms); cvs_launch_info.tuning_launches stays 0; every call -- whatever candidate configuration it ran with --
-    returns the same bits; the comparison ends by itself (cvs_launch_info.tune_state 1 -> 2: when a challenger is separated from
-    the default beyond the spread of the samples, or after 24 samples per candidate).  The launch is the full setup (12 planes): the basis pass
+    returns the same bits; the comparison ends by itself (cvs_launch_info.tune_state 1 -> 2) after two or three rounds of SUSTAINED turns
+    (20-100 consecutive calls per candidate, cvs_tune.cpp).  The launch is the full setup (12 planes): the basis pass
     and the fused steer on a large resident image are deliberately NOT tuned (see build_candidates) -- checked at the end"""
     import torch
     from cvsteer_amd import _lib as L
@@ -40,7 +40,7 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     times, configs = [], set()
     first = None
     states = []
-    for i in range(200):
+    for i in range(1500):
         times.append(call())
         li = f.launch_info()
         configs.add((li["block_order"], li["strip_rows"], li["state_layout"]))
@@ -50,14 +50,14 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
             break
         if first is None:
             first = (f.getDominantOrientationAngle().clone(), f.getDominantOrientationStrength().clone(), f.basis(3).clone())
-        elif i in (1, 2, 5, 9, 14, 22, 31, 45, 69, 120, 199):
+        elif i in (1, 2, 5, 9, 14, 22, 31, 45, 69, 120, 199, 260, 333, 480, 700, 1100):
             assert torch.equal(f.getDominantOrientationAngle(), first[0]) and torch.equal(f.getDominantOrientationStrength(), first[1]) and torch.equal(f.basis(3), first[2]), i
     steady = statistics.median(times[-15:])
     assert times[1] <= 1.5 * steady + 0.15, (times[:4], steady)          # the second call is an ordinary call (+ host jitter; rounds 2-3: 25-30 ms)
     assert max(times[1:]) <= 3.0 * steady + 0.2, (max(times[1:]), steady)  # ... and so is every other one
     assert len(configs) >= 2, configs                                     # candidates did take turns on these calls
     assert states[0] == 1 and states[-1] == 2, (states[:3], states[-3:])    # compared on the caller's calls, then decided
-    assert 2 not in states[:19]                                            # ... never before every candidate has 8 samples
+    assert 2 not in states[:79]                                            # ... never before two rounds of two 20-call turns
     last = f.launch_info()
     tail = set()
     for _ in range(6):
@@ -213,12 +213,13 @@ def test_state_layouts_give_identical_planes(cv):
         img = torch.from_numpy(rng.random(shape, dtype=np.float32)).cuda()
         for cls, nb in ((cv.SteerableFiltersG2, 7), (cv.SteerableFiltersG4, 11)):
             hs = []
-            for lay in (0, 1, 2):
+            for lay in (0, 1, 2, 3):
                 f = cls(None)
                 f.set_option(L.OPT_STATE_LAYOUT, lay)
                 f.setup(img)
-                # 2 = all twelve G2 planes in one group (what the tuner may also choose by itself); G4 has no such form
-                assert f.launch_info()["state_layout"] == (lay if nb == 7 else min(lay, 1))
+                # launch_info: 2 = all twelve G2 planes in one group -- what a full setup uses by default (option 1) or pinned (2);
+                # option 3 pins the two-group form; G4 has no merged form
+                assert f.launch_info()["state_layout"] == ({0: 0, 1: 2, 2: 2, 3: 1}[lay] if nb == 7 else min(lay, 1))
                 hs.append(f)
             for p in range(nb):
                 assert torch.equal(hs[0].basis(p), hs[2].basis(p)), (shape, p, "merged")
@@ -234,6 +235,9 @@ def test_state_layouts_give_identical_planes(cv):
                 assert hs[2].launch_info()["state_layout"] == 1
             for p in range(nb):
                 assert torch.equal(hs[0].basis(p), hs[1].basis(p)), (shape, p)
+                assert torch.equal(hs[0].basis(p), hs[3].basis(p)), (shape, p, "two groups pinned")
+            if nb == 7:
+                assert torch.equal(hs[0].getDominantOrientationStrength(), hs[3].getDominantOrientationStrength())
             s0, s1 = hs[0].basis_view(1)[3], hs[1].basis_view(1)[3]
             assert s1 > s0 and s1 % s0 == 0        # planes x row length against one row length
             if nb == 7:
