@@ -50,7 +50,8 @@ NOMINAL_SCLK_MHZ = 2000.0  # used for the VALU roof only when the card's clock c
 ROWS = COLS = 4096
 THETA = 0.3
 BYTES_PER_PIX = {"M1": 32, "M2": 40, "M3": 64, "M4": 52, "M5": 84, "M6": 48, "M6s": 56, "M2_u8": 37, "C4_feat3": 16, "C4_u8_feat3": 13}
-MAX_SETTLE_CALLS = 160     # the online tuner compares its candidates on the caller's own calls; legs call until it has decided
+MAX_SETTLE_CALLS = 1300    # the online tuner compares its candidates on the caller's own calls, in sustained turns of 20-100 calls (at most
+                           # 3 rounds x 4 candidates); legs call until it has decided
 EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
 EXIT_LEGS_FAILED = 5  # a secondary leg raised: headline + the legs finished so far are printed first
 EXIT_TERMINATED = 4   # SIGTERM (another rank failed / the launcher gave up): whatever was measured is printed first
@@ -547,9 +548,10 @@ def main():
             n = MAX_SETTLE_CALLS if handle is not None else 8
         for i in range(n):
             fn()
-            if handle is not None and i % 5 == 4:
+            if handle is not None and i % 25 == 24:
                 torch.cuda.synchronize()     # the tuner reads its samples back when their launches have finished, never by waiting
-                if handle.launch_info()["tune_state"] != 1:
+                hs_ = handle if isinstance(handle, (list, tuple)) else [handle]
+                if all(h_.launch_info()["tune_state"] != 1 for h_ in hs_):
                     break
         torch.cuda.synchronize()
 
@@ -743,6 +745,19 @@ def main():
 
         runs = sorted(one_object(imgs8[(2 + i) & 7]) for i in range(10))
         rf["first_call_frac"] = record("M2_first_call_synchronised", _median(runs), runs[0], runs[-1], BYTES_PER_PIX["M2"], npix)
+        # what a synchronised first call cannot avoid: the device is idle when the call starts, so the launch's dispatch latency lies INSIDE the
+        # event pair (in every other leg it hides behind the previous launch) -- measured as the event-to-event time of a one-element fill
+        tiny = torch.empty(64, device=dev)
+
+        def idle_floor():
+            e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(); tiny.zero_(); e1_.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1_)
+        floor_ms = _median([idle_floor() for _ in range(15)])
+        rf["first_call_idle_launch_floor_us"] = round(floor_ms * 1e3, 1)
+        rf["first_call_frac_net_of_floor"] = round(BYTES_PER_PIX["M2"] * npix / ((_median(runs) - floor_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         # a caller that does host work between images (example/steer.cpp:73-122) meets an idle card: 30 ms of pause before every region
         rf["after_idle_frac"] = leg("M2_after_idle", step, BYTES_PER_PIX["M2"], handle=f, settle_calls=4, valu_key="M2", idle_s=0.03)
 
@@ -762,15 +777,32 @@ def main():
             del fu
         del imgs8
 
-        if ws == 1 and args.all_legs:
-            # PCIe-inclusive figure (never the headline `value`): the same unit of work with HOST planes in and out
+        if ws == 1:
+            # The facade's own regime (what a cv::Mat caller of test/test.cpp:85-90 gets): HOST planes in and out, PCIe-inclusive, never
+            # `value`.  Beside it the link's roof: the bytes that must cross in each direction / the rate of a pinned 256 MiB copy in that
+            # direction measured here (the two directions overlap: full duplex), so that the figure reads as a fraction of what the link allows.
             import numpy as np
-            himgs = [np.random.default_rng(500 + i).random((ROWS, COLS), dtype=np.float32) for i in range(8)]
+            pin = torch.empty(64 << 20, dtype=torch.float32).pin_memory()
+            dbuf = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+
+            def link_rate(dst, src):
+                best = 0.0
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    dst.copy_(src, non_blocking=True)
+                    torch.cuda.synchronize()
+                    best = max(best, src.numel() * 4 / (time.perf_counter() - t0) / 1e9)
+                return best
+            time.sleep(1.0)   # host-link copies run at half rate for a moment after large device frees
+            h2d, d2h = link_rate(dbuf, pin), link_rate(pin, dbuf)
+            del pin, dbuf
+            rf.update({"pcie_h2d_GBs": round(h2d, 1), "pcie_d2h_GBs": round(d2h, 1)})
+            himgs = [np.random.default_rng(500 + i).random((ROWS, COLS), dtype=np.float32) for i in range(4)]
             hg, hh = np.empty_like(himgs[0]), np.empty_like(himgs[0])
             fh_ = cv.SteerableFiltersG2(None, 4, 0.67, device=local_rank)
             fh_.setup_steer(himgs[0], THETA, flags=cv.SETUP_BASIS, out=(hg, hh))
             torch.cuda.synchronize()
-            time.sleep(2.5)   # host-link copies run at half rate for a moment after large device frees
 
             def host_stream():
                 t0 = time.perf_counter()
@@ -781,8 +813,36 @@ def main():
             dt = min(host_stream(), host_stream(), host_stream())
             legs["M2_host_planes_pcie_inclusive"] = [None, round(dt * 1e3, 3), None, None, None, None]
             out["pcie_inclusive_Mpix_s"] = round(npix / dt / 1e6, 1)
-            del himgs, fh_
+            roof_s = max(4.0 * npix / (h2d * 1e9), 8.0 * npix / (d2h * 1e9))    # 4 B/pix up, two f32 planes down
+            rf.update({"host_e2e_Gpix_s": round(npix / dt / 1e9, 3), "host_e2e_pcie_roof_Gpix_s": round(npix / roof_s / 1e9, 3),
+                       "host_e2e_pcie_frac": round(roof_s / dt, 4)})
+            del himgs, fh_, hg, hh
+            # the batch driver's shape (cvsteer-run, example/steer.cpp:69-122): 8-bit host frames in, the three 8-bit feature maps out --
+            # 1 B/pix up, 3 B/pix down, one native call (cvs_batch_run on a one-GPU world: upload, launch, normalise, download in chunks)
+            try:
+                hb_ = batch.NativeBatch.local((local_rank,))
+                hb_.set_persist(False)
+                nfr_h = 32
+                host_u8 = np.random.default_rng(77).integers(0, 256, (nfr_h, 1080, 1920), dtype=np.uint8)
+                q8 = np.zeros((nfr_h, 3, 1080, 1920), np.uint8)
+                bbest = None
+                for rep in range(4):
+                    t0 = time.perf_counter()
+                    hb_.run_to_u8(host_u8, out=q8)
+                    dtb = time.perf_counter() - t0
+                    if rep and (bbest is None or dtb < bbest):
+                        bbest = dtb
+                hp_ = nfr_h * 1080 * 1920
+                roof_b = max(1.0 * hp_ / (h2d * 1e9), 3.0 * hp_ / (d2h * 1e9))
+                legs["C4_u8_host_in_u8_host_out_pcie_inclusive"] = [None, round(bbest * 1e3, 3), None, None, None, None]
+                rf.update({"host_u8_e2e_Gpix_s": round(hp_ / bbest / 1e9, 3), "host_u8_pcie_roof_Gpix_s": round(hp_ / roof_b / 1e9, 3),
+                           "host_u8_pcie_frac": round(roof_b / bbest, 4)})
+                hb_.close()
+                del host_u8, q8
+            except Exception as ex:
+                rf["host_u8_error"] = ("%s: %s" % (type(ex).__name__, ex))[:120]
 
+        if ws == 1 and args.all_legs:
             def same_handle_default(name, fn, bpp):
                 """the leg just timed, on the SAME handle (same state block) with the tuner switched off: what the tuner's pick is worth"""
                 f.set_option(L.OPT_AUTOTUNE, 0)
@@ -916,28 +976,6 @@ def main():
                 del e2e_out
             except Exception as ex:   # a failing end-to-end leg must not take the headline down with it
                 rf["e2e_error"] = ("%s: %s" % (type(ex).__name__, ex))[:120]
-            if args.all_legs:
-                # the same from HOST planes (what example/steer.cpp holds): PCIe-inclusive; never `value`
-                try:
-                    import numpy as _np
-                    hb_ = batch.NativeBatch.local((local_rank,))
-                    hb_.set_persist(False)
-                    host_u8 = (fsets[0] * 255.0).to(torch.uint8).cpu().numpy()
-                    q8 = _np.zeros((nfr, 3) + shape, _np.uint8)
-                    time.sleep(2.0)
-                    bbest = None
-                    for rep in range(4):
-                        t0 = time.perf_counter()
-                        hb_.run_to_u8(host_u8, out=q8)
-                        dt = time.perf_counter() - t0
-                        if rep and (bbest is None or dt < bbest):
-                            bbest = dt
-                    (bbest,) = max_over_ranks(bbest)
-                    out["c4_bytes_in_bytes_out_pcie_Mpix_s"] = round(ws * nfr * 1080 * 1920 / bbest / 1e6, 1)
-                    hb_.close()
-                    del host_u8, q8
-                except Exception as ex:
-                    out["c4_bytes_error"] = ("%s: %s" % (type(ex).__name__, ex))[:120]
         del fsets, ff, all_frames
 
         if ws == 1:
@@ -959,7 +997,7 @@ def main():
             c3 = max(10, args.steps // 10)
             # algorithmic bytes: 4 B read + 28 B written per pixel of every level, plus the 4 B written per pixel of every level made here
             whole_bytes = 32 * ppix + 4 * (ppix - lv[0].shape[0] * lv[0].shape[1])
-            settle(pyr_one_call, hp[0], 64)
+            settle(pyr_one_call, hp)   # (the small levels are compared by the tuner on these calls too: every level's handle must have decided)
             ms, lo, hi = timed(pyr_one_call, c3, 2)
             rf["c3_frac"] = record("C3_pyramid_8192_5_levels_whole", ms, lo, hi, whole_bytes / ppix, ppix, hp[0], None)
             out["c3_Mpix_s"] = round(ppix / (ms * 1e-3) / 1e6, 1)

@@ -895,6 +895,12 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     }
     TuneToken tok;
     if ((rc = tune_begin(h, a, 16 | 1 | 4 | (a.no_state ? 8 : 0), false, tok))) return rc;
+    if (env_opts().batch_merge > 0 && !a.no_state && h->layout >= 1 && h->layout != 3) a.merge_orient = 1;   // experiment: one 12-plane group per frame
+    if ((a.merge_orient != 0) != (h->ngrp == 1 && h->kind == CVS_KIND_G2)) {
+        layout_state(h, a.merge_orient != 0);
+        fill_state_args(h, a, true);
+        a.frame_stride = h->frame_stride;
+    }
     note_launch(h, a);
     const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream);
     tune_end(h, tok);

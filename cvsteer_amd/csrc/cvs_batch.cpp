@@ -446,7 +446,9 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
     int persist = 1;
     (void)cvs_get_option(s.h, CVS_OPT_PERSIST_STATE, &persist);
     // with state kept, the handle's frames after the call must be the whole shard: one chunk
-    const int nchunks = persist ? 1 : std::min(n, 4);
+    int want_chunks = 4;
+    if (const char* e = std::getenv("CVS_BATCH_HOST_CHUNKS")) want_chunks = std::max(1, std::atoi(e));   // experiment (round 6)
+    const int nchunks = persist ? 1 : std::min(n, want_chunks);
     std::vector<int> c0(nchunks + 1);
     for (int c = 0; c <= nchunks; ++c) c0[c] = (int)((long long)n * c / nchunks);
     std::vector<hipEvent_t> up_ev(nchunks), done_ev(nchunks);

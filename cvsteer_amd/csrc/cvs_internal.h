@@ -190,7 +190,8 @@ struct StateBlock {
     // tile queues of the dynamic launch order (two sets of 8 counters + a flag, 1 KiB each): a slot of a per-device slab, taken
     // with the block and returned with it -- so that whoever uses the block next has waited for `ready` first
     unsigned* tile_ctr = nullptr;
-    int ctr_parity = 0;        // the set the next dynamic launch uses (that launch zeroes the other one)
+    int ctr_parity = 0;        // bit 0: the set the next dynamic launch uses (that launch zeroes the other one); bit 1: the slot has served
+                               // another block -- the next dynamic launch resets its set with a kernel first (cvs_state.cpp tile_ctr_alloc)
 };
 hipError_t state_block_alloc(int device, size_t elems, StateBlock& b);
 void state_block_free(StateBlock& b);

@@ -1205,6 +1205,12 @@ static hipError_t dynamic_queues(BasisArgs& a, hipStream_t s, bool* captured)
         hipLaunchKernelGGL(k_reset_queues, dim3(1), dim3(64), 0, s, a.tile_ctr);
         return hipGetLastError();
     }
+    if (a.tile_parity && (*a.tile_parity & 2)) {   // a recycled queue slot: its sets are whatever the previous owner left (see tile_ctr_alloc)
+        hipLaunchKernelGGL(k_reset_queues, dim3(1), dim3(64), 0, s, a.tile_ctr);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        *a.tile_parity &= 1;
+    }
     if (a.tile_parity) *a.tile_parity ^= 1;
     return hipSuccess;
 }
@@ -1246,6 +1252,14 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
         constexpr unsigned kLds = 160u << 10, kStatic = (unsigned)(wpb * (2 * B::W + 2) * kRingLine * sizeof(float) + 64);
         const unsigned n = (unsigned)a.wg_per_cu, want = (kLds / n + kLds / (n + 1)) / 2;   // N fit, N + 1 do not: the middle of that interval
         lds_pad = want > kStatic ? want - kStatic : 0;
+        // never more than a workgroup may have (one or two per CU would ask for 120 / 67 KiB): the cap is then weaker than asked for
+        static const unsigned max_lds = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) return (unsigned)v;
+            (void)hipGetLastError();
+            return 64u << 10;
+        }();
+        if (kStatic + lds_pad > max_lds) lds_pad = max_lds > kStatic ? max_lds - kStatic : 0;
     }
 #define CVS_LAUNCH_K(...)                                                                  \
     do {                                                                                   \

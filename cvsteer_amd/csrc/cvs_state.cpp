@@ -26,8 +26,9 @@ CtrSlab g_ctr[64];
 
 // Allocations and blocking memsets are "potentially unsafe" while any stream of the process is under global-mode capture: the
 // guard marks them as belonging to no capture (ensure_state may run while the caller's stream, or another thread's, captures).
-unsigned* tile_ctr_alloc(int device)
+unsigned* tile_ctr_alloc(int device, bool* recycled)
 {
+    *recycled = false;
     if (device < 0 || device >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(g_ctr_mutex);
     RelaxedCapture relaxed;
@@ -48,14 +49,10 @@ unsigned* tile_ctr_alloc(int device)
     if (!sl.base || sl.free_slots.empty()) return nullptr;   // no slot: the handle keeps to the static orders
     const int i = sl.free_slots.back();
     unsigned* p = reinterpret_cast<unsigned*>(sl.base + (size_t)i * kCtrSlotBytes);
-    if (sl.used[i]) {
-        // a slot that has served another block: the set its last launch took its tickets from is not at zero, and the new block
-        // starts with set 0 again.  (The block that held the slot was idle when it was freed: state_block_free waits for it.)
-        if (hipMemset(p, 0, kCtrSlotBytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-    }
+    // a slot that has served another block: the set its last launch took its tickets from is not at zero.  NOT zeroed with hipMemset here:
+    // a fill's stores sit in an XCD's L2 while the queue atomics execute at the memory side (the round-5 finding behind k_reset_queues);
+    // the new owner's first dynamic launch puts a k_reset_queues launch in front of itself on its own stream (StateBlock::ctr_parity bit 1).
+    *recycled = sl.used[i] != 0;
     sl.free_slots.pop_back();
     sl.used[i] = 1;
     return p;
@@ -92,7 +89,9 @@ hipError_t state_block_alloc(int device, size_t elems, StateBlock& b)
     const hipError_t e = hipMalloc(&b.base, elems * sizeof(float));
     if (e == hipSuccess) {
         b.elems = elems;
-        b.tile_ctr = tile_ctr_alloc(device);
+        bool recycled = false;
+        b.tile_ctr = tile_ctr_alloc(device, &recycled);
+        b.ctr_parity = recycled ? 2 : 0;
     }
     return e;
 }

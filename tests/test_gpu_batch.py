@@ -366,6 +366,41 @@ def test_pyramid_bands_equal_single_gpu(cv, world, monkeypatch):
     nb4.close()
 
 
+def test_two_distinct_devices_rccl_round_trip(cv):
+    """the batch axis of example/steer.cpp:169 over RCCL between DISTINCT devices -- runs wherever two GPUs are visible (the driver's 8-GPU
+    node; a one-GPU box skips): 1080p frames scattered from device 0 with grouped ncclSend / ncclRecv, one fused launch per device, the
+    three maps gathered back, bit for bit the single-GPU result; then one banded pyramid (ncclBroadcast of the image, row bands of every
+    level per device, bands gathered into the root's planes) against the single-GPU chain, band seams included"""
+    import torch
+    from cvsteer_amd import _lib as L
+    from cvsteer_amd import batch
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("one GPU visible: RCCL between distinct devices cannot run here")
+    devs = tuple(range(min(ndev, 4)))
+    frames = _frames(len(devs) + 1, 1080, 1920, 31)          # an uneven split: one device gets two frames
+    want = _reference(cv, frames, (5, 6, 7))
+    nb = batch.NativeBatch.local(devs)
+    assert nb.transport == "rccl", nb.transport              # a rehearsal transport must never carry distinct devices
+    got, t = nb.run(frames, frames.shape[0], (1080, 1920), outputs=(5, 6, 7))
+    assert torch.equal(got, want)
+    assert t["scatter"] > 0.0 and t["compute"] > 0.0 and t["gather"] > 0.0
+    got8, _ = nb.run(frames, frames.shape[0], (1080, 1920), outputs=tuple(range(8)))
+    assert torch.equal(got8, _reference(cv, frames, tuple(range(8))))
+    rows, cols, levels = 2051, 3000, 4
+    img = torch.rand((rows, cols), device="cuda", generator=torch.Generator(device="cuda").manual_seed(32))
+    single = cv.SteerableFiltersG2(None)
+    lv = single.pyramid(img, levels)
+    tp = nb.pyramid_setup(img, rows, cols, levels, flags=cv.SETUP_FULL)
+    assert tp["broadcast"] > 0.0 and tp["gather"] > 0.0
+    for l, plane in enumerate(lv):
+        ref = cv.SteerableFiltersG2(plane)
+        for p in range(7):
+            assert torch.equal(nb.level_plane(l, L.PLANE_BASIS0 + p), ref.basis(p)), (l, p)
+        assert torch.equal(nb.level_plane(l, L.PLANE_THETA), ref.getDominantOrientationAngle()), l
+    nb.close()
+
+
 def test_setup_rows_band_is_bit_identical(cv):
     """cvs_setup_rows: any band of rows equals the same rows of a whole-image setup, incl. bands touching the borders"""
     import ctypes as C

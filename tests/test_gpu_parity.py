@@ -1143,6 +1143,64 @@ def test_block_order_never_changes_results(cv):
             cv.SteerableFiltersG2(None).set_option(L.OPT_BLOCK_ORDER, bad)
 
 
+def test_workgroups_per_cu_cap_never_changes_results(cv, monkeypatch):
+    """the occupancy cap (BasisArgs::wg_per_cu: dynamic LDS no kernel touches, on by rule for single G2 images of 2 Mpix and more, any value
+    through CVS_OPTS wgcap=0..8): every value launches -- one or two workgroups per CU would ask for more LDS than a workgroup may have and
+    are clamped -- and every G2 variant returns the bits of the uncapped launch; a cap forced through CVS_OPTS is what launch_info reports"""
+    import torch
+    from cvsteer_amd import _lib as L
+    img = torch.rand((1536, 2048), device="cuda", generator=torch.Generator(device="cuda").manual_seed(21))
+    frames = torch.rand((4, 600, 1000), device="cuda", generator=torch.Generator(device="cuda").manual_seed(22))
+    ref = None
+    for cap in (0, 1, 2, 3, 5, 8, None):
+        if cap is None:
+            monkeypatch.delenv("CVS_OPTS", raising=False)    # the engine's own rule
+        else:
+            monkeypatch.setenv("CVS_OPTS", "wgcap=%d" % cap)
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_AUTOTUNE, 0)
+        cur = []
+        f.setup(img, flags=cv.SETUP_BASIS)
+        if cap is not None:
+            assert f.launch_info()["wg_per_cu"] == cap
+        cur += [f.basis(p).clone() for p in range(7)]
+        g, h = f.setup_steer(img, 0.3, flags=cv.SETUP_FULL)
+        cur += [g, h, f.getDominantOrientationAngle().clone(), f.getDominantOrientationStrength().clone()]
+        cur += [o.clone() for o in f.pipeline(img)]
+        cur += [f.setup_pyr(img, flags=cv.SETUP_BASIS), f.basis(6).clone()]
+        cur += [f.pipeline_batch(frames).clone()]
+        f.set_persist(False)
+        cur += [f.pipeline_batch(frames, outputs=(5, 6, 7)).clone()]
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = cur
+        for k, (a_, b_) in enumerate(zip(cur, ref)):
+            assert torch.equal(a_, b_), (cap, k)
+
+
+def test_a_recycled_tile_queue_slot_is_reset_before_its_first_dynamic_launch(cv):
+    """the per-XCD tile queues of the dynamic launch order live in a slot that travels with the state block; a slot given back with a freed
+    block and taken by a new one holds an exhausted set.  The new owner's first dynamic launch resets it with a kernel on its own stream
+    (not a memset: memory-side atomics would not see it) -- every tail tile is written"""
+    import torch
+    from cvsteer_amd import _lib as L
+    img = torch.rand((1100, 1500), device="cuda", generator=torch.Generator(device="cuda").manual_seed(23))
+    ref = cv.SteerableFiltersG2(None)
+    ref.set_option(L.OPT_BLOCK_ORDER, L.ORDER_PLAIN)
+    want = [o.clone() for o in ref.pipeline(img)] + [ref.basis(p).clone() for p in range(7)]
+    for rnd in range(4):
+        f = cv.SteerableFiltersG2(None)
+        f.set_option(L.OPT_BLOCK_ORDER, L.ORDER_DYNAMIC_TAIL)
+        for _ in range(1 + (rnd & 1)):      # an odd and an even number of launches: either set is the exhausted one
+            outs = f.pipeline(img)
+        got = [o.clone() for o in outs] + [f.basis(p).clone() for p in range(7)]
+        for k, (a_, b_) in enumerate(zip(got, want)):
+            assert torch.equal(a_, b_), (rnd, k)
+        del f, outs
+        torch.cuda.synchronize()
+        cv.lib().cvs_release_cached_memory() # the parked block (and its queue slot) really goes back; the next handle recycles the slot
+
+
 def test_xcd_column_order_and_g4(cv):
     """block order 1000000 (every XCD on its own range of column blocks) on widths whose 256-column blocks divide among the 8
     XCDs and on widths where they do not, short and tall images, G2 and G4: identical outputs.  (G4 with this order pinned used

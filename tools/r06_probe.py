@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/r06_probe.py -- round-6 A/B probes, one process = one allocation history (run it in several).  Every comparison is made
 on ONE handle / state block with the online tuner off, settings alternating, SUSTAINED regions (a lead-in of a third of the region,
-then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c4w tune
+then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c4w c4m tune
   c4     32 x 1080p caller pipeline with state kept (BASELINE config 4): plain order vs dynamic tail, workgroups per CU, batch ways,
          strip height, planar [n][8][H][W] outputs vs row-interleaved [n][H][8][W] ones
   m4     full setup at 4096^2: two plane groups (layout 1) vs one merged group (layout 2), workgroups per CU
@@ -337,3 +337,78 @@ if "tune" in sections:
         a, b = (bpp * npx / (statistics.median(res[m]) * 1e-3) / PEAK for m in (1, 0))
         print("%-24s tuned %.4f | default %.4f  (%+.1f %%)  decided after %4d calls (state %d): challenger kept %d -- order %d strip %d layout %d wg %d" %
               (name, a, b, 100 * (a / b - 1), calls, li["tune_state"], li["tuned"], li["block_order"], li["strip_rows"], li["state_layout"], li["wg_per_cu"]), flush=True)
+
+
+if "c3x" in sections:
+    # which neighbour costs level 0 its read-ahead gain?  Level 0 (pyr_nt + warm) timed by events inside chains that contain only some levels.
+    bigs = [torch.rand((8192, 8192), device="cuda") for _ in range(2)]
+    fp3 = cv.SteerableFiltersG2(None, 4, 0.67)
+    lv = fp3.pyramid(bigs[0], 5)
+    hp = [cv.SteerableFiltersG2(None, 4, 0.67) for _ in lv]
+    fl = [0]
+
+    def run(levels, ev=None):
+        fl[0] ^= 1
+        for k in levels:
+            if ev is not None:
+                ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+            src = bigs[fl[0]] if k == 0 else lv[k]
+            if k < 4:
+                hp[k].setup_pyr(src, flags=cv.SETUP_BASIS, out=lv[k + 1])
+            else:
+                hp[k].setup(src, flags=cv.SETUP_BASIS)
+        if ev is not None:
+            ev.append(torch.cuda.Event(enable_timing=True)); ev[-1].record()
+    subsets = [(0,), (0, 4), (0, 3, 4), (0, 2), (0, 1), (0, 1, 2), (0, 1, 2, 3, 4)]
+    for o in ("", "pyr_nt=1,warm_any=1", "pyr_nt=1,warm_any=17"):
+        opts(o)()
+        print("CVS_OPTS %-28s ms per level inside chains of the given levels (median of 16, 2 rounds)" % (o or "(default)"))
+        for sub in subsets:
+            meds = []
+            for rnd in range(2):
+                for _ in range(6):
+                    run(sub)
+                rows = []
+                for _ in range(16):
+                    ev = []
+                    run(sub, ev)
+                    torch.cuda.synchronize()
+                    rows.append([ev[i].elapsed_time(ev[i + 1]) for i in range(len(sub))])
+                meds.append([statistics.median(r[i] for r in rows) for i in range(len(sub))])
+            m = [statistics.median(x[i] for x in meds) for i in range(len(sub))]
+            print("   levels %-16s %s" % (sub, " ".join("%.4f" % v for v in m)), flush=True)
+    opts("")()
+
+
+if "c4m" in sections:
+    nfr = 32
+    fsets = [torch.rand((nfr, 1080, 1920), device="cuda") for _ in range(2)]
+    fout = torch.empty((nfr, 8, 1080, 1920), device="cuda")
+    ff = cv.SteerableFiltersG2(None, 4, 0.67)
+    alt = [0]
+    fp = nfr * 1080 * 1920
+
+    def c4():
+        alt[0] ^= 1
+        ff.pipeline_batch(fsets[alt[0]], out=fout)
+
+    def pre(o, order=0):
+        def f():
+            ff.set_option(L.OPT_BLOCK_ORDER, order)
+            opts(o)()
+        return f
+    c4()
+    ab("C4 32x1080p pipeline, state kept: one 12-plane group per frame (batch_merge), frames requested ahead (warm_any=8)", 84 * fp, 150, [
+        ("two groups per frame (default)", pre(""), c4), ("merged", pre("batch_merge=1"), c4), ("merged + warm 2", pre("batch_merge=1,warm_any=8,warm=2"), c4),
+        ("merged + warm 2 + dynamic tail", pre("batch_merge=1,warm_any=8,warm=2", L.ORDER_DYNAMIC_TAIL), c4),
+        ("merged, wgcap=4", pre("batch_merge=1,wgcap=4"), c4), ("merged, wgcap=3", pre("batch_merge=1,wgcap=3"), c4),
+        ("warm 2 only", pre("warm_any=8,warm=2"), c4)])
+    # bit-identical whatever the grouping
+    opts("")(); ff.set_option(L.OPT_BLOCK_ORDER, 0)
+    ff.pipeline_batch(fsets[0], out=fout); ref = fout.clone(); ff.select_frame(7); rb = [ff.basis(p).clone() for p in range(7)] + [ff.getDominantOrientationAngle().clone()]
+    opts("batch_merge=1,warm_any=8,warm=2")()
+    fout.zero_(); ff.pipeline_batch(fsets[0], out=fout); ff.select_frame(7)
+    same = torch.equal(ref, fout) and all(torch.equal(a_, b_) for a_, b_ in zip(rb, [ff.basis(p) for p in range(7)] + [ff.getDominantOrientationAngle()]))
+    print("   merged + warm: outputs and state planes of frame 7 bit-identical to the default: %s (state_layout %d)" % (same, ff.launch_info()["state_layout"]))
+    opts("")()
+    del fsets, fout, ff
