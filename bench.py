@@ -50,8 +50,8 @@ NOMINAL_SCLK_MHZ = 2000.0  # used for the VALU roof only when the card's clock c
 ROWS = COLS = 4096
 THETA = 0.3
 BYTES_PER_PIX = {"M1": 32, "M2": 40, "M3": 64, "M4": 52, "M5": 84, "M6": 48, "M6s": 56, "M2_u8": 37, "C4_feat3": 16, "C4_u8_feat3": 13}
-MAX_SETTLE_CALLS = 1300    # the online tuner compares its candidates on the caller's own calls, in sustained turns of 20-100 calls (at most
-                           # 3 rounds x 4 candidates); legs call until it has decided
+MAX_SETTLE_CALLS = 1700    # the online tuner compares its candidates on the caller's own calls, in sustained turns of 20-100 calls (at most
+                           # 4 rounds x 4 candidates); legs call until it has decided
 EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
 EXIT_LEGS_FAILED = 5  # a secondary leg raised: headline + the legs finished so far are printed first
 EXIT_TERMINATED = 4   # SIGTERM (another rank failed / the launcher gave up): whatever was measured is printed first
@@ -883,7 +883,9 @@ def main():
                     if s_["sclk_mhz"] and legs[lg][5]:
                         legs[lg][5] = rf[nm + "_valu_frac"] = round(legs[lg][5] * (clock["mhz"] or NOMINAL_SCLK_MHZ) / s_["sclk_mhz"], 4)
                 step()
-            rf["g4_bound"] = "valu" if (rf["g4_valu_frac"] or 0) > rf["g4_frac"] else "hbm"
+            # both roofs sit at ~0.7 for the G4 pair launch at the clock the power cap leaves it (profiles/r05_g4_bound.txt): neither alone bounds it
+            gv = rf["g4_valu_frac"] or 0
+            rf["g4_bound"] = "valu and hbm (both roofs within 0.05)" if abs(gv - rf["g4_frac"]) <= 0.05 else ("valu" if gv > rf["g4_frac"] else "hbm")
             del outs8, f4
             # size dependence: the same kernels on one 8192x8192 image (4x the pixels per launch) -- the fixed start-up cost of
             # a launch (every wave primes its 8-row window before its first store) amortises -- and with two images taking turns

@@ -109,26 +109,23 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
     // the pipeline variants keep the taller strips (round 1 shape sweep)
     // (a handle's FIRST call counts as a fresh image too: the reference's callers build one object per image,
     // example/steer.cpp:86 -- only a handle that is handed the same pointer again is re-filtering a resident image)
-    const bool fresh = (h->last_image != (const void*)image->data || (env_opts().warm_any & 16)) && !pipe_outs;   // (16: experiment, every image counts as new)
+    const bool fresh = h->last_image != (const void*)image->data && !pipe_outs;
     h->last_image = image->data;
     a.strip_rows = default_strip_rows(h, a.rows, a.cols, fresh);
-    // New G2 images of 24 MiB and more: the waves of the launch's first fifth of row bands also touch the rest of the image (four
+    // New images of 24 MiB and more: the waves of the launch's first fifth of row bands also touch the rest of the image (four
     // bands each), so that it is requested from HBM while the launch is young and most of the launch streams its writes without
     // reads mixed in.  Same process, alternating settings (profiles/r05_fresh_warm.txt): basis pass on alternating 8192^2 images
     // 0.626 -> 0.744 of the HBM roofline, fused steer on rotating 4096^2 images 0.624 -> 0.716, one object per image 0.614 ->
     // 0.700, full setup 0.624 -> 0.697; a separate read pass in front of the launch (round 4's tuner candidate, removed) reached
     // 0.708 where this reaches 0.729 and cannot serve an 8192^2 image at all.  Not for: the launch that also emits the next pyramid
     // level (-8 %: its cached half-line stores want the L2 for themselves; with streaming stores for the level the launch gains
-    // 13 % and the next level's launch, which then reads its image from HBM, loses more: config 3 0.658 -> 0.640), G4 and the
-    // 20-plane pipeline at the SIMDs' limit (level), 8-bit and small images (level to -3 %).  CVS_OPTS warm=K overrides K (0 = off).
+    // 7-13 % and the next level's launch, which then reads its image from HBM, loses more: config 3 0.658 -> 0.640, measured again in round 6,
+    // profiles/r06_c3_chain_localisation.txt), 8-bit images of 4096^2 (-5 ... -6 %) and small images (level to -3 %).  G4 images are requested
+    // ahead as well since round 6 (+2.2 ... +2.4 % on rotating 4096^2 images, profiles/r06_fresh_exact_wait.txt).  CVS_OPTS warm=K overrides K (0 = off).
     {
         const size_t in_bytes = (size_t)a.rows * a.cols * (a.in_u8 ? 1 : sizeof(float));
         const int wk = env_opts().warm;
-        const int any = env_opts().warm_any;   // experiment: 1 = also launches that emit a pyramid level, 2 = G4, 4 = 8-bit images (by pixel count)
-        const bool big = (a.in_u8 && (any & 4)) ? (size_t)a.rows * a.cols >= ((size_t)6 << 20) : in_bytes >= ((size_t)24 << 20);
-        const bool pyr_fused = pyr && env_opts().pyr_split <= 0;
-        a.warm_k = (fresh && (h->kind == CVS_KIND_G2 || (any & 2)) && (!pyr_fused || (any & 1)) && big) ? (wk >= 0 ? wk : 4) : 0;
-        a.warm_exact = env_opts().warm_exact > 0 ? 1 : 0;
+        a.warm_k = (fresh && !pyr && in_bytes >= ((size_t)24 << 20)) ? (wk >= 0 ? wk : 4) : 0;
     }
     a.nt_stores = use_nt_stores(h, (size_t)a.rows * a.cols);
     a.diag = h->diag;
@@ -155,7 +152,6 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
         if ((rc = out_ref(c, pyr, rp))) return rc;
         a.pyr_out = rp.p;
         a.pyr_pitch = rp.pitch;
-        a.pyr_nt = env_opts().pyr_nt > 0 ? 1 : 0;
     }
     float* scr = scratch ? arena_take(h, scratch) : nullptr;
     if (overlap) {
@@ -174,18 +170,9 @@ int do_setup(cvs_handle h, const cvs_plane* image, unsigned flags, bool steer, f
             fill_state_args(h, a, orient_k);
         }
         note_launch(h, a);
-        // experiment (CVS_OPTS pyr_split=1): the level's image is made by a strip march of its own behind the filter launch
-        float* const pyr_later = (a.pyr_out && env_opts().pyr_split > 0) ? a.pyr_out : nullptr;
-        if (pyr_later) a.pyr_out = nullptr;
         const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, scr, h->stream);
         tune_end(h, tok);
         HIP_TRY(h, le);
-        if (pyr_later) {
-            hipError_t pe = hipSuccess;
-            if (!launch_pyr_strip(a.in, a.in_pitch, a.rows, a.cols, pyr_later, a.pyr_pitch, h->stream, &pe))
-                pe = launch_pyr_down(a.in, a.in_pitch, a.rows, a.cols, pyr_later, a.pyr_pitch, h->stream);
-            HIP_TRY(h, pe);
-        }
     }
     if ((flags & CVS_SETUP_ORIENT) && h->kind == CVS_KIND_G4) {  // extension: one per-pixel pass over the 11 planes
         PointArgs pa{};
@@ -889,18 +876,12 @@ int cvs_pipeline_batch(cvs_handle h, const cvs_plane* images, int n, const cvs_p
     if (!a.no_state && n >= 4 && h->strip_rows <= 0) a.strip_rows = 2 * (2 * h->width + 1) - 2 * h->width;
     if (const int ways = env_opts().batch_ways; ways > 0) a.z_ways = std::max(1, std::min(n, ways));
     a.frame_stride = h->frame_stride;
-    if (env_opts().warm_any & 8) {   // experiment: every frame of the batch is a new image; its first bands request the rest of the FRAME ahead
-        a.warm_k = env_opts().warm >= 0 ? env_opts().warm : 4;
-        a.warm_exact = env_opts().warm_exact > 0 ? 1 : 0;
-    }
+    // state kept: every frame is a new image -- the waves of a frame's first row bands also request the rest of the FRAME (two bands each:
+    // BasisArgs::warm_k, per frame).  32 x 1080p, same handle, alternating, sustained: +1.2 ... +2.3 % in 7 of 7 processes on three boxes
+    // (four bands +1.3 %, eight +0.3 %; profiles/r06_c4_warm.txt).  Not for the outputs-only batches (-1 %: they are bound by the SIMDs).
+    if (!a.no_state && regular && (size_t)rows * cols >= ((size_t)1 << 20)) a.warm_k = env_opts().warm >= 0 ? env_opts().warm : 2;
     TuneToken tok;
     if ((rc = tune_begin(h, a, 16 | 1 | 4 | (a.no_state ? 8 : 0), false, tok))) return rc;
-    if (env_opts().batch_merge > 0 && !a.no_state && h->layout >= 1 && h->layout != 3) a.merge_orient = 1;   // experiment: one 12-plane group per frame
-    if ((a.merge_orient != 0) != (h->ngrp == 1 && h->kind == CVS_KIND_G2)) {
-        layout_state(h, a.merge_orient != 0);
-        fill_state_args(h, a, true);
-        a.frame_stride = h->frame_stride;
-    }
     note_launch(h, a);
     const hipError_t le = launch_basis(h->kind, h->width, h->taps, a, nullptr, h->stream);
     tune_end(h, tok);

@@ -123,6 +123,7 @@ struct Slot {
     bool last_staged = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t up = nullptr, down = nullptr;  // host planes: upload / download streams beside `stream`
+    std::vector<hipEvent_t> host_ev;           // host planes: the chunk events of host_rank, created once (4 timing + 2 per chunk)
     int* agree = nullptr;                   // 4 ints of device memory for the status agreement of a multi-process world
 };
 
@@ -446,18 +447,25 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
     int persist = 1;
     (void)cvs_get_option(s.h, CVS_OPT_PERSIST_STATE, &persist);
     // with state kept, the handle's frames after the call must be the whole shard: one chunk
-    int want_chunks = 4;
-    if (const char* e = std::getenv("CVS_BATCH_HOST_CHUNKS")) want_chunks = std::max(1, std::atoi(e));   // experiment (round 6)
-    const int nchunks = persist ? 1 : std::min(n, want_chunks);
-    std::vector<int> c0(nchunks + 1);
-    for (int c = 0; c <= nchunks; ++c) c0[c] = (int)((long long)n * c / nchunks);
-    std::vector<hipEvent_t> up_ev(nchunks), done_ev(nchunks);
-    hipEvent_t t[4];
-    for (hipEvent_t& e : t) H_TRY(hipEventCreate(&e));
-    for (int c = 0; c < nchunks; ++c) {
-        H_TRY(hipEventCreateWithFlags(&up_ev[c], hipEventDisableTiming));
-        H_TRY(hipEventCreateWithFlags(&done_ev[c], hipEventDisableTiming));
+    // Chunks GROW (round 6): the downloads set the pace (three maps down for one frame up) and run back to back once the first chunk's
+    // maps exist, so what the chunking costs is the time until then -- upload + launch of the FIRST chunk.  A thirty-second of the shard
+    // first, every later chunk twice its predecessor (its upload and launch hide behind the predecessor's download): 1 | 2 | 4 | 8 | 17 frames
+    // for a shard of 32 instead of four chunks of 8: 0.79 -> 0.84 of the link's roof for 8-bit frames in / three 8-bit maps out
+    // (profiles/r06_host_chunks.txt).
+    std::vector<int> c0(1, 0);
+    if (persist) c0.push_back(n);
+    else
+        for (int sz = std::max(1, n / 32); c0.back() < n; sz *= 2) c0.push_back((n - c0.back() <= sz + sz / 2 || c0.size() >= 5) ? n : c0.back() + sz);
+    const int nchunks = (int)c0.size() - 1;
+    // the events are the slot's own (created once: a dozen hipEventCreate / Destroy per call were a tenth of a small batch's time)
+    while ((int)s.host_ev.size() < 4 + 2 * nchunks) {
+        hipEvent_t ev = nullptr;
+        H_TRY(s.host_ev.size() < 4 ? hipEventCreate(&ev) : hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        s.host_ev.push_back(ev);
     }
+    hipEvent_t* t = s.host_ev.data();
+    hipEvent_t* up_ev = s.host_ev.data() + 4;
+    hipEvent_t* done_ev = s.host_ev.data() + 4 + nchunks;
     // the download thread: chunk c may start once its launch has been queued (counter) and has finished (event)
     std::mutex mu;
     std::condition_variable cv;
@@ -626,8 +634,6 @@ int host_rank(const HostRun& R, Slot& s, std::string& err, double ms[3])
     } else {
         (void)hipDeviceSynchronize();
     }
-    for (hipEvent_t& ev : t) (void)hipEventDestroy(ev);
-    for (int c = 0; c < nchunks; ++c) { (void)hipEventDestroy(up_ev[c]); (void)hipEventDestroy(done_ev[c]); }
     s.last_n = n;
     s.last_k = K;
     s.last_rows = rows;
@@ -800,6 +806,7 @@ int cvs_batch_destroy(cvs_batch b)
         for (hipEvent_t e : s.ev)
             if (e) (void)hipEventDestroy(e);
         if (s.stream) (void)hipStreamDestroy(s.stream);
+        for (hipEvent_t ev : s.host_ev) (void)hipEventDestroy(ev);
         if (s.up) (void)hipStreamDestroy(s.up);
         if (s.down) (void)hipStreamDestroy(s.down);
         if (s.agree) (void)hipFree(s.agree);

@@ -151,7 +151,6 @@ int use_nt_stores(cvs_handle h, size_t npix);
 // process-wide overrides parsed once from the environment variable CVS_OPTS="name=value,..." (include/cvsteer_hip.h)
 struct EnvOpts {
     int autotune = -1, layout = -1, pyr_strip = -1, batch_ways = -1, nt_stores = -1, warm = -1, wgcap = -1, verbose = 0;
-    int warm_exact = -1, warm_any = 0, pyr_nt = -1, pyr_split = -1, batch_merge = -1;   // round-6 experiment switches (tools/ only)
     long pool_mb = 4096;
 };
 EnvOpts env_opts();

@@ -55,11 +55,6 @@ EnvOpts env_opts()
         else if (name == "nt_stores") v.nt_stores = val != 0;
         else if (name == "warm") v.warm = (int)std::max(0L, std::min(16L, val));
         else if (name == "wgcap") v.wgcap = (int)std::max(0L, std::min(8L, val));
-        else if (name == "warm_exact") v.warm_exact = val != 0;
-        else if (name == "warm_any") v.warm_any = (int)val;
-        else if (name == "pyr_nt") v.pyr_nt = val != 0;
-        else if (name == "pyr_split") v.pyr_split = val != 0;
-        else if (name == "batch_merge") v.batch_merge = val != 0;
         else if (name == "verbose") v.verbose = val != 0;
         else if (name == "pool_mb") v.pool_mb = val;
         else std::fprintf(stderr, "[cvsteer] CVS_OPTS: unknown name '%s' ignored\n", name.c_str());

@@ -58,7 +58,6 @@ struct BasisArgs {
     int warm_k;           // new images (set by the API layer; 0 = off): the waves of the launch's first row bands also touch the rows of warm_k
                           // bands further down each, so that the rest of the image is requested while the launch is young (dma_warm)
     int warm_bands;       // ... how many bands do that: ceil(bands / (warm_k + 1)); filled by the launcher
-    int warm_exact;       // experiment switch (round 6): the priming steps wait with the exact count VM_ROWS + nwarm
     int merge_orient;     // host only (cvs_tune.cpp -> do_setup): lay the G2 orientation planes out in one group with the basis planes
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
     int out_row_lo, out_row_hi;    // caller: compute output rows [out_row_lo, out_row_hi) only (0, 0 = the whole image);
@@ -102,7 +101,6 @@ struct BasisArgs {
     // API layer runs the stand-alone k_pyr_down otherwise (identical values).
     float* pyr_out;
     size_t pyr_pitch;          // elements
-    int pyr_nt;                // 1 = the level is written with streaming stores
     // diagnostic builds only (-DCVS_DIAG_STAMPS, tools/k1_timeline.py): per-wave {start, first store, end}
     // 100 MHz real-time stamps; never read by the product, nullptr in normal builds
     unsigned long long* diag;

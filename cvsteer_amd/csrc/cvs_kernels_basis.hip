@@ -47,9 +47,11 @@ namespace cvs {
 // filter-bank descriptors: which distinct 1-D kernels exist and which (row, column) pair
 // makes each basis plane.  Kernel ids: [0, NE) even (mirror), [NE, NE+NO) odd (anti-mirror).
 // ---------------------------------------------------------------------------------------
-// Packed f32.  A wave64 f32 vector instruction occupies its SIMD for FOUR cycles on this GPU, a packed one (v_pk_fma_f32,
-// v_pk_add_f32, v_pk_mul_f32: two f32 results per lane) for four as well (tools/valu_rate.hip: 566 G plain / 536 G packed wave
-// instructions per second chip-wide, profiles/r05_valu_rate.txt), and the strip kernels issue 70-100 % of what the SIMDs take.
+// Packed f32.  Measured on this GPU (tools/valu_rate.hip, profiles/r05_valu_rate.txt; cycles a SIMD is taken per wave64 instruction): a
+// vector instruction with a scalar-register operand -- every tap multiply of the plain form -- 4.3-4.7, a packed one (v_pk_fma_f32,
+// v_pk_add_f32, v_pk_mul_f32: two f32 results per lane) 4.3-4.5, and only tap-free simple instructions on VGPRs / literals 2.3-2.5 (two of
+// them from different waves go through together).  A tap multiply therefore costs what a packed one costs, and the strip kernels issue
+// 70-100 % of what the SIMDs take.
 // So the two passes work on PAIRS: an even (mirror) and an odd (anti-mirror) 1-D kernel side by side in the two halves of a
 // register pair.
 //   row pass     {s[W+i], s[W-i]} -> {sum_i, dif_i} in one v_pk_add_f32 (neg_hi on the second operand); row pair k accumulates
@@ -401,8 +403,10 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 // +3 % for the 12- and 20-plane launches in some processes, +2 % for the G4 pair launch.
 // Two sets of queues per handle, used alternately: a launch takes its tickets from one set and zeroes the OTHER one (which
 // the previous launch of the handle used; launches of a handle are ordered on its stream), so every launch finds its set at
-// zero without a host-side step, a reset kernel or a "last one out" protocol inside the launch.  (Under stream capture the
-// launcher puts a memset node in front instead: a graph replays the same set every time.)
+// zero without a host-side step, a reset kernel or a "last one out" protocol inside the launch.  (Under stream capture -- a graph
+// replays the same set every time -- and for a queue slot that has served another state block the launcher brackets the launch with
+// k_reset_queues launches instead: dynamic_queues below.  Kernels, not memset nodes: a fill's stores sit in an XCD's L2 while the queue
+// atomics execute at the memory side.)
 // ---------------------------------------------------------------------------------------
 constexpr int kQueueStride = 16;    // unsigned ints between two queue heads (64 B); head q at [q * 16], "all queues empty" flag at [8 * 16]
 constexpr int kQueueSetUints = 256; // one set of queues: 1 KiB; a handle's slot holds two
@@ -471,12 +475,128 @@ __device__ __forceinline__ bool pick_tile(const BasisArgs& a, int* s_tile, int& 
     return true;
 }
 
-// the kernel body: one wave filters one strip.  `line` = this wave's LDS ring ((2W+1) x kRingLine floats),
+// the kernel body: one wave filters one strip -- addressing, the hand-counted waits of the input ring and the stores; the arithmetic on
+// values in registers is row_pass / column_pass / pyr_* / pipe_values above.  `line` = this wave's LDS ring ((2W+1) x kRingLine floats),
 // `zframe` = frame index of a batched launch.
 // WPB = waves (adjacent 64-column strips of one row band) per workgroup.  Always 4: 8-wave workgroups were built
 // and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones; one- and
 // two-wave workgroups fill the wave slots better (no slot waits for the slowest of four) but lose 3-12 % on the G2 legs and
 // 7 % on fresh images (profiles/r03_wpb_probe.txt): the four strips of a workgroup write 1 KiB of every plane row from one CU.
+// ---------------------------------------------------------------------------------------
+// The pieces of a row step that work on values in registers only (no addressing, no stores); basis_body below strings them together.
+// All are inlined into the unrolled row loop: `j` is a constant there and every window slot a fixed register.
+// ---------------------------------------------------------------------------------------
+// Row pass: the 2W+1 samples of one input row (P[i] = {sample at +i, sample at -i}) -> window slot j of every row kernel.
+template <class B, bool PK>
+__device__ __forceinline__ void row_pass(const Folded<B>& t, const f2 (&P)[B::W + 1], const int j, f2 (&win2)[B::NRP][2 * B::W + 1],
+                                         [[maybe_unused]] float (&win1)[B::NS ? B::NS : 1][2 * B::W + 1])
+{
+    constexpr int W = B::W;
+    f2 SD[W + 1];   // {sum_i, dif_i}
+#pragma unroll
+    for (int i = 1; i <= W; ++i) SD[i] = pk_sumdif<PK>(P[i]);
+#pragma unroll
+    for (int k = 0; k < B::NRP; ++k) {
+        f2 acc = pk_mul<PK, false>(t.tp[k][W], SD[W]);
+#pragma unroll
+        for (int i = W - 1; i >= 1; --i) acc = pk_fma<PK, false>(t.tp[k][i], SD[i], acc);
+        // the centre tap of an odd kernel is +0.0 (tp[k][0].y): the CPU row filter still multiplies it in, which
+        // matters only for non-finite pixels (0 * Inf = NaN) -- keep that footprint identical
+        acc = pk_fma<PK, false>(t.tp[k][0], P[0], acc);
+        // (pinned here: the compiler would otherwise sink the row pass of the priming steps into the conditional column-pass blocks
+        // that use it, and keep the thirteen samples of every such step alive instead of its results)
+        asm volatile("" : "+v"(acc));
+        win2[k][j] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < B::NS; ++q) {
+        float acc = t.ts[q][W] * SD[W].x;
+#pragma unroll
+        for (int i = W - 1; i >= 1; --i) acc = fmaf(t.ts[q][i], SD[i].x, acc);
+        acc = fmaf(t.ts[q][0], P[0].x, acc);
+        asm volatile("" : "+v"(acc));
+        win1[q][j] = acc;
+    }
+}
+
+// Column pass on the window: the newest row is slot j, the centre row W back = slot (j + 1 + W) % NT.  b[p] = basis plane p of the bank at
+// the centre row.
+template <class B, bool PK>
+__device__ __forceinline__ void column_pass(const Folded<B>& t, const f2 (&win2)[B::NRP][2 * B::W + 1],
+                                            [[maybe_unused]] const float (&win1)[B::NS ? B::NS : 1][2 * B::W + 1], const int j, float (&b)[B::NB])
+{
+    constexpr int W = B::W, NT = 2 * W + 1;
+#pragma unroll
+    for (int q = 0; q < B::NPP; ++q) {
+        constexpr auto slot = [](int jj, int d) constexpr { return (jj + 1 + W + d + NT) % NT; };
+        const PairOp o = B::pp(q);
+        f2 acc;
+        // lo half: column kernel odd when o.swap, hi half: odd when not
+        if (o.swap) {
+            acc = pk_mul<PK, true>(t.tp[o.t][W], pk_addsub<PK, true, false>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
+#pragma unroll
+            for (int i = W - 1; i >= 1; --i)
+                acc = pk_fma<PK, true>(t.tp[o.t][i], pk_addsub<PK, true, false>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
+            acc.y = fmaf(t.tp[o.t][0].x, win2[o.w][slot(j, 0)].y, acc.y);
+        } else {
+            acc = pk_mul<PK, false>(t.tp[o.t][W], pk_addsub<PK, false, true>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
+#pragma unroll
+            for (int i = W - 1; i >= 1; --i)
+                acc = pk_fma<PK, false>(t.tp[o.t][i], pk_addsub<PK, false, true>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
+            acc.x = fmaf(t.tp[o.t][0].x, win2[o.w][slot(j, 0)].x, acc.x);
+        }
+        b[o.lo] = acc.x;
+        b[o.hi] = acc.y;
+    }
+#pragma unroll
+    for (int q = 0; q < B::NSP; ++q) {   // planes outside the pairs: an even row kernel, an even column kernel, plain instructions
+        constexpr auto slot = [](int jj, int d) constexpr { return (jj + 1 + W + d + NT) % NT; };
+        const SingleOp o = B::sp(q);
+        auto wv = [&](int sl) { return o.w >= 0 ? win2[o.w >= 0 ? o.w : 0][sl].x : win1[o.w >= 0 ? 0 : -1 - o.w][sl]; };
+        auto tap = [&](int i) { return o.t >= 0 ? t.tp[o.t >= 0 ? o.t : 0][i].x : t.ts[o.t >= 0 ? 0 : -1 - o.t][i]; };
+        float acc = tap(W) * (wv(slot(j, W)) + wv(slot(j, -W)));
+#pragma unroll
+        for (int i = W - 1; i >= 1; --i) acc = fmaf(tap(i), wv(slot(j, i)) + wv(slot(j, -i)), acc);
+        b[o.plane] = fmaf(tap(0), wv(slot(j, 0)), acc);
+    }
+}
+
+// The callers' sequence (test/test.cpp:86-90) on values still in registers: steer at theta_dom, oriented energy, magnitude / phase, the
+// three feature maps -> q = {g2, h2, e, magnitude, phase, edges, dark lines, bright lines}.  need_e: evaluate the energy (else q[2] = 0);
+// on_e: find*(e, phase) instead of find*(magnitude, phase).
+template <bool FEAT3>
+__device__ __forceinline__ void pipe_values(const float (&b)[7], float th, float c1, float c2, float c3, bool need_e, int amode, bool on_e, float (&q)[8])
+{
+    // theta_dom in (-pi/2, pi/2]: the bounded cos/sin path, no library call
+    g2_steer_angle<true>(b, th, q[0], q[1]);
+    q[2] = 0.f;
+    if (need_e) {
+        float s2, cc2;
+        sincos_small(__fmul_rn(th, 2.0f), s2, cc2);
+        q[2] = __fadd_rn(__fadd_rn(c1, __fmul_rn(c2, cc2)), __fmul_rn(c3, s2));
+    }
+    mag_phase(q[0], q[1], amode, q[3], q[4]);
+    const float en = on_e ? q[2] : q[3];
+    float le, ld, lb;
+    phase_lambda3<true>(q[4], le, ld, lb);   // one cos / sin pair for the three maps
+    q[5] = __fmul_rn(en, le);
+    q[6] = __fmul_rn(en, ld);
+    q[7] = __fmul_rn(en, lb);
+}
+
+// cv::pyrDown on the rows the wave has staged anyway (launch_pyr_down's arithmetic, op for op): hw = the last five horizontally blurred rows
+// ([1 4 6 4 1] at this lane's column), newest last; pyr_column = the vertical blur of the five, before the 1/256.
+template <int WP1>
+__device__ __forceinline__ void pyr_shift_in(float (&hw)[5], const f2 (&P)[WP1])
+{
+    hw[0] = hw[1]; hw[1] = hw[2]; hw[2] = hw[3]; hw[3] = hw[4];
+    hw[4] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P[0].x, 6.0f), __fmul_rn(__fadd_rn(P[1].y, P[1].x), 4.0f)), P[2].y), P[2].x);
+}
+__device__ __forceinline__ float pyr_column(const float (&hw)[5])
+{
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(hw[2], 6.0f), __fmul_rn(__fadd_rn(hw[1], hw[3]), 4.0f)), hw[0]), hw[4]);
+}
+
 #ifdef CVS_DIAG_CANARY
 #define CVS_BST(ST, ...) (++st_tally, bst<ST>(__VA_ARGS__))
 #else
@@ -598,7 +718,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     [[maybe_unused]] float win1[B::NS ? B::NS : 1][NT];
     // F_PYR: the last five horizontally blurred rows ([1 4 6 4 1] at this lane's column); even lanes of even centre
     // rows make one pixel of the next pyramid level each (launch_pyr_down's arithmetic, op for op)
-    [[maybe_unused]] float hw0 = 0.f, hw1 = 0.f, hw2 = 0.f, hw3 = 0.f, hw4 = 0.f;
+    [[maybe_unused]] float hw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] rsrc_t r_pyr = plane_rsrc(nullptr, 0);
     [[maybe_unused]] unsigned xpb = kLaneOff, pyr_pitch_b = 0;
     if constexpr ((FLAGS & F_PYR) != 0) {
@@ -689,9 +809,11 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 // row nobody uses; their count may be short, which only lets them read a line that is still being written.)
                 if constexpr (PHASE == 0) {
                     // window priming: behind row j's halo load lie the loads of the NT - 1 - j first rows that followed it, the nwarm
-                    // read-ahead loads and the j refills issued since -- VM_ROWS + nwarm at every step (56 at most: the counter has 6 bits)
-                    if (nwarm > 0 && a.warm_exact) wait_vmcnt(VM_ROWS + nwarm);
-                    else if (nwarm >= NT) wait_vmcnt(VM_ROWS + NT);
+                    // read-ahead loads and the j refills issued since: VM_ROWS + nwarm.  The wait uses VM_ROWS + min(nwarm, NT) -- two
+                    // immediates instead of a run-time switch; the exact count was measured in round 6 and buys nothing (M2 +0.0 %, M1 -1.1 %,
+                    // 8192^2 -0.2 %: profiles/r06_fresh_exact_wait.txt), the read-ahead loads are L2 / HBM requests that have long been
+                    // overtaken by the rows' own loads when the first row is needed
+                    if (nwarm >= NT) wait_vmcnt(VM_ROWS + NT);
                     else wait_vmcnt(VM_ROWS);
                 }
                 else if (VM_ROWS + S_ROW * (j + 1) >= 63) wait_vmcnt(63);   // (a constant once the loop is unrolled)
@@ -742,43 +864,19 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 
             if constexpr ((FLAGS & F_PYR) != 0) {
                 static_assert(W >= 2, "the pyramid level needs two columns / rows of halo");
-                hw0 = hw1; hw1 = hw2; hw2 = hw3; hw3 = hw4;
-                hw4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P[0].x, 6.0f), __fmul_rn(__fadd_rn(P[1].y, P[1].x), 4.0f)), P[2].y), P[2].x);
+                pyr_shift_in(hw, P);
                 // newest staged row = y0 - W + i (reflected like the image rows themselves); it completes the 5-row window of
                 // centre row c = y0 + i - W - 2.  This strip owns the even centre rows in [y0, yend).
                 const int ci = g * NT + j - W - 2;  // centre row relative to y0, wave-uniform
                 if (ci >= 0 && ci < yend - y0 && ((y0 + ci) & 1) == 0) {
-                    const float v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(hw2, 6.0f), __fmul_rn(__fadd_rn(hw1, hw3), 4.0f)), hw0), hw4);
-                    if (a.pyr_nt) CVS_BST(true, r_pyr, xpb, (unsigned)((y0 + ci) >> 1) * pyr_pitch_b, __fmul_rn(v, 1.0f / 256.0f));
-                    else CVS_BST(false, r_pyr, xpb, (unsigned)((y0 + ci) >> 1) * pyr_pitch_b, __fmul_rn(v, 1.0f / 256.0f));
+                    const float v = pyr_column(hw);
+                    // (cached stores: the next level's launch finds its image in the Infinity Cache.  Streaming stores + read-ahead make THIS launch
+                    // 7 % faster and the five-level call 2-3 % slower: profiles/r06_c3_variants.txt, r06_c3_chain_localisation.txt)
+                    CVS_BST(false, r_pyr, xpb, (unsigned)((y0 + ci) >> 1) * pyr_pitch_b, __fmul_rn(v, 1.0f / 256.0f));
                 }
             }
             if constexpr ((FLAGS & F_PYRONLY) == 0) {
-            f2 SD[W + 1];   // {sum_i, dif_i}
-#pragma unroll
-            for (int i = 1; i <= W; ++i) SD[i] = pk_sumdif<PK>(P[i]);
-#pragma unroll
-            for (int k = 0; k < B::NRP; ++k) {
-                f2 acc = pk_mul<PK, false>(t.tp[k][W], SD[W]);
-#pragma unroll
-                for (int i = W - 1; i >= 1; --i) acc = pk_fma<PK, false>(t.tp[k][i], SD[i], acc);
-                // the centre tap of an odd kernel is +0.0 (tp[k][0].y): the CPU row filter still multiplies it in, which
-                // matters only for non-finite pixels (0 * Inf = NaN) -- keep that footprint identical
-                acc = pk_fma<PK, false>(t.tp[k][0], P[0], acc);
-                // (pinned here: the compiler would otherwise sink the row pass of the priming steps into the conditional column-pass blocks
-                // that use it, and keep the thirteen samples of every such step alive instead of its results)
-                asm volatile("" : "+v"(acc));
-                win2[k][j] = acc;
-            }
-#pragma unroll
-            for (int q = 0; q < B::NS; ++q) {
-                float acc = t.ts[q][W] * SD[W].x;
-#pragma unroll
-                for (int i = W - 1; i >= 1; --i) acc = fmaf(t.ts[q][i], SD[i].x, acc);
-                acc = fmaf(t.ts[q][0], P[0].x, acc);
-                asm volatile("" : "+v"(acc));
-                win1[q][j] = acc;
-            }
+            row_pass<B, PK>(t, P, j, win2, win1);
 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----
             // which output row this is, and whether the strip owns it (wave-uniform)
@@ -826,40 +924,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     for (int k = (FLAGS & F_FEAT3) != 0 ? 5 : 0; k < 8; ++k) b2_off[k] = ka->out_off[k];
                 }
                 float b[NB];
-                // window slots: the newest row is slot j, the centre row W back = slot (j + 1 + W) % NT
-#pragma unroll
-                for (int q = 0; q < B::NPP; ++q) {
-                    constexpr auto slot = [](int jj, int d) constexpr { return (jj + 1 + W + d + NT) % NT; };
-                    const PairOp o = B::pp(q);
-                    f2 acc;
-                    // lo half: column kernel odd when o.swap, hi half: odd when not
-                    if (o.swap) {
-                        acc = pk_mul<PK, true>(t.tp[o.t][W], pk_addsub<PK, true, false>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
-#pragma unroll
-                        for (int i = W - 1; i >= 1; --i)
-                            acc = pk_fma<PK, true>(t.tp[o.t][i], pk_addsub<PK, true, false>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
-                        acc.y = fmaf(t.tp[o.t][0].x, win2[o.w][slot(j, 0)].y, acc.y);
-                    } else {
-                        acc = pk_mul<PK, false>(t.tp[o.t][W], pk_addsub<PK, false, true>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
-#pragma unroll
-                        for (int i = W - 1; i >= 1; --i)
-                            acc = pk_fma<PK, false>(t.tp[o.t][i], pk_addsub<PK, false, true>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
-                        acc.x = fmaf(t.tp[o.t][0].x, win2[o.w][slot(j, 0)].x, acc.x);
-                    }
-                    b[o.lo] = acc.x;
-                    b[o.hi] = acc.y;
-                }
-#pragma unroll
-                for (int q = 0; q < B::NSP; ++q) {   // planes outside the pairs: an even row kernel, an even column kernel, plain instructions
-                    constexpr auto slot = [](int jj, int d) constexpr { return (jj + 1 + W + d + NT) % NT; };
-                    const SingleOp o = B::sp(q);
-                    auto wv = [&](int sl) { return o.w >= 0 ? win2[o.w >= 0 ? o.w : 0][sl].x : win1[o.w >= 0 ? 0 : -1 - o.w][sl]; };
-                    auto tap = [&](int i) { return o.t >= 0 ? t.tp[o.t >= 0 ? o.t : 0][i].x : t.ts[o.t >= 0 ? 0 : -1 - o.t][i]; };
-                    float acc = tap(W) * (wv(slot(j, W)) + wv(slot(j, -W)));
-#pragma unroll
-                    for (int i = W - 1; i >= 1; --i) acc = fmaf(tap(i), wv(slot(j, i)) + wv(slot(j, -i)), acc);
-                    b[o.plane] = fmaf(tap(0), wv(slot(j, 0)), acc);
-                }
+                column_pass<B, PK>(t, win2, win1, j, b);
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
                 // output row relative to the plane pointers, and its byte offset in a state plane
                 unsigned yo, orow;
@@ -903,24 +968,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                             else CVS_BST(STREAM, plane_rsrc(orient_p + (size_t)k * a.orient_stride, oplane_bytes), xbr, orow_o, ov[k]);
                     }
                     if constexpr ((FLAGS & F_PIPE) != 0) {
-                        // the callers' sequence (test/test.cpp:86-90) on values still in registers:
-                        // steer at theta_dom, energy, magnitude/phase, the three feature maps
                         float q[8];
-                        // theta_dom in (-pi/2, pi/2]: the bounded cos/sin path, no library call
-                        g2_steer_angle<true>(b, th, q[0], q[1]);
-                        q[2] = 0.f;
-                        if (need_e) {
-                            float s2, cc2;
-                            sincos_small(__fmul_rn(th, 2.0f), s2, cc2);
-                            q[2] = __fadd_rn(__fadd_rn(c1, __fmul_rn(c2, cc2)), __fmul_rn(c3, s2));
-                        }
-                        mag_phase(q[0], q[1], amode, q[3], q[4]);
-                        const float en = (!FEAT3 && a.find_on_e) ? q[2] : q[3];
-                        float le, ld, lb;
-                        phase_lambda3<true>(q[4], le, ld, lb);   // one cos / sin pair for the three maps
-                        q[5] = __fmul_rn(en, le);
-                        q[6] = __fmul_rn(en, ld);
-                        q[7] = __fmul_rn(en, lb);
+                        pipe_values<FEAT3>(b, th, c1, c2, c3, need_e, amode, !FEAT3 && a.find_on_e, q);
                         if constexpr (BATCH == 2) {
                             if constexpr ((FLAGS & F_NOSTATE) != 0) {   // outputs only: pitch and plane offsets were read at the top of this row's block (not kept across
                                                                         // rows; with the state planes written too that costs more scalar work than it saves)

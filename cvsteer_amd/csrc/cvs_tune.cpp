@@ -65,9 +65,10 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // samples of the 32 x 1080p batch in 8 of 22 bench processes and then ran 6 % behind the plain order, a five-workgroups-per-CU
 // challenger for the full setup won in 13 of 13 and ran 3 % behind (profiles/r05_bench_lines*.jsonl).  Now a candidate's
 // turn is a run of kTurnMin..kTurnMax consecutive calls (about kTurnMs of GPU time), the first kLead of which are not counted,
-// and what is compared are the MEDIANS OF WHOLE TURNS: a challenger replaces the default only if, after at least two rounds,
-// every one of its turns was at least kGain faster than every turn of the default; challengers whose turns are not ahead of the
-// default's by half that margin on the median are dropped after two rounds; after kMaxRounds the default stays.  The default leads every
+// and what is compared are the MEDIANS OF WHOLE TURNS: a challenger replaces the default only if, after at least two rounds, its
+// median turn is at least kGain faster than the default's median turn and its turns -- all of two, all but one of three or four --
+// are ahead of the default's median turn by half that; challengers that are not ahead by even half the margin on the median are
+// dropped after two rounds; after kMaxRounds the default stays.  The default leads every
 // round (a card coming out of an idle pause speeds up over tens of launches: whoever is sampled later looks faster -- that drift
 // can only work against a challenger).
 //
@@ -117,7 +118,7 @@ static std::map<int, std::vector<hipEvent_t>> g_free_events;   // per device: ti
 constexpr int kLead = 5;                        // calls at the head of a turn that are not counted
 constexpr int kTurnMin = 20, kTurnMax = 100;    // calls per turn
 constexpr double kTurnMs = 12.0;                // ... about this much GPU time
-constexpr int kMinRounds = 2, kMaxRounds = 3, kMaxUnfit = 3;
+constexpr int kMinRounds = 2, kMaxRounds = 4, kMaxUnfit = 3;
 constexpr float kGain = 0.02f;
 
 static void apply(BasisArgs& a, const Cand& c)
@@ -150,13 +151,11 @@ static void evaluate(TuneEntry& e)
         if (e.turn[c].size() >= 4) e.medians[c].push_back(median_of(e.turn[c]));   // (a turn most of whose samples failed to record does not count)
         e.turn[c].clear();
     }
-    auto lo = [](const std::vector<float>& v) { return *std::min_element(v.begin(), v.end()); };
-    auto hi = [](const std::vector<float>& v) { return *std::max_element(v.begin(), v.end()); };
     int decision = -1;
     if (e.medians[0].empty()) {   // every sample of the default failed to record: nothing to hold a challenger against
         if (e.round >= kMaxRounds) decision = 0;
     } else if (e.round >= kMinRounds) {
-        const float d_best = lo(e.medians[0]), d_mid = median_of(e.medians[0]);
+        const float d_mid = median_of(e.medians[0]);
         int best = -1, live = 0;
         float mbest = std::numeric_limits<float>::max();
         for (size_t c = 1; c < e.cand.size(); ++c) {
@@ -167,9 +166,14 @@ static void evaluate(TuneEntry& e)
                 continue;
             }
             const float m = median_of(e.medians[c]);
-            if (m > d_mid * (1.0f - 0.5f * kGain)) { e.dropped[c] = 1; continue; }   // not ahead by even half the margin: out
+            if (m > d_mid * (1.0f - 0.5f * kGain)) { e.dropped[c] = 1; continue; }   // not ahead by even half the margin on the median: out
             ++live;
-            if (hi(e.medians[c]) <= d_best * (1.0f - kGain) && m < mbest) { mbest = m; best = (int)c; }   // every turn ahead of every turn of the default
+            // kept: its median turn kGain ahead of the default's median turn, and its turns -- all of two, all but one of three or four (a
+            // turn that ran into somebody else's burst) -- ahead of the default's median turn by half that
+            int wins = 0;
+            for (float v : e.medians[c]) wins += v <= d_mid * (1.0f - 0.5f * kGain) ? 1 : 0;
+            const int nt_ = (int)e.medians[c].size();
+            if (m <= d_mid * (1.0f - kGain) && wins >= nt_ - (nt_ >= 3 ? 1 : 0) && m < mbest) { mbest = m; best = (int)c; }
         }
         if (best >= 0) decision = best;
         else if (live == 0 || e.round >= kMaxRounds) decision = 0;

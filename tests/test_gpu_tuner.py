@@ -134,12 +134,15 @@ def test_new_images_are_requested_ahead_and_results_do_not_change(cv, monkeypatc
                     assert torch.equal(a_, b_), (shape, order, it)
             f.setup(imgs[0]); f.setup(imgs[0])
             assert f.launch_info()["warm"] == 0          # the same image again: resident, nothing to request ahead
-        # forced on where the engine leaves it off (G4: both half banks; the launch that emits the next pyramid level), and a row range
+        # G4 (both half banks request ahead, round 6), the launch that emits the next pyramid level (never does), and a row range
         f4w, f4p = cv.SteerableFiltersG4(None), cv.SteerableFiltersG4(None)
+        monkeypatch.setenv("CVS_OPTS", "warm=0")
         f4p.setup(imgs[1])
         assert f4p.launch_info()["warm"] == 0
-        monkeypatch.setenv("CVS_OPTS", "warm=3")
+        monkeypatch.delenv("CVS_OPTS")
         f4w.setup(imgs[1])
+        assert f4w.launch_info()["warm"] == (4 if big else 0)
+        monkeypatch.setenv("CVS_OPTS", "warm=3")
         fpw = cv.SteerableFiltersG2(None)
         lvl_w = fpw.setup_pyr(imgs[2], flags=cv.SETUP_BASIS)
         monkeypatch.delenv("CVS_OPTS")
@@ -156,6 +159,35 @@ def test_new_images_are_requested_ahead_and_results_do_not_change(cv, monkeypatc
         fr._check(cv.lib().cvs_setup_rows(fr._h, C.byref(pl), cv.SETUP_BASIS, lo, hi), "cvs_setup_rows")
         for p in (0, 6):
             assert torch.equal(fr.basis(p)[lo:hi], refs[2][2 + p][lo:hi]), (shape, p, "rows")
+
+
+def test_frames_of_a_state_kept_batch_are_requested_ahead_and_results_do_not_change(cv, monkeypatch):
+    """cvs_pipeline_batch with the state kept on frames of 1 Mpix and more: every frame's first row bands also request the rest of the frame
+    (cvs_launch_info.warm = 2, per frame); outputs-only batches and small frames do not.  Outputs and state planes are the bits of CVS_OPTS warm=0."""
+    import torch
+    from cvsteer_amd import _lib as L
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    for shape, want in (((1080, 1920), 2), ((300, 500), 0)):
+        frames = torch.rand((5,) + shape, device="cuda", generator=gen)
+        monkeypatch.setenv("CVS_OPTS", "warm=0")
+        ref = cv.SteerableFiltersG2(None)
+        r_out = ref.pipeline_batch(frames).clone()
+        assert ref.launch_info()["warm"] == 0
+        ref.select_frame(3)
+        r_state = [ref.basis(p).clone() for p in range(7)] + [ref.getDominantOrientationAngle().clone()]
+        monkeypatch.delenv("CVS_OPTS")
+        for order in (L.ORDER_PLAIN, L.ORDER_DYNAMIC_TAIL):
+            f = cv.SteerableFiltersG2(None)
+            f.set_option(L.OPT_BLOCK_ORDER, order)
+            out = f.pipeline_batch(frames)
+            assert f.launch_info()["warm"] == want, (shape, f.launch_info())
+            f.select_frame(3)
+            assert torch.equal(out, r_out), (shape, order)
+            for a_, b_ in zip([f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle()], r_state):
+                assert torch.equal(a_, b_), (shape, order)
+            f.set_persist(False)
+            out3 = f.pipeline_batch(frames, outputs=(5, 6, 7))
+            assert f.launch_info()["warm"] == 0 and torch.equal(out3, r_out[:, 5:8])
 
 
 def test_objects_come_and_go_without_draining_the_device(cv):

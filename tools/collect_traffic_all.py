@@ -47,7 +47,7 @@ for key in sorted(w):
         if key[0].startswith(pref) and abs(wr - wexp) <= 0.03 * wexp:
             row.update({"leg": leg, "algorithmic_bytes": alg, "hbm_over_algorithmic": round((fr + wr) / alg, 3)})
     rows.append(row)
-out = {"method": "see tools/profile_traffic_all.sh; bench.py --placement 0 (plain blocks), resident images unless the leg says otherwise: "
+out = {"method": "see tools/profile_traffic_all.sh (counter-only rocprofv3 passes over bench.py --all-legs, library defaults), resident images unless the leg says otherwise: "
                  "a resident 4096^2 / 1080p input is served by the Infinity Cache, so read_bytes can be BELOW the input's size",
        "rows": rows}
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic_all_legs.json" % rnd), "w"), indent=1)

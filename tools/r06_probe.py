@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/r06_probe.py -- round-6 A/B probes, one process = one allocation history (run it in several).  Every comparison is made
 on ONE handle / state block with the online tuner off, settings alternating, SUSTAINED regions (a lead-in of a third of the region,
-then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c4w c4m tune
+then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c4w c4m strips tune
   c4     32 x 1080p caller pipeline with state kept (BASELINE config 4): plain order vs dynamic tail, workgroups per CU, batch ways,
          strip height, planar [n][8][H][W] outputs vs row-interleaved [n][H][8][W] ones
   m4     full setup at 4096^2: two plane groups (layout 1) vs one merged group (layout 2), workgroups per CU
@@ -412,3 +412,24 @@ if "c4m" in sections:
     print("   merged + warm: outputs and state planes of frame 7 bit-identical to the default: %s (state_layout %d)" % (same, ff.launch_info()["state_layout"]))
     opts("")()
     del fsets, fout, ff
+
+
+if "strips" in sections:
+    # the default strip height of mid-size images (states the Infinity Cache holds: 19 rows since round 2) against 10 rows, tuner off
+    for shape in ((1024, 1024), (1080, 1920), (1536, 2048), (2048, 2048), (2160, 3840)):
+        r, c = shape
+        img = torch.rand(shape, device="cuda")
+        g, h = cv.alloc_planes(2, r, c, device="cuda")
+        o8 = cv.alloc_planes(8, r, c, device="cuda")
+        f = cv.SteerableFiltersG2(None, 4, 0.67)
+
+        def sr(n):
+            def fn():
+                f.set_option(L.OPT_STRIP_ROWS, n)
+                opts("")()
+            return fn
+        for name, bpp, fn in (("M1", 32, lambda: f.setup(img, flags=cv.SETUP_BASIS)), ("M2", 40, lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))),
+                              ("M4", 52, lambda: f.setup(img, flags=cv.SETUP_FULL)), ("M5", 84, lambda: f.pipeline(img, out=o8))):
+            fn()
+            ab("%s %dx%d" % (name, r, c), bpp * r * c, 200, [("default (0)", sr(0), fn), ("10 rows", sr(10), fn), ("19 rows", sr(19), fn), ("28 rows", sr(28), fn)], rounds=2)
+        del f, img, g, h, o8
