@@ -23,7 +23,7 @@ int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input)
     //   G2  10 rows (k = 2): ~14k waves per 4096^2 launch keep every CU's store queues busy, the extra halo rows are cache
     //       hits, and on a stream of new images vertically adjacent strips must run close in time for their shared rows to
     //       hit (8 rotating images, round 2: 10-row strips 66 %, 19-row strips 57 %).  19 rows (k = 3) remain the default for
-    //       states the Infinity Cache holds; the tuner compares both heights there.
+    //       images below 3 Mpix whose state the Infinity Cache holds; the tuner compares both heights there.
     //   G4  40 rows (k = 4) for the half banks: the pair launch is close to SIMD-bound, and 27-row strips filter 44 % more
     //       rows than they write against 30 % (-3..-6 %, profiles/r04_order_probe.txt).
     const int nt = 2 * h->width + 1, halo = 2 * h->width;
@@ -32,7 +32,10 @@ int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input)
     long k = std::lround((ideal + halo) / nt);
     const bool big_state = h->sb.base != nullptr && h->num_frames == 1 &&
                            (size_t)rows * cols * sizeof(float) * (size_t)(h->nb + 5) >= ((size_t)256 << 20);   // states the Infinity Cache cannot hold
-    const long kmax = h->kind == CVS_KIND_G4 ? 4 : (fresh_input || big_state || (size_t)rows * cols >= ((size_t)32 << 20)) ? 2 : 3;
+    // (round 6: 10 rows from 3 Mpix on whatever the state's size -- same handle, tuner off, two processes: at 1536 x 2048 and 2048^2 the full
+    // setup, the fused steer and the caller pipeline run 6-17 % faster with 10 rows than with 19, the basis pass -2 ... +12 %; at 1080p the two
+    // heights are level, 19 rows 2-6 % ahead for the basis pass: profiles/r06_strip_heights_mid_size.txt)
+    const long kmax = h->kind == CVS_KIND_G4 ? 4 : (fresh_input || big_state || (size_t)rows * cols >= ((size_t)3 << 20)) ? 2 : 3;
     if (k < 2) k = 2;
     if (k > kmax) k = kmax;
     return (int)(k * nt - halo);

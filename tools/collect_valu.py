@@ -13,7 +13,7 @@ def rows(sub):
         out += [r for r in csv.DictReader(open(fn)) if r["Counter_Name"] == "SQ_INSTS_VALU"]
     return out
 cal = [float(r["Counter_Value"]) for r in rows("pmc_valu_cal") if "k<0>" in r["Kernel_Name"]]
-# tools/valu_rate.hip k<0> (inline-asm v_fma_f32, nothing for the compiler to pack) as tools/profile_all_r05.sh runs it (4096 iterations):
+# tools/valu_rate.hip k<0> (inline-asm v_fma_f32, nothing for the compiler to pack) as tools/profile_all.sh runs it (4096 iterations):
 # 2048 workgroups x 4 waves, 4096 iterations x 16 vector instructions per wave (+ ~50 of set-up / final sum)
 known = 2048 * 4 * (4096 * 16 + 50)
 factor = known / (sum(cal) / len(cal)) if cal else 1.0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_all_r05.sh -- one GPU call: kernel-trace stats (headline; all legs), PMC traffic (headline; all legs), SQ counters,
+# tools/profile_all.sh -- one GPU call: kernel-trace stats (headline; all legs), PMC traffic (headline; all legs), SQ counters,
 # vector-instruction counts with their calibration.  Raw output in gpurun_out/; tools/collect_*.py condense it into profiles/.
 set -u
 export TMPDIR=/tmp
