@@ -40,6 +40,7 @@
 
 #include "cvs_device_math.h"
 #include "cvs_internal.h"
+#include "cvs_lit_taps.h"
 
 namespace cvs {
 
@@ -167,6 +168,26 @@ template <class B>
 struct Folded {
     f2 tp[B::NTP][B::W + 1];
     float ts[B::NS ? B::NS : 1][B::W + 1];
+};
+
+// Where a launch's taps come from.  TapsArg: the kernel arguments (scalar registers; any taps the handle was made with).  TapsLitG2: the
+// reference's DEFAULT G2 / H2 taps as compile-time constants -- they end up as 32-bit literals in the instructions.  Why: a vector instruction
+// with a scalar-register operand takes its SIMD for 4.3-4.7 cycles, the same instruction with a literal 2.3-2.5 and goes through beside
+// another wave's (profiles/r05_valu_rate.txt), and the pipeline variants -- plain arithmetic, bound by instruction issue -- spend a quarter of
+// their vector instructions on tap multiplies.  Same operations on the same values in the same order: bit-identical.  The launcher picks
+// the literal instance only when the handle's folded taps equal the table bit for bit (launch_fast_impl).
+template <class B>
+struct TapsArg {
+    const Folded<B>& t;
+    __device__ __forceinline__ f2 tp(int m, int i) const { return t.tp[m][i]; }
+    __device__ __forceinline__ float ts(int q, int i) const { return t.ts[q][i]; }
+};
+struct TapsLitG2 {
+    __device__ __forceinline__ f2 tp(int m, int i) const
+    {
+        return f2{__builtin_bit_cast(float, kLitEvenG2[BankG2::te(m)][i]), __builtin_bit_cast(float, kLitOddG2[BankG2::to(m)][i])};
+    }
+    __device__ __forceinline__ float ts(int, int) const { return 0.f; }
 };
 
 // PK = false: the same results from plain instructions on the two halves (same operations, same order).
@@ -487,8 +508,8 @@ __device__ __forceinline__ bool pick_tile(const BasisArgs& a, int* s_tile, int& 
 // All are inlined into the unrolled row loop: `j` is a constant there and every window slot a fixed register.
 // ---------------------------------------------------------------------------------------
 // Row pass: the 2W+1 samples of one input row (P[i] = {sample at +i, sample at -i}) -> window slot j of every row kernel.
-template <class B, bool PK>
-__device__ __forceinline__ void row_pass(const Folded<B>& t, const f2 (&P)[B::W + 1], const int j, f2 (&win2)[B::NRP][2 * B::W + 1],
+template <class B, bool PK, class T>
+__device__ __forceinline__ void row_pass(const T& t, const f2 (&P)[B::W + 1], const int j, f2 (&win2)[B::NRP][2 * B::W + 1],
                                          [[maybe_unused]] float (&win1)[B::NS ? B::NS : 1][2 * B::W + 1])
 {
     constexpr int W = B::W;
@@ -497,12 +518,12 @@ __device__ __forceinline__ void row_pass(const Folded<B>& t, const f2 (&P)[B::W 
     for (int i = 1; i <= W; ++i) SD[i] = pk_sumdif<PK>(P[i]);
 #pragma unroll
     for (int k = 0; k < B::NRP; ++k) {
-        f2 acc = pk_mul<PK, false>(t.tp[k][W], SD[W]);
+        f2 acc = pk_mul<PK, false>(t.tp(k, W), SD[W]);
 #pragma unroll
-        for (int i = W - 1; i >= 1; --i) acc = pk_fma<PK, false>(t.tp[k][i], SD[i], acc);
+        for (int i = W - 1; i >= 1; --i) acc = pk_fma<PK, false>(t.tp(k, i), SD[i], acc);
         // the centre tap of an odd kernel is +0.0 (tp[k][0].y): the CPU row filter still multiplies it in, which
         // matters only for non-finite pixels (0 * Inf = NaN) -- keep that footprint identical
-        acc = pk_fma<PK, false>(t.tp[k][0], P[0], acc);
+        acc = pk_fma<PK, false>(t.tp(k, 0), P[0], acc);
         // (pinned here: the compiler would otherwise sink the row pass of the priming steps into the conditional column-pass blocks
         // that use it, and keep the thirteen samples of every such step alive instead of its results)
         asm volatile("" : "+v"(acc));
@@ -510,10 +531,10 @@ __device__ __forceinline__ void row_pass(const Folded<B>& t, const f2 (&P)[B::W 
     }
 #pragma unroll
     for (int q = 0; q < B::NS; ++q) {
-        float acc = t.ts[q][W] * SD[W].x;
+        float acc = t.ts(q, W) * SD[W].x;
 #pragma unroll
-        for (int i = W - 1; i >= 1; --i) acc = fmaf(t.ts[q][i], SD[i].x, acc);
-        acc = fmaf(t.ts[q][0], P[0].x, acc);
+        for (int i = W - 1; i >= 1; --i) acc = fmaf(t.ts(q, i), SD[i].x, acc);
+        acc = fmaf(t.ts(q, 0), P[0].x, acc);
         asm volatile("" : "+v"(acc));
         win1[q][j] = acc;
     }
@@ -521,8 +542,8 @@ __device__ __forceinline__ void row_pass(const Folded<B>& t, const f2 (&P)[B::W 
 
 // Column pass on the window: the newest row is slot j, the centre row W back = slot (j + 1 + W) % NT.  b[p] = basis plane p of the bank at
 // the centre row.
-template <class B, bool PK>
-__device__ __forceinline__ void column_pass(const Folded<B>& t, const f2 (&win2)[B::NRP][2 * B::W + 1],
+template <class B, bool PK, class T>
+__device__ __forceinline__ void column_pass(const T& t, const f2 (&win2)[B::NRP][2 * B::W + 1],
                                             [[maybe_unused]] const float (&win1)[B::NS ? B::NS : 1][2 * B::W + 1], const int j, float (&b)[B::NB])
 {
     constexpr int W = B::W, NT = 2 * W + 1;
@@ -533,17 +554,17 @@ __device__ __forceinline__ void column_pass(const Folded<B>& t, const f2 (&win2)
         f2 acc;
         // lo half: column kernel odd when o.swap, hi half: odd when not
         if (o.swap) {
-            acc = pk_mul<PK, true>(t.tp[o.t][W], pk_addsub<PK, true, false>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
+            acc = pk_mul<PK, true>(t.tp(o.t, W), pk_addsub<PK, true, false>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
 #pragma unroll
             for (int i = W - 1; i >= 1; --i)
-                acc = pk_fma<PK, true>(t.tp[o.t][i], pk_addsub<PK, true, false>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
-            acc.y = fmaf(t.tp[o.t][0].x, win2[o.w][slot(j, 0)].y, acc.y);
+                acc = pk_fma<PK, true>(t.tp(o.t, i), pk_addsub<PK, true, false>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
+            acc.y = fmaf(t.tp(o.t, 0).x, win2[o.w][slot(j, 0)].y, acc.y);
         } else {
-            acc = pk_mul<PK, false>(t.tp[o.t][W], pk_addsub<PK, false, true>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
+            acc = pk_mul<PK, false>(t.tp(o.t, W), pk_addsub<PK, false, true>(win2[o.w][slot(j, W)], win2[o.w][slot(j, -W)]));
 #pragma unroll
             for (int i = W - 1; i >= 1; --i)
-                acc = pk_fma<PK, false>(t.tp[o.t][i], pk_addsub<PK, false, true>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
-            acc.x = fmaf(t.tp[o.t][0].x, win2[o.w][slot(j, 0)].x, acc.x);
+                acc = pk_fma<PK, false>(t.tp(o.t, i), pk_addsub<PK, false, true>(win2[o.w][slot(j, i)], win2[o.w][slot(j, -i)]), acc);
+            acc.x = fmaf(t.tp(o.t, 0).x, win2[o.w][slot(j, 0)].x, acc.x);
         }
         b[o.lo] = acc.x;
         b[o.hi] = acc.y;
@@ -553,7 +574,7 @@ __device__ __forceinline__ void column_pass(const Folded<B>& t, const f2 (&win2)
         constexpr auto slot = [](int jj, int d) constexpr { return (jj + 1 + W + d + NT) % NT; };
         const SingleOp o = B::sp(q);
         auto wv = [&](int sl) { return o.w >= 0 ? win2[o.w >= 0 ? o.w : 0][sl].x : win1[o.w >= 0 ? 0 : -1 - o.w][sl]; };
-        auto tap = [&](int i) { return o.t >= 0 ? t.tp[o.t >= 0 ? o.t : 0][i].x : t.ts[o.t >= 0 ? 0 : -1 - o.t][i]; };
+        auto tap = [&](int i) { return o.t >= 0 ? t.tp(o.t >= 0 ? o.t : 0, i).x : t.ts(o.t >= 0 ? 0 : -1 - o.t, i); };
         float acc = tap(W) * (wv(slot(j, W)) + wv(slot(j, -W)));
 #pragma unroll
         for (int i = W - 1; i >= 1; --i) acc = fmaf(tap(i), wv(slot(j, i)) + wv(slot(j, -i)), acc);
@@ -602,7 +623,7 @@ __device__ __forceinline__ float pyr_column(const float (&hw)[5])
 #else
 #define CVS_BST(ST, ...) bst<ST>(__VA_ARGS__)
 #endif
-template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB, bool U8 = false>
+template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB, bool U8 = false, bool LIT = false>
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe, const int bx, const int by)
 {
     constexpr unsigned EB = U8 ? 1u : 4u;   // bytes per input sample
@@ -613,6 +634,10 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
     // the eight-outputs-only batch 4 % slower packed (profiles/r05_packed_ab.txt, table 7).  The orientation-only epilogue (full setup) is
     // level to 1 % ahead packed and stays packed.
     constexpr bool PK = (FLAGS & F_PIPE) == 0;
+    // LIT: the taps are the reference's defaults, compiled in as literals (TapsLitG2) -- the plain-arithmetic pipeline variants of the G2 bank only
+    static_assert(!LIT || (!PK && B::KIND == 2 && B::HALF == 0), "literal taps exist for the pipeline variants of the whole G2 bank");
+    using Taps = std::conditional_t<LIT, TapsLitG2, TapsArg<B>>;
+    const Taps taps = [&]() -> Taps { if constexpr (LIT) return TapsLitG2{}; else return TapsArg<B>{t}; }();
     // vector-memory instructions per output row that EVERY launch of this variant issues (state planes, fused steer, the three
     // maps of FEAT3; outputs selected at run time are not counted): a lower bound is all the hand-counted waits need
     constexpr int S_ROW = (((FLAGS & F_NOSTATE) == 0 && (FLAGS & F_PYRONLY) == 0) ? NB : 0) +
@@ -876,7 +901,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                 }
             }
             if constexpr ((FLAGS & F_PYRONLY) == 0) {
-            row_pass<B, PK>(t, P, j, win2, win1);
+            row_pass<B, PK>(taps, P, j, win2, win1);
 
             // ---- column pass on the window; newest row is slot j, centre is W rows back ----
             // which output row this is, and whether the strip owns it (wave-uniform)
@@ -924,7 +949,7 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     for (int k = (FLAGS & F_FEAT3) != 0 ? 5 : 0; k < 8; ++k) b2_off[k] = ka->out_off[k];
                 }
                 float b[NB];
-                column_pass<B, PK>(t, win2, win1, j, b);
+                column_pass<B, PK>(taps, win2, win1, j, b);
                 // lanes right of the image carry kLaneOff in xb: their stores are dropped by the range check
                 // output row relative to the plane pointers, and its byte offset in a state plane
                 unsigned yo, orow;
@@ -1087,6 +1112,26 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
         }
     }
     basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB, U8>(a, t, lds[threadIdx.x >> 6], z, bx, by);
+}
+
+// The pipeline variants with the reference's default taps compiled in (TapsLitG2): single-resource form, f32 images.  `t` is still passed (same
+// argument layout as k_basis: kernarg_fresh) and not read.
+template <class B, int FLAGS, bool STREAM, int BATCH>
+__global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis_lit(const BasisArgs a, const Folded<B> t)
+{
+    __shared__ float lds[4][(2 * B::W + 2) * kRingLine];
+    __shared__ int s_tile;
+    int bx = 0, by = 0;
+    unsigned z = 0;
+    if (!pick_tile(a, &s_tile, bx, by, z)) return;
+    if constexpr (BATCH != 0) {   // (frames dealt from z_ways parts of the batch: see k_basis)
+        if (a.z_ways > 1) {
+            const unsigned per = ((unsigned)a.batch + a.z_ways - 1) / a.z_ways;
+            z = (z % a.z_ways) * per + z / a.z_ways;
+            if (z >= (unsigned)a.batch) return;
+        }
+    }
+    basis_body<B, FLAGS, STREAM, BATCH, true, 4, false, true>(a, t, lds[threadIdx.x >> 6], z, bx, by);
 }
 
 // G + H half banks in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
@@ -1295,6 +1340,15 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
     // which honours row_lo / row_hi / row_base
     const bool banded = a.row_lo != 0 || a.row_hi != a.rows || a.row_base != 0;
     const bool one = !banded && a.state_bytes > 0 && a.state_bytes <= kMaxPlaneBytes;
+    // the handle's taps are the reference's defaults, bit for bit: the pipeline variants run the instance with the taps compiled in
+    bool lit = false;
+    if constexpr (B::KIND == 2 && B::HALF == 0) {
+        lit = a.lit_taps != 0;
+        for (int m = 0; m < B::NTP && lit; ++m)
+            for (int i = 0; i <= B::W && lit; ++i)
+                lit = __builtin_bit_cast(unsigned, f.tp[m][i].x) == kLitEvenG2[B::te(m)][i] && __builtin_bit_cast(unsigned, f.tp[m][i].y) == kLitOddG2[B::to(m)][i];
+    }
+    a.lit_taps = lit ? 1 : 0;
     // BasisArgs::wg_per_cu: the launch asks for more LDS than it uses, so that at most that many workgroups share a CU (see cvs_tune.cpp)
     unsigned lds_pad = 0;
     if (a.wg_per_cu > 0 && a.wg_per_cu < 8) {
@@ -1320,6 +1374,13 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
     } while (0)
 #define CVS_LAUNCH_U(FL, BATCHED, WP, U)                                                   \
     do {                                                                                   \
+        if constexpr (B::KIND == 2 && B::HALF == 0 && ((FL) & F_PIPE) != 0 && !(U) && (BATCHED) != 1) {   \
+            if (lit && one) {                                                              \
+                if (a.nt_stores) CVS_LAUNCH_K(k_basis_lit<B, FL, true, BATCHED>);          \
+                else CVS_LAUNCH_K(k_basis_lit<B, FL, false, BATCHED>);                     \
+                break;                                                                     \
+            }                                                                              \
+        }                                                                                  \
         if (one) {                                                                         \
             if (a.nt_stores) CVS_LAUNCH_K(k_basis<B, FL, true, BATCHED, true, WP, U>);     \
             else CVS_LAUNCH_K(k_basis<B, FL, false, BATCHED, true, WP, U>);                \
