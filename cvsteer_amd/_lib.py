@@ -36,7 +36,7 @@ class CvsError(RuntimeError):
 class LaunchInfo(C.Structure):
     """struct cvs_launch_info"""
     _fields_ = [("struct_size", C.c_uint32), ("block_order", C.c_int32), ("strip_rows", C.c_int32), ("nt_stores", C.c_int32),
-                ("state_layout", C.c_int32), ("warm", C.c_int32), ("tuning_launches", C.c_int32), ("tuned", C.c_int32), ("tune_state", C.c_int32), ("wg_per_cu", C.c_int32)]
+                ("state_layout", C.c_int32), ("warm", C.c_int32), ("tuning_launches", C.c_int32), ("tuned", C.c_int32), ("tune_state", C.c_int32), ("wg_per_cu", C.c_int32), ("literal_taps", C.c_int32)]
 
 
 _PP = C.POINTER(Plane)

@@ -150,7 +150,7 @@ int default_strip_rows(cvs_handle h, int rows, int cols, bool fresh_input = fals
 int use_nt_stores(cvs_handle h, size_t npix);
 // process-wide overrides parsed once from the environment variable CVS_OPTS="name=value,..." (include/cvsteer_hip.h)
 struct EnvOpts {
-    int autotune = -1, layout = -1, pyr_strip = -1, batch_ways = -1, nt_stores = -1, warm = -1, wgcap = -1, verbose = 0;
+    int autotune = -1, layout = -1, pyr_strip = -1, batch_ways = -1, nt_stores = -1, warm = -1, wgcap = -1, lit = -1, verbose = 0;
     long pool_mb = 4096;
 };
 EnvOpts env_opts();

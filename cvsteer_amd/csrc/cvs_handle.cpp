@@ -25,7 +25,7 @@
 
 namespace cvs {
 
-// CVS_OPTS="autotune=0,layout=1,pyr_strip=1,batch_ways=2,warm=4,wgcap=3,nt_stores=1,verbose=1,pool_mb=4096": the one documented
+// CVS_OPTS="autotune=0,layout=1,pyr_strip=1,batch_ways=2,warm=4,wgcap=3,nt_stores=1,lit=0,verbose=1,pool_mb=4096": the one documented
 // environment hook (A/B aids for new handles; unknown names are reported once on stderr and ignored)
 EnvOpts env_opts()
 {
@@ -55,6 +55,7 @@ EnvOpts env_opts()
         else if (name == "nt_stores") v.nt_stores = val != 0;
         else if (name == "warm") v.warm = (int)std::max(0L, std::min(16L, val));
         else if (name == "wgcap") v.wgcap = (int)std::max(0L, std::min(8L, val));
+        else if (name == "lit") v.lit = val != 0;
         else if (name == "verbose") v.verbose = val != 0;
         else if (name == "pool_mb") v.pool_mb = val;
         else std::fprintf(stderr, "[cvsteer] CVS_OPTS: unknown name '%s' ignored\n", name.c_str());
@@ -322,6 +323,8 @@ void fill_state_args(cvs_handle h, BasisArgs& a, bool orient)
     a.state_bytes = h->frame_stride * sizeof(float);
     a.tile_ctr = h->sb.tile_ctr;   // queues of the dynamic launch order (nullptr: none, static orders only)
     a.tile_parity = &h->sb.ctr_parity;
+    a.lit_taps = env_opts().lit != 0;   // (CVS_OPTS lit=0: A/B and tests of the instances that take their taps from the kernel arguments)
+    a.lit_used = &h->last.literal_taps;
 }
 
 // Process-wide cache of released state blocks.  The reference's usage model is one short-lived object per image

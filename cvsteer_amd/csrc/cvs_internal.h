@@ -62,8 +62,9 @@ struct BasisArgs {
     int row_lo, row_hi, row_base;  // set by launch_basis: output rows of this launch / row the plane pointers start at
     int out_row_lo, out_row_hi;    // caller: compute output rows [out_row_lo, out_row_hi) only (0, 0 = the whole image);
                                    // the band-split of one large image over several GPUs (cvs_setup_rows)
-    int lit_taps;         // in: 1 = the launcher may use the instances with the reference's default taps compiled in (0: CVS_OPTS lit=0);
-                          // out (host only): 1 = it did -- the handle's taps equal the table and the variant has such an instance
+    int lit_taps;         // 1 = the launcher may use the instances with the reference's default taps compiled in (it still holds the handle's taps
+                          // against the table, bit for bit); 0: CVS_OPTS lit=0
+    int* lit_used;        // host: the launcher notes here whether the launch ran such an instance (cvs_launch_info.literal_taps); may be nullptr
     int block_order;      // 0 = row-major grid (default), kOrderXcdColumns, kOrderDynamic
     int grid_x, grid_y;   // filled by the launcher
     int dyn_static;       // dynamic order: the first dyn_static tiles are dealt statically (tile = workgroup index); filled by the launcher

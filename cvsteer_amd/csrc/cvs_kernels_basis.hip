@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -1114,9 +1115,10 @@ __global__ __launch_bounds__(64 * WPB, B::MIN_WAVES) void k_basis(const BasisArg
     basis_body<B, FLAGS, STREAM, BATCH, ONE, WPB, U8>(a, t, lds[threadIdx.x >> 6], z, bx, by);
 }
 
-// The pipeline variants with the reference's default taps compiled in (TapsLitG2): single-resource form, f32 images.  `t` is still passed (same
-// argument layout as k_basis: kernarg_fresh) and not read.
-template <class B, int FLAGS, bool STREAM, int BATCH>
+// The pipeline variants with the reference's default taps compiled in (TapsLitG2): single-resource form.  `t` is still passed (same
+// argument layout as k_basis: kernarg_fresh) and not read.  Same handle, alternating, sustained, three processes (profiles/r06_literal_taps.txt):
+// 32 x 1080p with state +2.9 ... +3.0 %, three maps only +1.6 ... +2.0 % (single 4096^2 image +2.8 ... +4.8 %), single-image pipeline +0.5 ... +0.9 %.
+template <class B, int FLAGS, bool STREAM, int BATCH, bool U8 = false>
 __global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis_lit(const BasisArgs a, const Folded<B> t)
 {
     __shared__ float lds[4][(2 * B::W + 2) * kRingLine];
@@ -1131,7 +1133,7 @@ __global__ __launch_bounds__(256, B::MIN_WAVES) void k_basis_lit(const BasisArgs
             if (z >= (unsigned)a.batch) return;
         }
     }
-    basis_body<B, FLAGS, STREAM, BATCH, true, 4, false, true>(a, t, lds[threadIdx.x >> 6], z, bx, by);
+    basis_body<B, FLAGS, STREAM, BATCH, true, 4, U8, true>(a, t, lds[threadIdx.x >> 6], z, bx, by);
 }
 
 // G + H half banks in ONE launch: blockIdx.z picks the half bank (a wave-uniform branch), so both halves share
@@ -1346,9 +1348,15 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
         lit = a.lit_taps != 0;
         for (int m = 0; m < B::NTP && lit; ++m)
             for (int i = 0; i <= B::W && lit; ++i)
-                lit = __builtin_bit_cast(unsigned, f.tp[m][i].x) == kLitEvenG2[B::te(m)][i] && __builtin_bit_cast(unsigned, f.tp[m][i].y) == kLitOddG2[B::to(m)][i];
+            {   // (through plain floats: __builtin_bit_cast on an element of the vector type reads element 0 whatever the index -- seen with this compiler)
+                const float ex = f.tp[m][i].x, oy = f.tp[m][i].y;
+                unsigned ue, uo;
+                std::memcpy(&ue, &ex, sizeof ue);
+                std::memcpy(&uo, &oy, sizeof uo);
+                lit = ue == kLitEvenG2[B::te(m)][i] && uo == kLitOddG2[B::to(m)][i];
+            }
     }
-    a.lit_taps = lit ? 1 : 0;
+    if (a.lit_used) *a.lit_used = 0;   // set where such an instance is launched (CVS_LAUNCH_U)
     // BasisArgs::wg_per_cu: the launch asks for more LDS than it uses, so that at most that many workgroups share a CU (see cvs_tune.cpp)
     unsigned lds_pad = 0;
     if (a.wg_per_cu > 0 && a.wg_per_cu < 8) {
@@ -1374,10 +1382,11 @@ static hipError_t launch_fast_impl(BasisArgs& a, const Folded<B>& f, hipStream_t
     } while (0)
 #define CVS_LAUNCH_U(FL, BATCHED, WP, U)                                                   \
     do {                                                                                   \
-        if constexpr (B::KIND == 2 && B::HALF == 0 && ((FL) & F_PIPE) != 0 && !(U) && (BATCHED) != 1) {   \
+        if constexpr (B::KIND == 2 && B::HALF == 0 && ((FL) & F_PIPE) != 0 && (BATCHED) != 1) {   \
             if (lit && one) {                                                              \
-                if (a.nt_stores) CVS_LAUNCH_K(k_basis_lit<B, FL, true, BATCHED>);          \
-                else CVS_LAUNCH_K(k_basis_lit<B, FL, false, BATCHED>);                     \
+                if (a.lit_used) *a.lit_used = 1;                                           \
+                if (a.nt_stores) CVS_LAUNCH_K(k_basis_lit<B, FL, true, BATCHED, U>);       \
+                else CVS_LAUNCH_K(k_basis_lit<B, FL, false, BATCHED, U>);                  \
                 break;                                                                     \
             }                                                                              \
         }                                                                                  \

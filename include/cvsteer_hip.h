@@ -73,7 +73,8 @@ enum {
 };
 
 /* options for cvs_set_option.  Process-wide overrides for new handles (A/B aids): the environment variable
- * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2, pyr_strip=0|1, batch_ways=N, warm=K (0 = off), wgcap=N (workgroups per CU, 0 = no cap),
+ * CVS_OPTS="name=value,..." with autotune=0|1, layout=0|1|2|3, pyr_strip=0|1, batch_ways=N, warm=K (0 = off), wgcap=N (workgroups per CU, 0 = no cap),
+ * lit=0|1 (0: never the kernel instances with the default taps compiled in),
  * nt_stores=0|1 (output stores plain / nontemporal instead of by size), verbose=1 (the tuner prints its decisions to stderr),
  * pool_mb=N (state-block cache, default 4096, 0 = off).  Read at every call; results never depend on any of them. */
 enum {
@@ -186,6 +187,9 @@ typedef struct cvs_launch_info {
                                  caller's launches, 2 = decided */
     int32_t wg_per_cu;        /* last basis launch: workgroups per CU it was held to (single G2 images of 2 Mpix and more: three or four
                                  instead of the six the registers allow -- fewer write fronts); 0 = no cap */
+    int32_t literal_taps;     /* last basis launch: 1 = it ran a kernel instance with the reference's default G2 / H2 taps compiled in as literal
+                                 operands (the caller-pipeline variants of a handle made with width 4, spacing 0.67f: same values, cheaper
+                                 instruction issue); 0 = taps from the kernel arguments (any other handle or launch) */
 } cvs_launch_info;
 int cvs_get_launch_info(cvs_handle h, cvs_launch_info* out);
 /* the handle's idx-th tap vector (m_g1.. members), 2*width+1 floats */

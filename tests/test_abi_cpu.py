@@ -112,3 +112,22 @@ def test_facade_library_exports_reference_class_surface():
                    "fa::SteerableFilters::create(int, float, float (*)(float))",
                    "fa::SteerableFilters::wrap(fa::Mat1f const&, fa::Mat1f&)"):
         assert needle in syms, needle
+
+
+def test_literal_tap_table_is_the_reference_taps_fixture(tmp_path):
+    """cvsteer_amd/csrc/cvs_lit_taps.h (the default G2 / H2 taps compiled into the k_basis_lit instances) is what tools/gen_lit_taps.py makes of
+    tests/golden/taps_ref.json -- the bit patterns of the reference's own tap functions -- and nothing else"""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "cvsteer_amd", "csrc", "cvs_lit_taps.h")
+    committed = open(hdr).read()
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_lit_taps.py")], capture_output=True, text=True, check=True).stdout
+    assert open(hdr).read() == committed, "tools/gen_lit_taps.py changes the committed header"
+    assert committed.strip() == out.strip()
+    import json
+    g2 = json.load(open(os.path.join(root, "tests", "golden", "taps_ref.json")))["g2"]
+    words = re.findall(r"0x([0-9a-f]{8})u", committed)
+    assert len(words) == 30
+    assert words[:5] == [g2["G21"][4 + i] for i in range(5)] and words[25:] == [g2["H23"][4 + i] for i in range(5)]

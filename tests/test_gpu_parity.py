@@ -1201,6 +1201,53 @@ def test_a_recycled_tile_queue_slot_is_reset_before_its_first_dynamic_launch(cv)
         cv.lib().cvs_release_cached_memory() # the parked block (and its queue slot) really goes back; the next handle recycles the slot
 
 
+def test_literal_tap_instances_equal_the_argument_tap_instances(cv, ora, monkeypatch):
+    """a handle made with the reference's defaults (width 4, spacing 0.67f) runs the caller-pipeline variants as instances with the taps compiled
+    in as literal operands (cvs_launch_info.literal_taps = 1; k_basis_lit); CVS_OPTS lit=0 -- and any handle with other taps -- runs the
+    instances that take them from the kernel arguments.  Same operations on the same values: every output and state plane bit for bit, single
+    images (state kept, outputs only with several masks, streaming and plain stores) and frame batches (regular, with and without state)."""
+    import torch
+    from cvsteer_amd import _lib as L
+    gen = torch.Generator(device="cuda").manual_seed(41)
+    for shape, nt in (((1100, 1500), 1), ((257, 449), 0), ((1536, 2048), 1)):
+        img = torch.rand(shape, device="cuda", generator=gen)
+        frames = torch.rand((3,) + shape, device="cuda", generator=gen)
+        got = {}
+        for lit in (1, 0):
+            monkeypatch.setenv("CVS_OPTS", "nt_stores=%d,lit=%d" % (nt, lit))
+            f = cv.SteerableFiltersG2(None)
+            f.set_option(L.OPT_AUTOTUNE, 0)
+            cur = [o.clone() for o in f.pipeline(img)]
+            assert f.launch_info()["literal_taps"] == lit, (shape, lit, f.launch_info())
+            cur += [f.basis(p).clone() for p in range(7)] + [f.getDominantOrientationAngle().clone(), f.getDominantOrientationStrength().clone()]
+            cur += [f.pipeline_batch(frames).clone()]
+            assert f.launch_info()["literal_taps"] == lit
+            f.select_frame(2)
+            cur += [f.basis(3).clone(), f.coefficients()[0].clone()]
+            f.set_persist(False)
+            for mask in ((5, 6, 7), (0, 1), (2, 3, 4), (4,)):
+                o = [torch.empty_like(img) if k in mask else None for k in range(8)]
+                f.pipeline(img, out=o)
+                assert f.launch_info()["literal_taps"] == lit
+                cur += [o[k] for k in mask]
+                cur += [f.pipeline_batch(frames, outputs=mask).clone()]
+            f.setup(img, flags=cv.SETUP_FULL)
+            assert f.launch_info()["literal_taps"] == 0     # only the pipeline variants have such instances
+            got[lit] = cur
+        for k, (a_, b_) in enumerate(zip(got[1], got[0])):
+            assert torch.equal(a_, b_), (shape, k)
+    monkeypatch.delenv("CVS_OPTS")
+    # other taps (same width, another spacing): the argument instances, whatever lit says -- and right against the oracle
+    img = torch.rand((300, 420), device="cuda", generator=gen)
+    f = cv.SteerableFiltersG2(None, 4, 0.5)
+    outs = f.pipeline(img)
+    assert f.launch_info()["literal_taps"] == 0
+    truth = ora.basis(ora.KIND_G2, img.cpu().numpy(), 4, 0.5, f64=True)
+    for p in range(7):
+        assert np.abs(f.basis(p).cpu().numpy() - truth[p]).max() <= 1e-5, p
+    assert all(torch.isfinite(o).all() for o in outs)
+
+
 def test_xcd_column_order_and_g4(cv):
     """block order 1000000 (every XCD on its own range of column blocks) on widths whose 256-column blocks divide among the 8
     XCDs and on widths where they do not, short and tall images, G2 and G4: identical outputs.  (G4 with this order pinned used

@@ -119,6 +119,26 @@ for order in (L.ORDER_PLAIN, L.ORDER_DYNAMIC_TAIL):
     lst = [frames[0][i] for i in range(6)]      # unrelated planes: the frame-table form
     ff.pipeline_batch(lst)
 section("batch_32x1080p")
+# the pipeline variants once more with the taps in scalar registers (the launches above ran the instances with the default taps compiled in)
+os.environ["CVS_OPTS"] = "lit=0"
+ff.set_option(L.OPT_BLOCK_ORDER, L.ORDER_PLAIN)
+ff.set_persist(True)
+ff.pipeline_batch(frames[0], out=fo8)
+assert ff.launch_info()["literal_taps"] == 0
+ff.set_persist(False)
+ff.pipeline_batch(frames[1], out=fo3, outputs=(5, 6, 7))
+ff.pipeline_batch(frames[1], out=fo8)
+one = frames[0][0].contiguous()
+fsingle = cv.SteerableFiltersG2(None, 4, 0.67)
+fsingle.pipeline(one)
+fsingle.set_persist(False)
+fsingle.pipeline(one)
+os.environ.pop("CVS_OPTS", None)
+fsingle.set_persist(True)
+fsingle.pipeline(one)
+assert fsingle.launch_info()["literal_taps"] == 1
+del fsingle, one
+section("pipeline_variants_taps_from_arguments")
 del frames, fo8, fo3, ff
 # random shapes / options / entry points (ragged widths, few rows, strip heights, row ranges)
 rng = np.random.default_rng(5)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/r06_probe.py -- round-6 A/B probes, one process = one allocation history (run it in several).  Every comparison is made
 on ONE handle / state block with the online tuner off, settings alternating, SUSTAINED regions (a lead-in of a third of the region,
-then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c4w c4m strips tune
+then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c4w c4m strips lit tune
   c4     32 x 1080p caller pipeline with state kept (BASELINE config 4): plain order vs dynamic tail, workgroups per CU, batch ways,
          strip height, planar [n][8][H][W] outputs vs row-interleaved [n][H][8][W] ones
   m4     full setup at 4096^2: two plane groups (layout 1) vs one merged group (layout 2), workgroups per CU
@@ -433,3 +433,48 @@ if "strips" in sections:
             fn()
             ab("%s %dx%d" % (name, r, c), bpp * r * c, 200, [("default (0)", sr(0), fn), ("10 rows", sr(10), fn), ("19 rows", sr(19), fn), ("28 rows", sr(28), fn)], rounds=2)
         del f, img, g, h, o8
+
+
+if "lit" in sections:
+    # the pipeline variants with the reference's default taps compiled in as literal operands (k_basis_lit) against the same variants with the
+    # taps in scalar registers (CVS_OPTS lit=0): same handle, alternating, sustained; and bit for bit the same outputs
+    n = 4096
+    img = torch.rand((n, n), device="cuda")
+    outs8 = cv.alloc_planes(8, n, n, device="cuda")
+    f = cv.SteerableFiltersG2(None, 4, 0.67)
+    m5 = lambda: f.pipeline(img, out=outs8)
+    m5()
+    assert f.launch_info()["literal_taps"] == 1, f.launch_info()
+    ab("M5 caller pipeline 4096^2, state kept (84 B/pix)", 84 * n * n, 150, [("taps in scalar registers (lit=0)", opts("lit=0"), m5), ("taps as literals", opts(""), m5)])
+    ref = [o.clone() for o in outs8] + [f.basis(p).clone() for p in range(7)] + [f.getDominantOrientationAngle().clone()]
+    opts("lit=0")(); m5(); assert f.launch_info()["literal_taps"] == 0
+    same = all(torch.equal(a_, b_) for a_, b_ in zip(ref, list(outs8) + [f.basis(p) for p in range(7)] + [f.getDominantOrientationAngle()]))
+    print("   outputs and state planes bit-identical: %s" % same)
+    f.set_persist(False)
+    o3 = [None] * 5 + list(outs8[5:])
+    m5o = lambda: f.pipeline(img, out=o3)
+    ab("M5 three maps only, single 4096^2 image (16 B/pix)", 16 * n * n, 150, [("lit=0", opts("lit=0"), m5o), ("literals", opts(""), m5o)])
+    nfr = 32
+    fsets = [torch.rand((nfr, 1080, 1920), device="cuda") for _ in range(2)]
+    fout = torch.empty((nfr, 8, 1080, 1920), device="cuda")
+    fo3 = torch.empty((nfr, 3, 1080, 1920), device="cuda")
+    ff = cv.SteerableFiltersG2(None, 4, 0.67)
+    alt = [0]
+    fp = nfr * 1080 * 1920
+
+    def c4():
+        alt[0] ^= 1
+        ff.pipeline_batch(fsets[alt[0]], out=fout)
+
+    def c4f():
+        alt[0] ^= 1
+        ff.pipeline_batch(fsets[alt[0]], out=fo3, outputs=(5, 6, 7))
+    c4()
+    ab("C4 32x1080p pipeline, state kept (84 B/pix)", 84 * fp, 150, [("lit=0", opts("lit=0"), c4), ("literals", opts(""), c4)])
+    ff.set_persist(False)
+    c4f()
+    ab("C4 32x1080p three maps only (16 B/pix)", 16 * fp, 150, [("lit=0", opts("lit=0"), c4f), ("literals", opts(""), c4f)])
+    opts("")(); ff.pipeline_batch(fsets[0], out=fo3, outputs=(5, 6, 7)); r3 = fo3.clone(); lit1 = ff.launch_info()["literal_taps"]
+    opts("lit=0")(); fo3.zero_(); ff.pipeline_batch(fsets[0], out=fo3, outputs=(5, 6, 7))
+    print("   three maps bit-identical: %s (literal_taps %d / %d)" % (torch.equal(r3, fo3), lit1, ff.launch_info()["literal_taps"]))
+    opts("")()
