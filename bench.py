@@ -50,8 +50,8 @@ NOMINAL_SCLK_MHZ = 2000.0  # used for the VALU roof only when the card's clock c
 ROWS = COLS = 4096
 THETA = 0.3
 BYTES_PER_PIX = {"M1": 32, "M2": 40, "M3": 64, "M4": 52, "M5": 84, "M6": 48, "M6s": 56, "M2_u8": 37, "C4_feat3": 16, "C4_u8_feat3": 13}
-MAX_SETTLE_CALLS = 1700    # the online tuner compares its candidates on the caller's own calls, in sustained turns of 20-100 calls (at most
-                           # 4 rounds x 4 candidates); legs call until it has decided
+MAX_SETTLE_CALLS = 2100    # the online tuner compares its candidates on the caller's own calls, in sustained turns of 20-100 calls (at most
+                           # a burn-in round + 4 rounds x 4 candidates); legs call until it has decided
 EXIT_WATCHDOG = 3     # secondary legs ran into --extra-timeout: headline printed, status non-zero
 EXIT_LEGS_FAILED = 5  # a secondary leg raised: headline + the legs finished so far are printed first
 EXIT_TERMINATED = 4   # SIGTERM (another rank failed / the launcher gave up): whatever was measured is printed first

@@ -68,7 +68,8 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // samples of the 32 x 1080p batch in 8 of 22 bench processes and then ran 6 % behind the plain order, a five-workgroups-per-CU
 // challenger for the full setup won in 13 of 13 and ran 3 % behind (profiles/r05_bench_lines*.jsonl).  Now a candidate's
 // turn is a run of kTurnMin..kTurnMax consecutive calls (about kTurnMs of GPU time), the first kLead of which are not counted,
-// and what is compared are the MEDIANS OF WHOLE TURNS: a challenger replaces the default only if, after at least two rounds, its
+// the first ROUND is burn-in (see evaluate), and what is compared are the MEDIANS OF WHOLE TURNS: a challenger replaces the default
+// only if, after at least two counted rounds, its
 // median turn is at least kGain faster than the default's median turn and its turns -- all of two, all but one of three or four --
 // are ahead of the default's median turn by half that; challengers that are not ahead by even half the margin on the median are
 // dropped after two rounds; after kMaxRounds the default stays.  The default leads every
@@ -121,7 +122,7 @@ static std::map<int, std::vector<hipEvent_t>> g_free_events;   // per device: ti
 constexpr int kLead = 5;                        // calls at the head of a turn that are not counted
 constexpr int kTurnMin = 20, kTurnMax = 100;    // calls per turn
 constexpr double kTurnMs = 12.0;                // ... about this much GPU time
-constexpr int kMinRounds = 2, kMaxRounds = 4, kMaxUnfit = 3;
+constexpr int kBurnIn = 1, kMinRounds = 2, kMaxRounds = 4, kMaxUnfit = 3;   // rounds: burn-in, then at least / at most this many that count
 constexpr float kGain = 0.02f;
 
 static void apply(BasisArgs& a, const Cand& c)
@@ -151,20 +152,25 @@ static float median_of(std::vector<float> v)
 static void evaluate(TuneEntry& e)
 {
     for (size_t c = 0; c < e.cand.size(); ++c) {
-        if (e.turn[c].size() >= 4) e.medians[c].push_back(median_of(e.turn[c]));   // (a turn most of whose samples failed to record does not count)
+        // Round 1 is burn-in and does not count: a configuration's FIRST turn in a process runs 15-25 % slower than its later ones for
+        // tens of launches (verbose logs of four bench processes, profiles/r06_tuner_first_turn.txt: default 0.01663 then 0.01419 ns/pix,
+        // dynamic tail 0.01000 then 0.00803) -- counted, it made a cold default lose to a warm challenger, or a cold challenger drop out
+        if (e.round > kBurnIn && e.turn[c].size() >= 4) e.medians[c].push_back(median_of(e.turn[c]));   // (a turn most of whose samples failed to record does not count)
         e.turn[c].clear();
     }
+    const int counted = e.round - kBurnIn;   // rounds that count
     int decision = -1;
+    if (counted < 1) return;
     if (e.medians[0].empty()) {   // every sample of the default failed to record: nothing to hold a challenger against
-        if (e.round >= kMaxRounds) decision = 0;
-    } else if (e.round >= kMinRounds) {
+        if (counted >= kMaxRounds) decision = 0;
+    } else if (counted >= kMinRounds) {
         const float d_mid = median_of(e.medians[0]);
         int best = -1, live = 0;
         float mbest = std::numeric_limits<float>::max();
         for (size_t c = 1; c < e.cand.size(); ++c) {
             if (e.dropped[c]) continue;
             if ((int)e.medians[c].size() < kMinRounds) {   // passed or lost its turns
-                if (e.round >= kMaxRounds) e.dropped[c] = 1;
+                if (counted >= kMaxRounds) e.dropped[c] = 1;
                 else ++live;
                 continue;
             }
@@ -179,7 +185,7 @@ static void evaluate(TuneEntry& e)
             if (m <= d_mid * (1.0f - kGain) && wins >= nt_ - (nt_ >= 3 ? 1 : 0) && m < mbest) { mbest = m; best = (int)c; }
         }
         if (best >= 0) decision = best;
-        else if (live == 0 || e.round >= kMaxRounds) decision = 0;
+        else if (live == 0 || counted >= kMaxRounds) decision = 0;
     }
     if (decision >= 0) {
         e.chosen = decision;

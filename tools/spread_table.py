@@ -1,9 +1,9 @@
-"""tools/spread_table.py [FILE.jsonl] -- bench.py lines (default profiles/r05_bench_lines.jsonl, one run per line) -> the min / median / max table of
-DESIGN.md section 6 (round-4 column: profiles/HISTORY_round_4.md)."""
+"""tools/spread_table.py [FILE.jsonl] -- bench.py lines (default profiles/r06_bench_lines.jsonl, one run per line) -> the min / median / max table of
+DESIGN.md section 6 (last column: the four runs of round 5's final code, profiles/r05_bench_lines.jsonl)."""
 import json,os,statistics,sys
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-runs=[json.loads(l) for l in open(sys.argv[1] if len(sys.argv)>1 else os.path.join(ROOT,'profiles','r05_bench_lines.jsonl')) if l.startswith('{')]
-earlier=os.path.join(ROOT,'profiles','r05_bench_lines_earlier_in_the_round.jsonl')
+runs=[json.loads(l) for l in open(sys.argv[1] if len(sys.argv)>1 else os.path.join(ROOT,'profiles','r06_bench_lines.jsonl')) if l.startswith('{')]
+earlier=os.path.join(ROOT,'profiles','r06_bench_lines_earlier_in_the_round.jsonl')
 allruns=runs+([json.loads(l) for l in open(earlier) if l.startswith('{')] if os.path.exists(earlier) else [])
 rows=[("**M2 filter + steer (headline)**",40,"headline","0.810 / 0.827 / 0.833"),
 ("**M1 basis pass (north_star ≥ 0.70)**",32,"M1_basis","0.786 / 0.805 / 0.816"),
@@ -21,14 +21,15 @@ rows=[("**M2 filter + steer (headline)**",40,"headline","0.810 / 0.827 / 0.833")
 ("C4 32 × 1080p, three maps only",16,"C4_32x1080p_three_maps_only","0.292–0.304 (146–152 Gpix/s)"),
 ("C3 pyramid of 8192², 5 levels, whole","—","C3_pyramid_8192_5_levels_whole","0.656 / 0.665 / 0.675"),
 ("M5 / G4 after 30 ms of idleness",84,"M5_pipeline_after_idle","0.606–0.647 / 0.564–0.648"),]
+prev=[json.loads(l) for l in open(os.path.join(ROOT,'profiles','r05_bench_lines.jsonl')) if l.startswith('{')]
 def fmt(k, rs=None):
     vals=sorted((r["roofline"]["frac"] if k=="headline" else (r["legs"].get(k) or [None])[0]) for r in (rs or runs))
     vals=[v for v in vals if v]
     return "%.3f / %.3f / %.3f"%(vals[0],statistics.median(vals),vals[-1])
-print("| leg | B/pix | round 5, final code, %d runs (min / median / max) | all %d runs of round 5 | round 4 (six boxes) |"%(len(runs),len(allruns)))
+print("| leg | B/pix | round 6, final code, %d runs (min / median / max) | all %d runs of round 6 | round 5, final code (4 runs) |"%(len(runs),len(allruns)))
 print("|---|---|---|---|---|")
 for name,b,k,r4 in rows:
     if k=="M5_pipeline_after_idle":
-        print("| %s | %s | %s and %s | %s and %s | %s |"%(name,"84 / 48",fmt(k),fmt("M6_g4_basis_after_idle"),fmt(k,allruns),fmt("M6_g4_basis_after_idle",allruns),r4))
+        print("| %s | %s | %s and %s | %s and %s | %s and %s |"%(name,"84 / 48",fmt(k),fmt("M6_g4_basis_after_idle"),fmt(k,allruns),fmt("M6_g4_basis_after_idle",allruns),fmt(k,prev),fmt("M6_g4_basis_after_idle",prev)))
     else:
-        print("| %s | %s | %s | %s | %s |"%(name,b,("**%s**"%fmt(k)) if name.startswith("**") else fmt(k),fmt(k,allruns),r4))
+        print("| %s | %s | %s | %s | %s |"%(name,b,("**%s**"%fmt(k)) if name.startswith("**") else fmt(k),fmt(k,allruns),fmt(k,prev)))
