@@ -311,7 +311,7 @@ def test_impulse_response_is_the_outer_product_of_the_reference_taps(ora, golden
 
 
 def test_every_timed_kernel_instance_has_a_parity_test():
-    """profiles/r05_kernel_stats_all_legs.csv lists every kernel instance `bench.py` launched in its profiled run;
+    """profiles/r06_kernel_stats_all_legs.csv lists every kernel instance `bench.py` launched in its profiled run;
     tests/golden/timed_instances.json maps each one to the bench legs that time it and to the `-m gpu` tests that hold it
     against the oracle (round-2 verdict item 1).  This check keeps the three in step: no timed instance without an entry, no
     entry that names a test which does not exist."""
@@ -321,10 +321,10 @@ def test_every_timed_kernel_instance_has_a_parity_test():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     mapping = json.load(open(os.path.join(root, "tests", "golden", "timed_instances.json")))
-    timed = [r[0] for r in csv.reader(open(os.path.join(root, "profiles", "r05_kernel_stats_all_legs.csv"))) if r and r[0].startswith("cvs::")]
+    timed = [r[0] for r in csv.reader(open(os.path.join(root, "profiles", "r06_kernel_stats_all_legs.csv"))) if r and r[0].startswith("cvs::")]
     assert len(timed) >= 12
     for name in timed:
-        key = name.split("(unsigned char")[0]
+        key = name.split("(unsigned char")[0].split("(unsigned int")[0]
         assert key in mapping, "timed kernel instance without a parity test on record: " + name
         assert mapping[key]["tests"] and mapping[key]["legs"]
     defined = set()

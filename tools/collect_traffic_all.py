@@ -29,9 +29,9 @@ known = [
     ("cvs::k_basis<cvs::BankG2, 0, true, 0, true, 4", 7 * 4 * P8, "M1 basis 8192^2", 32 * P8),
     ("cvs::k_basis<cvs::BankG2, 2, true, 0, true, 4", 9 * 4 * P8, "M2 filter + steer 8192^2", 40 * P8),
     ("cvs::k_basis<cvs::BankG2, 1, true, 0, true, 4", 12 * 4 * P4, "M4 full setup 4096^2", 52 * P4),
-    ("cvs::k_basis<cvs::BankG2, 5, true, 0, true, 4", 20 * 4 * P4, "M5 pipeline 4096^2", 84 * P4),
-    ("cvs::k_basis<cvs::BankG2, 5, true, 2, true, 4", 20 * 4 * F, "C4 32 x 1080p, state kept", 84 * F),
-    ("cvs::k_basis<cvs::BankG2, 77, true, 2, true, 4", 3 * 4 * F, "C4 32 x 1080p, three feature maps", 16 * F),
+    ("cvs::k_basis_lit<cvs::BankG2, 5, true, 0", 20 * 4 * P4, "M5 pipeline 4096^2", 84 * P4),
+    ("cvs::k_basis_lit<cvs::BankG2, 5, true, 2", 20 * 4 * F, "C4 32 x 1080p, state kept", 84 * F),
+    ("cvs::k_basis_lit<cvs::BankG2, 77, true, 2", 3 * 4 * F, "C4 32 x 1080p, three feature maps", 16 * F),
     ("cvs::k_basis_pair<cvs::BankG4G, cvs::BankG4H, 0, true, true", 11 * 4 * P4, "M6 G4 basis 4096^2 (both half banks: z = 2)", 48 * P4),
     ("cvs::k_basis_pair<cvs::BankG4G, cvs::BankG4H, 2, true, true", 13 * 4 * P4, "M6 G4 basis + steer 4096^2", 56 * P4),
     ("cvs::k_point<(cvs::PointOp)1, 4, true, true", 2 * 4 * P4, "M3 steer scalar 4096^2", 36 * P4),

@@ -19,9 +19,9 @@ known = 2048 * 4 * (4096 * 16 + 50)
 factor = known / (sum(cal) / len(cal)) if cal else 1.0
 pix4096, pixc4 = 4096 * 4096, 32 * 1080 * 1920
 legs = {"M1": ("k_basis<cvs::BankG2, 0, true, 0, true", pix4096), "M2": ("k_basis<cvs::BankG2, 2, true, 0, true", pix4096),
-        "M4": ("k_basis<cvs::BankG2, 1, true, 0, true", pix4096), "M5": ("k_basis<cvs::BankG2, 5, true, 0, true", pix4096),
+        "M4": ("k_basis<cvs::BankG2, 1, true, 0, true", pix4096), "M5": ("k_basis_lit<cvs::BankG2, 5, true, 0", pix4096),
         "M6": ("k_basis_pair<cvs::BankG4G, cvs::BankG4H, 0, true, true", pix4096), "M6s": ("k_basis_pair<cvs::BankG4G, cvs::BankG4H, 2, true, true", pix4096),
-        "C4_state": ("k_basis<cvs::BankG2, 5, true, 2, true", pixc4), "C4_feat3": ("k_basis<cvs::BankG2, 77, true, 2, true", pixc4)}
+        "C4_state": ("k_basis_lit<cvs::BankG2, 5, true, 2", pixc4), "C4_feat3": ("k_basis_lit<cvs::BankG2, 77, true, 2", pixc4)}   # (pipeline variants: the literal-tap instances a default handle runs)
 agg = collections.defaultdict(list)
 for r in rows("pmc_valu"):
     agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
