@@ -2,7 +2,7 @@
 LSan, /root/reference .travis.yml:48-51).  Builds the two harnesses of tests/cpp with -fsanitize=address,undefined
 and runs them: the batch driver's file readers on mutated PGM / .npy files, and the device-free host logic of libcvsteer_hip.so
 (argument checks, overlap rules, CVS_OPTS parser, state layouts, taps).  tools/run_sanitizers.sh is the full campaign (it also runs
-this CPU suite against instrumented twins of the libraries); its log is profiles/r05_asan_cpu.txt."""
+this CPU suite against instrumented twins of the libraries); its log is profiles/r06_asan_cpu.txt."""
 import os
 import shutil
 import subprocess
@@ -45,5 +45,5 @@ def test_device_free_host_logic_under_asan_ubsan(tmp_path):
 
 
 def test_the_committed_campaign_log_is_clean():
-    log = open(os.path.join(ROOT, "profiles", "r05_asan_cpu.txt")).read()
+    log = open(os.path.join(ROOT, "profiles", "r06_asan_cpu.txt")).read()
     assert "RESULT: clean" in log and "pytest: rc 0" in log and "fuzz_readers: rc 0" in log and "host_logic_san: rc 0" in log

@@ -97,9 +97,11 @@ for it in range(iters):
         env.append("warm=%d" % int(rng.choice([0, 1, 3, 4, 9])))
     if rng.integers(0, 3) == 0:
         env.append("wgcap=%d" % int(rng.integers(0, 6)))
+    if rng.integers(0, 3) == 0:
+        env.append("lit=0")                                    # round 6: the pipeline variants with their taps from the kernel arguments instead of literals
     os.environ["CVS_OPTS"] = ",".join(env)
     if rng.integers(0, 2):
-        opts[L.OPT_STATE_LAYOUT] = int(rng.integers(0, 3))    # planar / row-interleaved groups / one merged group (round 4)
+        opts[L.OPT_STATE_LAYOUT] = int(rng.integers(0, 4))    # planar / the engine's choice / one merged group / two groups pinned (round 6)
     if rng.integers(0, 4) == 0:
         opts[L.OPT_AUTOTUNE] = 1                              # otherwise tools run with what the environment says (the tuner's candidates take turns)
     entry = str(rng.choice(["setup", "setup_steer", "pipeline", "batch", "rows", "pyr"]))

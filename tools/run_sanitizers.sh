@@ -5,10 +5,10 @@
 #      the file readers' fuzz harness (tests/cpp/fuzz_readers.cpp);
 #   2. `pytest -m "not gpu"` against the instrumented twins (CVSTEER_HIP_LIB / ORACLE_LIB, libasan preloaded into python);
 #   3. 10 000 mutated PGM / .npy files through the batch driver's readers.
-# Writes the log to OUT (default profiles/r05_asan_cpu.txt); exit status 0 = no sanitizer report anywhere.
+# Writes the log to OUT (default profiles/r06_asan_cpu.txt); exit status 0 = no sanitizer report anywhere.
 # The reference's CI does the same with its gtest (.travis.yml:48-51: sanitize-address, sanitize-leak toolchains).
 cd "$(dirname "$0")/.." || exit 1
-out=${1:-profiles/r05_asan_cpu.txt}
+out=${1:-profiles/r06_asan_cpu.txt}
 asan=$(gcc -print-file-name=libasan.so)
 {
   echo "== tools/run_sanitizers.sh, $(gcc --version | head -1); AddressSanitizer + UndefinedBehaviorSanitizer, host side only (CPU box)"
