@@ -97,6 +97,44 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     assert len(seen) == 1, seen
 
 
+def test_a_bucket_of_mixed_shapes_still_comes_to_a_decision(cv):
+    """the tuner's keys are pixel-count buckets; a caller that alternates a 2048-wide and a 1600-wide image of one bucket
+    (one object per image of whatever size comes along, example/steer.cpp:86) offers the XCD-column order a shape it does not fit (its column
+    blocks must divide by 8) on every other call.  The comparison used to stay undecided for ever; now a candidate that cannot take its turn
+    passes, is dropped after three passes, and the rounds are bounded.  Every call returns the bits of a tuner-off handle."""
+    import torch
+    from cvsteer_amd import _lib as L
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    imgs = [torch.rand((2048, 2048), device="cuda", generator=gen), torch.rand((2700, 1600), device="cuda", generator=gen)]
+    ref = cv.SteerableFiltersG2(None)
+    ref.set_option(L.OPT_AUTOTUNE, 0)
+    want = []
+    for im in imgs:
+        ref.setup(im, flags=cv.SETUP_FULL)
+        want.append((ref.getDominantOrientationAngle().clone(), ref.basis(5).clone()))
+    f = cv.SteerableFiltersG2(None)
+    decided_at = None
+    for i in range(4200):
+        k = (i // 3) & 1                      # runs of three calls per shape: both shapes meet every candidate's turn
+        f.setup(imgs[k], flags=cv.SETUP_FULL)
+        if i % 50 == 49:
+            torch.cuda.synchronize()
+            assert torch.equal(f.getDominantOrientationAngle(), want[k][0]) and torch.equal(f.basis(5), want[k][1]), i
+            if f.launch_info()["tune_state"] == 2:
+                decided_at = i
+                break
+    assert decided_at is not None, f.launch_info()
+    seen = set()
+    for i in range(12):                       # (a call on another image than the one before is a NEW image: its own key -- look at the repeats)
+        k = i & 1
+        f.setup(imgs[k], flags=cv.SETUP_FULL)
+        f.setup(imgs[k], flags=cv.SETUP_FULL)
+        li = f.launch_info()
+        assert li["tune_state"] == 2
+        seen.add((k, li["block_order"], li["strip_rows"]))
+    assert len(seen) == 2, seen               # one configuration per shape from here on
+
+
 def test_new_images_are_requested_ahead_and_results_do_not_change(cv, monkeypatch):
     """launches on NEW G2 images (another pointer than the handle's previous call) of 24 MiB and more: the waves of the launch's first
     row bands also touch the rest of the image (cvs_launch_info.warm = bands per wave; cvs_kernels_basis.hip dma_warm), every
