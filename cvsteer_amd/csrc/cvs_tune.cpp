@@ -70,7 +70,7 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // turn is a run of kTurnMin..kTurnMax consecutive calls (about kTurnMs of GPU time), the first kLead of which are not counted,
 // the first ROUND is burn-in (see evaluate), and what is compared are the MEDIANS OF WHOLE TURNS: a challenger replaces the default
 // only if, after at least two counted rounds, its
-// median turn is at least kGain faster than the default's median turn and its turns -- all of two, all but one of three or four --
+// median turn is at least kGain (3 %) faster than the default's median turn and its turns -- all of two, all but one of three or four --
 // are ahead of the default's median turn by half that; challengers that are not ahead by even half the margin on the median are
 // dropped after two rounds; after kMaxRounds the default stays.  The default leads every
 // round (a card coming out of an idle pause speeds up over tens of launches: whoever is sampled later looks faster -- that drift
@@ -123,7 +123,8 @@ constexpr int kLead = 5;                        // calls at the head of a turn t
 constexpr int kTurnMin = 20, kTurnMax = 100;    // calls per turn
 constexpr double kTurnMs = 12.0;                // ... about this much GPU time
 constexpr int kBurnIn = 1, kMinRounds = 2, kMaxRounds = 4, kMaxUnfit = 3;   // rounds: burn-in, then at least / at most this many that count
-constexpr float kGain = 0.02f;
+constexpr float kGain = 0.03f;   // (2 % until the strip-height challengers came: a 9-row strip won its turns by 2.1 % -- per-call event time -- and ran 1-1.6 % BEHIND
+                                 // back to back, where its 11 % more workgroups also cost between the launches: profiles/r06_tuner_value_probe.txt, session 24)
 
 static void apply(BasisArgs& a, const Cand& c)
 {
@@ -319,28 +320,35 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
         e.cand.push_back(c);
     }
     if (h->kind == CVS_KIND_G2) {
+        const bool multi = a.orient != nullptr || a.pipe;
+        const bool large = (size_t)a.rows * a.cols >= ((size_t)8 << 20);
+        // Shorter strips than the 10-row default (round 6).  Which height streams best depends on the SHAPE -- the row pitch decides which
+        // addresses the ~64 row bands in flight write at the same time -- and flips between shapes of one size class: same handle, tuner
+        // off, two processes (profiles/r06_strip_heights_fine.txt): launches that write the orientation planes too run 4-12 % faster with
+        // 7 rows at 1536 x 2048, 2048^2, 2160 x 3840, 3000 x 4000 and 4000 x 6000 and 8 % SLOWER at 4096^2; the basis pass and the fused
+        // steer gain 3-11 % from 9 or 8 rows at 2048^2 and 4000 x 6000 and lose 1-5 % at 4096^2.  No rule in sight: a challenger each.
+        if (a.batch == 0 && def.strip == sr_short) add({def.order, multi ? 7 : 9});
         if (fresh_input) {
             // a stream of new images: short strips are a must (the halo rows of vertically adjacent strips only hit in cache when
             // those strips run close in time); the plain order, the XCD-column order and the dynamic tail are within 1 % of each
             // other in sustained runs on large images, so only smaller ones compare them.  (Rounds 4 also offered a pure-read pass
             // over the image in front of the launch; the first waves of the launch do that themselves now: BasisArgs::warm_k.)
-            if ((size_t)a.rows * a.cols < ((size_t)8 << 20)) {
+            if (!large) {
                 add({kOrderDynamic, sr_short});
                 add({kOrderXcdColumns, sr_short});
             }
         } else {
             // Resident image.  What has beaten the default (plain order, 10-row strips) by more than 2 % in SUSTAINED side-by-side
             // runs on one handle (profiles/r04_order_probe_sustained.txt): for launches that also write the orientation planes
-            // (12 / 20 planes) the dynamic tail (+3 %) and the merged grouping (below) on handles whose plane groups lie badly;
-            // for the basis pass and the fused steer on a large image NOTHING (all orders within 1 %, taller strips behind), so
-            // those are not tuned at all.
-            const bool multi = a.orient != nullptr || a.pipe;
-            const bool large = (size_t)a.rows * a.cols >= ((size_t)8 << 20);
+            // (12 / 20 planes) the dynamic tail (+3 %); for the basis pass and the fused steer on a large image no ORDER (all within
+            // 1 %) -- they compare strip heights only.
             if (multi || !large) add({kOrderDynamic, sr_short});
-            if (!large) {   // smaller images (the default there is the 19-row strip): both heights, the column order
+            if (!large) {   // smaller images (below 3 Mpix the default is the 19-row strip): both heights, the column order
                 add({0, sr_short});
                 add({0, sr_tall});
                 add({kOrderXcdColumns, sr_short});
+            } else if (a.batch == 0 && !multi && def.strip == sr_short) {
+                add({def.order, 8});
             }
         }
     } else {

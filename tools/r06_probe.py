@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/r06_probe.py -- round-6 A/B probes, one process = one allocation history (run it in several).  Every comparison is made
 on ONE handle / state block with the online tuner off, settings alternating, SUSTAINED regions (a lead-in of a third of the region,
-then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c4w c4m strips lit tune
+then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c4w c4m strips strips2 strips3 lit tune
   c4     32 x 1080p caller pipeline with state kept (BASELINE config 4): plain order vs dynamic tail, workgroups per CU, batch ways,
          strip height, planar [n][8][H][W] outputs vs row-interleaved [n][H][8][W] ones
   m4     full setup at 4096^2: two plane groups (layout 1) vs one merged group (layout 2), workgroups per CU
@@ -314,13 +314,22 @@ if "tune" in sections:
     def batch3():
         alt[0] ^= 1
         fs.pipeline_batch(frames[alt[0]], out=fo3, outputs=(5, 6, 7))
-    legs = (("M4", 52, n * n, f, lambda: f.setup(img, flags=cv.SETUP_FULL)), ("M5", 84, n * n, f, lambda: f.pipeline(img, out=outs)),
+    big = torch.rand((4000, 6000), device="cuda")
+    uhd = torch.rand((2160, 3840), device="cuda")
+    gb, hb = cv.alloc_planes(2, 4000, 6000, device="cuda")
+    ouhd = cv.alloc_planes(8, 2160, 3840, device="cuda")
+    fbig, fuhd = cv.SteerableFiltersG2(None), cv.SteerableFiltersG2(None)
+    extra = (("M4 4000x6000", 52, 24000000, fbig, lambda: fbig.setup(big, flags=cv.SETUP_FULL)),
+             ("M2 4000x6000", 40, 24000000, fbig, lambda: fbig.setup_steer(big, 0.3, flags=cv.SETUP_BASIS, out=(gb, hb))),
+             ("M5 2160x3840", 84, 2160 * 3840, fuhd, lambda: fuhd.pipeline(uhd, out=ouhd)),
+             ("M4 2160x3840", 52, 2160 * 3840, fuhd, lambda: fuhd.setup(uhd, flags=cv.SETUP_FULL)))
+    legs = extra + (("M4", 52, n * n, f, lambda: f.setup(img, flags=cv.SETUP_FULL)), ("M5", 84, n * n, f, lambda: f.pipeline(img, out=outs)),
             ("G4", 48, n * n, f4, lambda: f4.setup(img)), ("M4 1536x2048", 52, 1536 * 2048, f, lambda: f.setup(small, flags=cv.SETUP_FULL)),
             ("C4 32x1080p state kept", 84, 32 * 1080 * 1920, fb, batch8), ("C4 32x1080p three maps", 16, 32 * 1080 * 1920, fs, batch3))
     for name, bpp, npx, hd, fn in legs:
         hd.set_option(L.OPT_AUTOTUNE, 1)
         calls = 0
-        for _ in range(100):
+        for _ in range(120):
             for _ in range(25):
                 fn()
             calls += 25
@@ -478,3 +487,84 @@ if "lit" in sections:
     opts("lit=0")(); fo3.zero_(); ff.pipeline_batch(fsets[0], out=fo3, outputs=(5, 6, 7))
     print("   three maps bit-identical: %s (literal_taps %d / %d)" % (torch.equal(r3, fo3), lit1, ff.launch_info()["literal_taps"]))
     opts("")()
+
+
+if "strips2" in sections:
+    # mid-size single images are short launches (15-40 us): how many workgroups there are against how many run at once decides the tail.  A fine
+    # sweep of the strip height (tuner off, same handle), with the number of workgroups of each height beside it.
+    import math
+    heights = (5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 19)
+    for shape in ((1080, 1920), (1536, 2048), (2048, 2048), (2160, 3840), (3000, 4000)):
+        r, c = shape
+        img = torch.rand(shape, device="cuda")
+        g, h = cv.alloc_planes(2, r, c, device="cuda")
+        o8 = cv.alloc_planes(8, r, c, device="cuda")
+        f = cv.SteerableFiltersG2(None, 4, 0.67)
+        gx = (math.ceil(c / 64) + 3) // 4
+        print("%dx%d: workgroups per height: %s" % (r, c, " ".join("%d:%d" % (hh, gx * math.ceil(r / hh)) for hh in heights)))
+        for name, bpp, fn in (("M1", 32, lambda: f.setup(img, flags=cv.SETUP_BASIS)), ("M2", 40, lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))),
+                              ("M4", 52, lambda: f.setup(img, flags=cv.SETUP_FULL)), ("M5", 84, lambda: f.pipeline(img, out=o8))):
+            res = {}
+            for rnd in range(2):
+                for hh in heights:
+                    f.set_option(L.OPT_STRIP_ROWS, hh)
+                    fn(); fn()
+                    res.setdefault(hh, []).append(timeit(fn, 150))
+            li = f.launch_info()
+            best = min(heights, key=lambda hh: statistics.median(res[hh]))
+            print("   %s wg_cap %d: %s   best %d" % (name, li["wg_per_cu"], " ".join("%d:%.3f" % (hh, bpp * r * c / (statistics.median(res[hh]) * 1e-3) / PEAK) for hh in heights), best), flush=True)
+        del f, img, g, h, o8
+
+
+if "strips3" in sections:
+    # does the 7-row strip of the 3-12 Mpix sweep (strips2) also hold for the launches that write the orientation planes at 4096^2 and above, on new
+    # images, and for the 32 x 1080p batch with state?
+    heights = (6, 7, 8, 9, 10)
+
+    def sweep(title, bpp, npx, f, fn, steps):
+        res = {}
+        for rnd in range(3):
+            for hh in heights:
+                f.set_option(L.OPT_STRIP_ROWS, hh)
+                fn(); fn()
+                res.setdefault(hh, []).append(timeit(fn, steps))
+        print("   %-44s %s" % (title, " ".join("%d:%.4f" % (hh, bpp * npx / (statistics.median(res[hh]) * 1e-3) / PEAK) for hh in heights)), flush=True)
+        f.set_option(L.OPT_STRIP_ROWS, 0)
+    for shape in ((4096, 4096), (4000, 6000)):
+        r, c = shape
+        imgs = [torch.rand(shape, device="cuda") for _ in range(4)]
+        o8 = cv.alloc_planes(8, r, c, device="cuda")
+        g, h = cv.alloc_planes(2, r, c, device="cuda")
+        f = cv.SteerableFiltersG2(None, 4, 0.67)
+        k = [0]
+
+        def nxt():
+            k[0] = (k[0] + 1) & 3
+            return imgs[k[0]]
+        print("%dx%d" % shape)
+        sweep("M4 resident", 52, r * c, f, lambda: f.setup(imgs[0], flags=cv.SETUP_FULL), 120)
+        sweep("M5 resident", 84, r * c, f, lambda: f.pipeline(imgs[0], out=o8), 100)
+        sweep("M4 on 4 rotating images", 52, r * c, f, lambda: f.setup(nxt(), flags=cv.SETUP_FULL), 120)
+        sweep("M2 + orientation (setup_steer FULL) resident", 60, r * c, f, lambda: f.setup_steer(imgs[0], 0.3, flags=cv.SETUP_FULL, out=(g, h)), 120)
+        sweep("M1 resident (for reference)", 32, r * c, f, lambda: f.setup(imgs[0], flags=cv.SETUP_BASIS), 120)
+        sweep("M2 resident (for reference)", 40, r * c, f, lambda: f.setup_steer(imgs[0], 0.3, flags=cv.SETUP_BASIS, out=(g, h)), 120)
+        del f, imgs, o8, g, h
+    nfr = 32
+    fsets = [torch.rand((nfr, 1080, 1920), device="cuda") for _ in range(2)]
+    fout = torch.empty((nfr, 8, 1080, 1920), device="cuda")
+    fo3 = torch.empty((nfr, 3, 1080, 1920), device="cuda")
+    ff = cv.SteerableFiltersG2(None, 4, 0.67)
+    alt = [0]
+
+    def c4():
+        alt[0] ^= 1
+        ff.pipeline_batch(fsets[alt[0]], out=fout)
+
+    def c4f():
+        alt[0] ^= 1
+        ff.pipeline_batch(fsets[alt[0]], out=fo3, outputs=(5, 6, 7))
+    print("32 x 1080p")
+    sweep("C4 state kept", 84, nfr * 1080 * 1920, ff, c4, 100)
+    ff.set_persist(False)
+    heights = (7, 10, 13, 19, 28)
+    sweep("C4 three maps only", 16, nfr * 1080 * 1920, ff, c4f, 100)
