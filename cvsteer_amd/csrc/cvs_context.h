@@ -158,7 +158,7 @@ EnvOpts env_opts();
 // compared on the caller's own launches); tune_end goes right behind the launch
 struct TuneToken {
     void* entry = nullptr;
-    int cand = 0;
+    int cand = 0, calls = 1;
     double npix = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };

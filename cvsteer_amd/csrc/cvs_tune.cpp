@@ -59,8 +59,8 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // order, the dynamic tail), the strip height, and for full G2 setups the grouping of the state planes.  Which combination is
 // fastest depends on the box and -- more -- on the PROCESS, i.e. on where the allocator put the planes, so a short list (at
 // most four) is compared where the code runs.  NOTHING extra is launched: while a key is undecided each of the caller's own
-// calls runs one candidate, bracketed by a pair of events on the caller's stream; samples are read back later with
-// hipEventQuery, never waited for.
+// calls runs one candidate, every turn of a candidate bracketed by ONE pair of events on the caller's stream; the times are
+// read back later with hipEventQuery, never waited for.
 //
 // Round 6: candidates are compared in SUSTAINED turns.  Rounds 4-5 let the candidates take turns in blocks of five calls and
 // decided with Welch's t on the pooled samples.  That was precise about the wrong quantity: a configuration that wins five-call
@@ -102,13 +102,20 @@ struct TuneEntry {
     int pending = 0;               // samples recorded but not read back yet
     int chosen = -1;               // index into cand once decided
     bool round_complete = false;   // a whole round has been issued since the last evaluation
-    double ms_per_call = 0;        // last sampled call of the default (sets the length of the next round's turns)
+    double ms_per_call = 0;        // time per call of the default's last turn (sets the length of the next round's turns)
+    // the turn in progress: ONE event pair around its counted calls (see tune_begin)
+    hipEvent_t t_e0 = nullptr;
+    hipStream_t t_stream = nullptr;
+    double t_npix = 0;
+    int t_calls = 0, t_device = 0;
+    bool t_valid = false;
 };
 
-struct Sample {
+struct Sample {   // one TURN: the events around its counted calls
     TuneEntry* entry;
     int cand;
-    double npix;
+    double npix;       // pixels of all the calls between the events
+    int calls;
     hipEvent_t e0, e1;
     int device;
 };
@@ -156,7 +163,7 @@ static void evaluate(TuneEntry& e)
         // Round 1 is burn-in and does not count: a configuration's FIRST turn in a process runs 15-25 % slower than its later ones for
         // tens of launches (verbose logs of four bench processes, profiles/r06_tuner_first_turn.txt: default 0.01663 then 0.01419 ns/pix,
         // dynamic tail 0.01000 then 0.00803) -- counted, it made a cold default lose to a warm challenger, or a cold challenger drop out
-        if (e.round > kBurnIn && e.turn[c].size() >= 4) e.medians[c].push_back(median_of(e.turn[c]));   // (a turn most of whose samples failed to record does not count)
+        if (e.round > kBurnIn && !e.turn[c].empty()) e.medians[c].push_back(median_of(e.turn[c]));   // (one value per turn; a turn that could not be timed does not count)
         e.turn[c].clear();
     }
     const int counted = e.round - kBurnIn;   // rounds that count
@@ -191,7 +198,7 @@ static void evaluate(TuneEntry& e)
     if (decision >= 0) {
         e.chosen = decision;
         if (env_opts().verbose) {
-            std::fprintf(stderr, "[cvsteer] tuned on the caller's launches (ns/pix, median of each sustained turn):");
+            std::fprintf(stderr, "[cvsteer] tuned on the caller's launches (ns per pixel of each sustained turn):");
             for (size_t c = 0; c < e.cand.size(); ++c) {
                 std::fprintf(stderr, " (order %d, strip %d, merged %d, wg %d%s)", e.cand[c].order, e.cand[c].strip, e.cand[c].merge, e.cand[c].wg, e.dropped[c] ? ", dropped" : "");
                 for (float m : e.medians[c]) std::fprintf(stderr, " %.5f", m);
@@ -217,7 +224,7 @@ static void harvest()
         TuneEntry& e = *sm.entry;
         if (q == hipSuccess && hipEventElapsedTime(&ms, sm.e0, sm.e1) == hipSuccess && ms > 0.f) {
             if (e.turn[sm.cand].size() < (size_t)kTurnMax) e.turn[sm.cand].push_back((float)(ms * 1e6 / sm.npix));
-            if (sm.cand == 0) e.ms_per_call = ms;
+            if (sm.cand == 0) e.ms_per_call = ms / std::max(1, sm.calls);
         }
         (void)hipGetLastError();
         --e.pending;
@@ -431,19 +438,40 @@ int tune_begin(cvs_handle h, BasisArgs& a, int variant, bool fresh_input, TuneTo
     const int c = e.cur;
     const bool fit = fits(a, e.cand[c]);
     if (fit) apply(a, e.cand[c]);
-    const bool counted = fit && e.in_turn >= kLead;    // a configuration's first launches after a change are not representative
-    if (counted) {
-        hipEvent_t e0 = take_event(h->device), e1 = take_event(h->device);
-        if (e0 && e1 && hipEventRecord(e0, h->stream) == hipSuccess) {
-            tok.e0 = e0;
-            tok.e1 = e1;
-            tok.entry = &e;
-            tok.cand = c;
-            tok.npix = (double)a.rows * (double)a.cols * (double)(a.batch > 0 ? a.batch : 1);
-        } else {
-            if (e0) g_free_events[h->device].push_back(e0);
-            if (e1) g_free_events[h->device].push_back(e1);
-            (void)hipGetLastError();
+    // ONE event pair per turn, around its counted calls (everything behind the first kLead: a configuration's first launches after a change
+    // are not representative).  Until late in round 6 every call had its own pair; that measures how long a kernel ISSUES, not what a run of
+    // them delivers: the stores a kernel leaves behind drain in the gap the events make, and a configuration that issues faster but leaves
+    // more behind (shorter strips: more workgroups) won per call -- 2-3 % -- and ran 1-6 % SLOWER back to back (the headline launch itself, once:
+    // profiles/r06_tuner_value_probe.txt, session 28).  A turn whose calls come from more than one stream, or that met a shape its candidate
+    // does not fit, cannot be timed this way and does not count.
+    if (e.in_turn >= kLead) {
+        if (e.in_turn == kLead) {   // the first counted call opens the turn
+            if (e.t_e0) g_free_events[e.t_device].push_back(e.t_e0);
+            e.t_e0 = take_event(h->device);
+            e.t_device = h->device;
+            e.t_stream = h->stream;
+            e.t_npix = 0;
+            e.t_calls = 0;
+            e.t_valid = fit && e.t_e0 && hipEventRecord(e.t_e0, h->stream) == hipSuccess;
+            if (!e.t_valid) (void)hipGetLastError();
+        }
+        if (!fit || h->stream != e.t_stream) e.t_valid = false;
+        e.t_npix += (double)a.rows * (double)a.cols * (double)(a.batch > 0 ? a.batch : 1);
+        ++e.t_calls;
+        if (e.in_turn == e.turn_len - 1) {   // the last call closes it: tune_end records the second event behind this launch
+            hipEvent_t e1 = e.t_valid ? take_event(h->device) : nullptr;
+            if (e1) {
+                tok.e0 = e.t_e0;
+                tok.e1 = e1;
+                tok.entry = &e;
+                tok.cand = c;
+                tok.npix = e.t_npix;
+                tok.calls = e.t_calls;
+                e.t_e0 = nullptr;
+            } else if (e.t_e0) {
+                g_free_events[e.t_device].push_back(e.t_e0);
+                e.t_e0 = nullptr;
+            }
         }
     }
     if (++e.in_turn >= e.turn_len) next_cand();
@@ -456,7 +484,7 @@ void tune_end(cvs_handle h, const TuneToken& tok)
     std::lock_guard<std::mutex> lock(g_tune_mutex);
     TuneEntry* e = static_cast<TuneEntry*>(tok.entry);
     if (hipEventRecord(tok.e1, h->stream) == hipSuccess) {
-        g_samples.push_back({e, tok.cand, tok.npix, tok.e0, tok.e1, h->device});
+        g_samples.push_back({e, tok.cand, tok.npix, tok.calls, tok.e0, tok.e1, h->device});
         ++e->pending;
     } else {
         (void)hipGetLastError();
