@@ -332,9 +332,13 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
         // Shorter strips than the 10-row default (round 6).  Which height streams best depends on the SHAPE -- the row pitch decides which
         // addresses the ~64 row bands in flight write at the same time -- and flips between shapes of one size class: same handle, tuner
         // off, two processes (profiles/r06_strip_heights_fine.txt): launches that write the orientation planes too run 4-12 % faster with
-        // 7 rows at 1536 x 2048, 2048^2, 2160 x 3840, 3000 x 4000 and 4000 x 6000 and 8 % SLOWER at 4096^2; the basis pass and the fused
-        // steer gain 3-11 % from 9 or 8 rows at 2048^2 and 4000 x 6000 and lose 1-5 % at 4096^2.  No rule in sight: a challenger each.
-        if (a.batch == 0 && def.strip == sr_short) add({def.order, multi ? 7 : 9});
+        // 7 rows at 1536 x 2048, 2048^2, 2160 x 3840, 3000 x 4000 and 4000 x 6000 and 8 % SLOWER at 4096^2.  No rule in sight: a challenger.
+        // NOT for the basis pass and the fused steer: their 9- and 8-row strips gain 3-11 % at some shapes on some boxes and were offered for
+        // a while -- until an 8-row strip that was 3 % ahead over its 12 ms turns took the HEADLINE launch from 0.835 to 0.798 in one bench
+        // process of eight: run for seconds it draws the card's clock down (1.88 instead of 2.07 GHz under the same 1400 W), which no turn
+        // of a few milliseconds can see (profiles/r06_bench_lines_earlier_in_the_round.jsonl, the last line).  Margins of a few per cent on
+        // a launch that runs at the power cap are not decidable on the caller's own calls; margins of 6-10 % (7 rows, below) are.
+        if (a.batch == 0 && multi && def.strip == sr_short) add({def.order, 7});
         if (fresh_input) {
             // a stream of new images: short strips are a must (the halo rows of vertically adjacent strips only hit in cache when
             // those strips run close in time); the plain order, the XCD-column order and the dynamic tail are within 1 % of each
@@ -347,15 +351,13 @@ static void build_candidates(cvs_handle h, const BasisArgs& a, bool fresh_input,
         } else {
             // Resident image.  What has beaten the default (plain order, 10-row strips) by more than 2 % in SUSTAINED side-by-side
             // runs on one handle (profiles/r04_order_probe_sustained.txt): for launches that also write the orientation planes
-            // (12 / 20 planes) the dynamic tail (+3 %); for the basis pass and the fused steer on a large image no ORDER (all within
-            // 1 %) -- they compare strip heights only.
+            // (12 / 20 planes) the dynamic tail (+3 %); for the basis pass and the fused steer on a large image NOTHING (all orders within
+            // 1 %; strip heights: see above), so those are not tuned at all.
             if (multi || !large) add({kOrderDynamic, sr_short});
             if (!large) {   // smaller images (below 3 Mpix the default is the 19-row strip): both heights, the column order
                 add({0, sr_short});
                 add({0, sr_tall});
                 add({kOrderXcdColumns, sr_short});
-            } else if (a.batch == 0 && !multi && def.strip == sr_short) {
-                add({def.order, 8});
             }
         }
     } else {

@@ -20,7 +20,7 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     it, 25-30 ms); cvs_launch_info.tuning_launches stays 0; every call -- whatever candidate configuration it ran with --
     returns the same bits; the comparison ends by itself (cvs_launch_info.tune_state 1 -> 2) after two or three rounds of SUSTAINED turns
     (20-100 consecutive calls per candidate, cvs_tune.cpp).  The launch is the full setup (12 planes); the basis pass
-    and the fused steer on a large resident image compare strip heights only (see build_candidates) -- checked at the end"""
+    and the fused steer on a large resident image are deliberately NOT tuned (see build_candidates) -- checked at the end"""
     import torch
     from cvsteer_amd import _lib as L
     n = 4096
@@ -82,22 +82,20 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
         seen.add((li["block_order"], li["strip_rows"]))
     assert len(seen) <= 2 and torch.equal(f3.getDominantOrientationAngle(), first[0])   # (first call = fresh-image default, then the resident default)
     del last
-    # the fused steer and the basis pass on this large resident image compare strip heights only (round 6: 9 and 8 rows against 10; no order wins
-    # there) -- and at 4096^2 the 10-row default is what they end up with
+    # the fused steer and the basis pass on this large resident image: one configuration from the second call on, tuner or not (no order wins
+    # there, and strip heights of a few per cent are not decidable on a launch that runs at the power cap: build_candidates)
     f4 = cv.SteerableFiltersG2(None)
-    for name, fn in (("steer", lambda: f4.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))), ("basis", lambda: f4.setup(img, flags=cv.SETUP_BASIS))):
-        fn()
-        orders = set()
-        for k in range(2100):
-            fn()
-            li = f4.launch_info()
-            orders.add(li["block_order"])
-            if k % 25 == 24:
-                torch.cuda.synchronize()
-                if li["tune_state"] == 2:
-                    break
-        assert f4.launch_info()["tune_state"] == 2, (name, f4.launch_info())
-        assert orders == {0}, (name, orders)
+    seen = set()
+    for k in range(30):
+        if k & 1:
+            f4.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h))
+        else:
+            f4.setup(img, flags=cv.SETUP_BASIS)
+        li = f4.launch_info()
+        if k >= 2:
+            seen.add((li["block_order"], li["strip_rows"]))
+            assert li["tune_state"] == 0
+    assert len(seen) == 1, seen
 
 
 def test_a_bucket_of_mixed_shapes_still_comes_to_a_decision(cv):
