@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/r06_probe.py -- round-6 A/B probes, one process = one allocation history (run it in several).  Every comparison is made
 on ONE handle / state block with the online tuner off, settings alternating, SUSTAINED regions (a lead-in of a third of the region,
-then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c4w c4m strips strips2 strips3 lit tune
+then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c3s c4w c4m strips strips2 strips3 lit tune
   c4     32 x 1080p caller pipeline with state kept (BASELINE config 4): plain order vs dynamic tail, workgroups per CU, batch ways,
          strip height, planar [n][8][H][W] outputs vs row-interleaved [n][H][8][W] ones
   m4     full setup at 4096^2: two plane groups (layout 1) vs one merged group (layout 2), workgroups per CU
@@ -568,3 +568,30 @@ if "strips3" in sections:
     ff.set_persist(False)
     heights = (7, 10, 13, 19, 28)
     sweep("C4 three maps only", 16, nfr * 1080 * 1920, ff, c4f, 100)
+
+
+if "c3s" in sections:
+    # config 3 once more with what the strip sweeps taught: the height of level 0 (8192^2 new image + emission, 73 % of the call) and of level 1, and their occupancy caps
+    bigs = [torch.rand((8192, 8192), device="cuda") for _ in range(2)]
+    fp3 = cv.SteerableFiltersG2(None, 4, 0.67)
+    lv = fp3.pyramid(bigs[0], 5)
+    ppix = sum(l.shape[0] * l.shape[1] for l in lv)
+    hp = [cv.SteerableFiltersG2(None, 4, 0.67) for _ in lv]
+    fl = [0]
+
+    def pyr():
+        fl[0] ^= 1
+        cv.pyramid_setup(hp, bigs[fl[0]], level_images=lv[1:], flags=cv.SETUP_BASIS)
+    whole = 32 * ppix + 4 * (ppix - 8192 * 8192)
+
+    def heights(h0, h1, o=""):
+        def f():
+            hp[0].set_option(L.OPT_STRIP_ROWS, h0)
+            hp[1].set_option(L.OPT_STRIP_ROWS, h1)
+            opts(o)()
+        return f
+    pyr()
+    ab("C3 whole, strip height of level 0 / level 1 (0 = default 10)", whole, 24, [("10 / 10", heights(0, 0), pyr), ("7 / 10", heights(7, 0), pyr), ("8 / 10", heights(8, 0), pyr),
+        ("9 / 10", heights(9, 0), pyr), ("12 / 10", heights(12, 0), pyr), ("14 / 10", heights(14, 0), pyr), ("19 / 10", heights(19, 0), pyr), ("28 / 10", heights(28, 0), pyr),
+        ("10 / 7", heights(0, 7), pyr), ("10 / 9", heights(0, 9), pyr), ("10 / 19", heights(0, 19), pyr), ("19 / 19", heights(19, 19), pyr)])
+    heights(0, 0)()
