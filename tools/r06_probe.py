@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/r06_probe.py -- round-6 A/B probes, one process = one allocation history (run it in several).  Every comparison is made
 on ONE handle / state block with the online tuner off, settings alternating, SUSTAINED regions (a lead-in of a third of the region,
-then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c3s c4w c4m strips strips2 strips3 lit tune
+then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c3s c4w c4m strips strips2 strips3 strips4 lit tune
   c4     32 x 1080p caller pipeline with state kept (BASELINE config 4): plain order vs dynamic tail, workgroups per CU, batch ways,
          strip height, planar [n][8][H][W] outputs vs row-interleaved [n][H][8][W] ones
   m4     full setup at 4096^2: two plane groups (layout 1) vs one merged group (layout 2), workgroups per CU
@@ -595,3 +595,30 @@ if "c3s" in sections:
         ("9 / 10", heights(9, 0), pyr), ("12 / 10", heights(12, 0), pyr), ("14 / 10", heights(14, 0), pyr), ("19 / 10", heights(19, 0), pyr), ("28 / 10", heights(28, 0), pyr),
         ("10 / 7", heights(0, 7), pyr), ("10 / 9", heights(0, 9), pyr), ("10 / 19", heights(0, 19), pyr), ("19 / 19", heights(19, 19), pyr)])
     heights(0, 0)()
+
+
+if "strips4" in sections:
+    # 7 against 10 rows for the launches that write the orientation planes, 3-14 Mpix, resident AND new images (four rotating), tuner off
+    for shape in ((1536, 2048), (2048, 2048), (2000, 3000), (2160, 3840), (3000, 4000), (3456, 4608)):
+        r, c = shape
+        imgs = [torch.rand(shape, device="cuda") for _ in range(4)]
+        o8 = cv.alloc_planes(8, r, c, device="cuda")
+        g, h = cv.alloc_planes(2, r, c, device="cuda")
+        f = cv.SteerableFiltersG2(None, 4, 0.67)
+        k = [0]
+
+        def nxt():
+            k[0] = (k[0] + 1) & 3
+            return imgs[k[0]]
+
+        def sr(n):
+            def fn():
+                f.set_option(L.OPT_STRIP_ROWS, n)
+                opts("")()
+            return fn
+        for name, bpp, fn in (("M4 resident", 52, lambda: f.setup(imgs[0], flags=cv.SETUP_FULL)), ("M4 new images", 52, lambda: f.setup(nxt(), flags=cv.SETUP_FULL)),
+                              ("M5 resident", 84, lambda: f.pipeline(imgs[0], out=o8)), ("M5 new images", 84, lambda: f.pipeline(nxt(), out=o8)),
+                              ("setup_steer FULL resident", 60, lambda: f.setup_steer(imgs[0], 0.3, flags=cv.SETUP_FULL, out=(g, h)))):
+            fn()
+            ab("%s %dx%d" % (name, r, c), bpp * r * c, 150, [("10 rows", sr(10), fn), ("7 rows", sr(7), fn), ("8 rows", sr(8), fn)], rounds=2)
+        del f, imgs, o8, g, h
