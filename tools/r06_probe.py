@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/r06_probe.py -- round-6 A/B probes, one process = one allocation history (run it in several).  Every comparison is made
 on ONE handle / state block with the online tuner off, settings alternating, SUSTAINED regions (a lead-in of a third of the region,
-then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c3s c4w c4m strips strips2 strips3 strips4 lit tune
+then `steps` launches between two events), three rounds, medians.  Sections (argv): c4 m4 c3 fresh c3lv c3x c3s c4w c4m strips strips2 strips3 strips4 long lit tune
   c4     32 x 1080p caller pipeline with state kept (BASELINE config 4): plain order vs dynamic tail, workgroups per CU, batch ways,
          strip height, planar [n][8][H][W] outputs vs row-interleaved [n][H][8][W] ones
   m4     full setup at 4096^2: two plane groups (layout 1) vs one merged group (layout 2), workgroups per CU
@@ -622,3 +622,74 @@ if "strips4" in sections:
             fn()
             ab("%s %dx%d" % (name, r, c), bpp * r * c, 150, [("10 rows", sr(10), fn), ("7 rows", sr(7), fn), ("8 rows", sr(8), fn)], rounds=2)
         del f, imgs, o8, g, h
+
+
+if "long" in sections:
+    # what the tuner's remaining challengers are worth when they run for SECONDS (the power management answers a configuration over a longer time than a 12 ms turn):
+    # regions of ~1.5 s each, alternating, same handle, tuner off; shader clock and power read from sysfs during each region
+    import glob, threading, time
+    pr = torch.cuda.get_device_properties(0)
+    want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    card = [c_ for c_ in glob.glob("/sys/class/drm/card*/device") if want in os.path.realpath(c_)]
+    fclk = (sorted(glob.glob(os.path.join(card[0], "hwmon/hwmon*/freq1_input"))) or [None])[0] if card else None
+
+    def region(fn, seconds=1.5):
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        clk, stop = [], [False]
+
+        def sampler():
+            while not stop[0]:
+                try:
+                    clk.append(int(open(fclk).read().split()[0]))
+                except Exception:
+                    pass
+                time.sleep(0.05)
+        th = threading.Thread(target=sampler) if fclk else None
+        if th:
+            th.start()
+        n, t0 = 0, time.perf_counter()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(200):
+                fn()
+            n += 200
+            torch.cuda.synchronize()
+        b_.record()
+        torch.cuda.synchronize()
+        stop[0] = True
+        if th:
+            th.join()
+        half = sorted(clk[len(clk) // 2:])
+        return a_.elapsed_time(b_) / n, (half[len(half) // 2] / 1e6 if half else 0)
+    n_ = 4096
+    img = torch.rand((n_, n_), device="cuda")
+    big = torch.rand((4000, 6000), device="cuda")
+    o8 = cv.alloc_planes(8, n_, n_, device="cuda")
+    g, h = cv.alloc_planes(2, n_, n_, device="cuda")
+    f = cv.SteerableFiltersG2(None, 4, 0.67)
+    fb = cv.SteerableFiltersG2(None, 4, 0.67)
+
+    def cfg(hd, order=0, strip=0, o=""):
+        def fn():
+            hd.set_option(L.OPT_BLOCK_ORDER, order)
+            hd.set_option(L.OPT_STRIP_ROWS, strip)
+            opts(o)()
+        return fn
+    cases = [("M4 4096^2", 52 * n_ * n_, lambda: f.setup(img, flags=cv.SETUP_FULL), [("plain 10", cfg(f)), ("dynamic tail", cfg(f, L.ORDER_DYNAMIC_TAIL)), ("7 rows", cfg(f, 0, 7))]),
+             ("M5 4096^2", 84 * n_ * n_, lambda: f.pipeline(img, out=o8), [("plain 10, wg 3", cfg(f)), ("wg 5", cfg(f, 0, 0, "wgcap=5")), ("dynamic tail", cfg(f, L.ORDER_DYNAMIC_TAIL)), ("7 rows", cfg(f, 0, 7))]),
+             ("M2 4096^2 (headline)", 40 * n_ * n_, lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h)), [("plain 10", cfg(f)), ("9 rows", cfg(f, 0, 9)), ("8 rows", cfg(f, 0, 8))]),
+             ("M4 4000x6000", 52 * 24000000, lambda: fb.setup(big, flags=cv.SETUP_FULL), [("plain 10", cfg(fb)), ("7 rows", cfg(fb, 0, 7)), ("dynamic tail", cfg(fb, L.ORDER_DYNAMIC_TAIL))])]
+    for title, nbytes, fn, variants in cases:
+        fn()
+        res = {lab: [] for lab, _ in variants}
+        for rnd in range(2):
+            for lab, pre in variants:
+                pre()
+                res[lab].append(region(fn))
+        print(title + "  (1.5 s regions, two rounds: fraction of the HBM roofline @ shader clock)")
+        for lab, _ in variants:
+            print("   %-18s %s" % (lab, "   ".join("%.4f @ %.2f GHz" % (nbytes / (ms * 1e-3) / PEAK, ck / 1e3) for ms, ck in res[lab])), flush=True)
+    cfg(f)(); cfg(fb)()
