@@ -56,25 +56,25 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // Launch configuration: defaults, and the ONLINE comparison of a few alternatives on the caller's own launches.
 //
 // What a basis launch leaves open is the order in which its tiles are dealt to the chip (plain row-major, the XCD-column
-// order, the dynamic tail), the strip height, and for full G2 setups the grouping of the state planes.  Which combination is
-// fastest depends on the box and -- more -- on the PROCESS, i.e. on where the allocator put the planes, so a short list (at
-// most four) is compared where the code runs.  NOTHING extra is launched: while a key is undecided each of the caller's own
-// calls runs one candidate, every turn of a candidate bracketed by ONE pair of events on the caller's stream; the times are
-// read back later with hipEventQuery, never waited for.
+// order, the dynamic tail), the strip height and the number of workgroups per CU.  Which combination is fastest depends on the
+// box and -- more -- on the PROCESS, i.e. on where the allocator put the planes, so a short list (at most four) is compared
+// where the code runs.  NOTHING extra is launched: while a key is undecided each of the caller's own calls runs one candidate,
+// every turn of a candidate bracketed by ONE pair of events on the caller's stream; the times are read back later with
+// hipEventQuery, never waited for.
 //
 // Round 6: candidates are compared in SUSTAINED turns.  Rounds 4-5 let the candidates take turns in blocks of five calls and
 // decided with Welch's t on the pooled samples.  That was precise about the wrong quantity: a configuration that wins five-call
 // blocks interleaved with other configurations need not win when it runs for good -- the dynamic tail won the interleaved
 // samples of the 32 x 1080p batch in 8 of 22 bench processes and then ran 6 % behind the plain order, a five-workgroups-per-CU
-// challenger for the full setup won in 13 of 13 and ran 3 % behind (profiles/r05_bench_lines*.jsonl).  Now a candidate's
-// turn is a run of kTurnMin..kTurnMax consecutive calls (about kTurnMs of GPU time), the first kLead of which are not counted,
-// the first ROUND is burn-in (see evaluate), and what is compared are the MEDIANS OF WHOLE TURNS: a challenger replaces the default
-// only if, after at least two counted rounds, its
-// median turn is at least kGain (3 %) faster than the default's median turn and its turns -- all of two, all but one of three or four --
-// are ahead of the default's median turn by half that; challengers that are not ahead by even half the margin on the median are
-// dropped after two rounds; after kMaxRounds the default stays.  The default leads every
-// round (a card coming out of an idle pause speeds up over tens of launches: whoever is sampled later looks faster -- that drift
-// can only work against a challenger).
+// challenger for the full setup won in 13 of 13 and ran 3 % behind (profiles/r05_bench_lines*.jsonl).  Now a
+// candidate's turn is a run of kTurnMin..kTurnMax consecutive calls (about kTurnMs of GPU time) timed as a WHOLE behind its first
+// kLead calls, the first ROUND is burn-in (see evaluate), and a challenger replaces the default only if, after at least two
+// counted rounds, its median turn is at least kGain (3 %) faster than the default's median turn and its turns -- all of two,
+// all but one of three or four -- are ahead of the default's median turn by half that; challengers that are not ahead by even
+// half the margin on the median are dropped after two rounds; after kMaxRounds counted rounds the default stays.  The default
+// leads every round.  What no turn of a few milliseconds can see is how the card's power management answers a configuration
+// that runs for seconds (build_candidates: the strip heights that were withdrawn): the margin and the short list of
+// challengers with effects of 5 % and more are the protection against that.
 //
 // Keys are by pixel-count BUCKET (half octaves), not by exact shape: the reference's callers build one object per image of
 // whatever size comes along (example/steer.cpp:86).  Samples are kept as time per pixel so that shapes of one bucket pool.  A
@@ -86,20 +86,20 @@ int use_nt_stores(cvs_handle h, size_t npix)
 // ---------------------------------------------------------------------------------------------------------------------
 struct Cand {
     int order, strip;
-    int merge = 0;   // G2 launches that write orientation planes: one 12-plane group instead of basis | orientation (cvs_handle.cpp layout_state)
+    int merge = 0;   // the default's grouping of the G2 state planes (default_config), carried along: never varied any more
     int wg = -1;     // workgroups per CU; -1 = what default_config's rule says
     bool operator==(const Cand& o) const { return order == o.order && strip == o.strip && merge == o.merge && wg == o.wg; }
 };
 
 struct TuneEntry {
     std::vector<Cand> cand;        // cand[0] = the default
-    std::vector<std::vector<float>> turn;      // per candidate: samples (ns per pixel) of its turn of the round in progress
-    std::vector<std::vector<float>> medians;   // per candidate: the median of every completed turn
+    std::vector<std::vector<float>> turn;      // per candidate: ns per pixel of its turn of the round in progress (one value)
+    std::vector<std::vector<float>> medians;   // per candidate: ns per pixel of every counted turn
     std::vector<char> dropped;     // challengers out of the race
     std::vector<int> unfit;        // turns a candidate has passed because the call's shape did not fit it
     int cur = 0, in_turn = 0, round = 0;
     int turn_len = 0;              // calls per turn in this round
-    int pending = 0;               // samples recorded but not read back yet
+    int pending = 0;               // turns recorded but not read back yet
     int chosen = -1;               // index into cand once decided
     bool round_complete = false;   // a whole round has been issued since the last evaluation
     double ms_per_call = 0;        // time per call of the default's last turn (sets the length of the next round's turns)
