@@ -291,7 +291,11 @@ static bool default_config(cvs_handle h, BasisArgs& a, int variant)
     const bool fast = basis_fast_path(h->kind, h->width, h->taps);
     const bool big = (size_t)a.rows * a.cols >= ((size_t)1 << 20);
     // the plain row-major order: with the row-interleaved state it is within a few per cent of the best order on every box
-    // and every variant measured, resident image or fresh (profiles/r04_layout_probe.txt); what beats it is box-dependent
+    // and every variant measured, resident image or fresh (profiles/r04_layout_probe.txt); what beats it is box-dependent.
+    // (Round 6 held the dynamic tail against it for SECONDS -- regions of 1.5 s, same handle, alternating -- for single images of 8 Mpix and
+    // more whose launch writes the orientation planes too: ahead on six boxes, full setup at 4096^2 +1.4 ... +3.4 %, pipeline +0.9 ... +3.5 %,
+    // on new images 0 ... +1 % (profiles/r06_long_regions.txt); made the default, the seventh box read 0.786 with it where the plain order
+    // reads 0.80 and its tuner went back to the plain order.  It stays a challenger.)
     a.block_order = h->block_order >= 0 ? h->block_order : 0;
     return fast && big;
 }

@@ -682,6 +682,16 @@ if "long" in sections:
              ("M5 4096^2", 84 * n_ * n_, lambda: f.pipeline(img, out=o8), [("plain 10, wg 3", cfg(f)), ("wg 5", cfg(f, 0, 0, "wgcap=5")), ("dynamic tail", cfg(f, L.ORDER_DYNAMIC_TAIL)), ("7 rows", cfg(f, 0, 7))]),
              ("M2 4096^2 (headline)", 40 * n_ * n_, lambda: f.setup_steer(img, 0.3, flags=cv.SETUP_BASIS, out=(g, h)), [("plain 10", cfg(f)), ("9 rows", cfg(f, 0, 9)), ("8 rows", cfg(f, 0, 8))]),
              ("M4 4000x6000", 52 * 24000000, lambda: fb.setup(big, flags=cv.SETUP_FULL), [("plain 10", cfg(fb)), ("7 rows", cfg(fb, 0, 7)), ("dynamic tail", cfg(fb, L.ORDER_DYNAMIC_TAIL))])]
+    imgs4 = [img] + [torch.rand((n_, n_), device="cuda") for _ in range(3)]
+    rot = [0]
+
+    def nxt4():
+        rot[0] = (rot[0] + 1) & 3
+        return imgs4[rot[0]]
+    cases += [("M4 4096^2, four rotating images", 52 * n_ * n_, lambda: f.setup(nxt4(), flags=cv.SETUP_FULL), [("plain 10", cfg(f)), ("dynamic tail", cfg(f, L.ORDER_DYNAMIC_TAIL))]),
+              ("M5 4096^2, four rotating images", 84 * n_ * n_, lambda: f.pipeline(nxt4(), out=o8), [("plain 10, wg 3", cfg(f)), ("dynamic tail", cfg(f, L.ORDER_DYNAMIC_TAIL))])]
+    if "fresh_only" in sections:
+        cases = cases[-2:]
     for title, nbytes, fn, variants in cases:
         fn()
         res = {lab: [] for lab, _ in variants}
