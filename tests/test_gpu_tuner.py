@@ -40,7 +40,7 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
     times, configs = [], set()
     first = None
     states = []
-    for i in range(1500):
+    for i in range(2600):
         times.append(call())
         li = f.launch_info()
         configs.add((li["block_order"], li["strip_rows"], li["state_layout"]))
@@ -50,7 +50,7 @@ def test_online_tuner_issues_no_extra_launches_and_never_stalls(cv):
             break
         if first is None:
             first = (f.getDominantOrientationAngle().clone(), f.getDominantOrientationStrength().clone(), f.basis(3).clone())
-        elif i in (1, 2, 5, 9, 14, 22, 31, 45, 69, 120, 199, 260, 333, 480, 700, 1100):
+        elif i in (1, 2, 5, 9, 14, 22, 31, 45, 69, 120, 199, 260, 333, 480, 700, 1100, 1600, 2200):
             assert torch.equal(f.getDominantOrientationAngle(), first[0]) and torch.equal(f.getDominantOrientationStrength(), first[1]) and torch.equal(f.basis(3), first[2]), i
     steady = statistics.median(times[-15:])
     assert times[1] <= 1.5 * steady + 0.15, (times[:4], steady)          # the second call is an ordinary call (+ host jitter; rounds 2-3: 25-30 ms)
