@@ -94,9 +94,10 @@ enum {
     CVS_OPT_PERSIST_STATE = 9, /* cvs_pipeline / cvs_pipeline_batch: 1 (default) = keep basis + orientation planes like the
                                   reference object does; 0 = write the requested outputs only (no state afterwards) */
     CVS_OPT_AUTOTUNE = 12,   /* 1 (default): while a (kind, entry point, shape bucket) is undecided, each call runs one of a few launch
-                                configurations between two events on the caller's stream (no extra launches, no waiting); the
-                                engine keeps a challenger only when its samples are separated from the default's beyond their
-                                spread; 0 = always the defaults */
+                                configurations, every candidate in sustained turns of 20-100 consecutive calls timed as a whole between
+                                two events on the caller's stream (no extra launches, no waiting); the engine keeps a challenger only
+                                when its turns are 3 % ahead of the default's, consistently; 0 = always the
+                                defaults */
     CVS_OPT_HOST_OVERLAP = 13, /* cvs_setup / cvs_setup_steer / cvs_pipeline with HOST planes on images of 1 Mpix and more:
                                   1 (default) = the image goes up, is filtered and comes down in row bands, all three at once
                                   (full-duplex host link, a second host thread for the downloads); 0 = one after the other */
