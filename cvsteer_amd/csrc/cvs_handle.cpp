@@ -426,10 +426,11 @@ void release_state(cvs_handle h)
 
 // Where the planes of the current geometry (h->rows, h->dense_pitch, h->layout_stride) lie inside a frame's block.
 // merge_orient (G2, interleaved layout): the five orientation planes join the basis planes in ONE group of twelve -- a full
-// setup or a pipeline launch then writes one sweep instead of two.  Which of the two is faster depends on the process: two
-// groups run the 12-plane launch at 0.755 or at 0.854 of the HBM roofline depending on where the allocator put the block,
-// one group at 0.81-0.82 either way (profiles/r04_groups_probe.txt), so the launch tuner compares them on the spot for the
-// launches that write orientation planes (cvs_tune.cpp); a basis-only launch always uses the two-group form (dense stream).
+// setup or a pipeline launch then writes one sweep instead of two.  Two groups run the 12-plane launch at 0.755 or at 0.854 of
+// the HBM roofline depending on where the allocator put the block, one group at 0.81-0.82 either way
+// (profiles/r04_groups_probe.txt); rounds 4-5 let the tuner compare the two, since round 6 one group is what single-image
+// launches that write the orientation planes use (cvs_tune.cpp default_config; profiles/r06_m4_layout_ab.txt); a basis-only
+// launch, a frame batch and CVS_OPT_STATE_LAYOUT = 3 use the two-group form.
 // twelve planes in one group must still lie within the 32-bit buffer offsets of one launch
 bool state_merge_fits(cvs_handle h, int rows, size_t dense_pitch)
 {
