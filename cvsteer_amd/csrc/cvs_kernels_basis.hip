@@ -504,6 +504,62 @@ __device__ __forceinline__ bool pick_tile(const BasisArgs& a, int* s_tile, int& 
 // and measured on one handle (tools/ab_same.py) -- no gain for any variant, -1..-6 % for the 12/20-plane ones; one- and
 // two-wave workgroups fill the wave slots better (no slot waits for the slowest of four) but lose 3-12 % on the G2 legs and
 // 7 % on fresh images (profiles/r03_wpb_probe.txt): the four strips of a workgroup write 1 KiB of every plane row from one CU.
+#ifdef CVS_DIAG_CANARY
+#define CVS_BST(ST, ...) (++st_tally, bst<ST>(__VA_ARGS__))
+#else
+#define CVS_BST(ST, ...) bst<ST>(__VA_ARGS__)
+#endif
+// Fused scalar steer (G2.cpp:137-145 / G4.cpp:114-122) of one output row: g and / or h from the bank's planes b and the host-computed weights,
+// stored to the caller's two planes -- whose pointer and pitch are read from the kernel arguments per row (kernarg_fresh: kept in scalar
+// registers across the row loop they were spilled to vector lanes).  `st_tally`: the canary twin's store count (dead in the product).
+template <class B, bool STREAM>
+__device__ __forceinline__ void store_steered(const BasisArgs& a, const float (&b)[B::NB], const unsigned xbr, const unsigned yo, [[maybe_unused]] unsigned& st_tally)
+{
+    constexpr int NB = B::NB;
+    const kernarg_ptr_t ks = kernarg_fresh();
+    const rsrc_t rg = plane_rsrc(ks->steer_g, kMaxPlaneBytes);
+    const rsrc_t rh = plane_rsrc(ks->steer_h, kMaxPlaneBytes);
+    const unsigned og = yo * (unsigned)(ks->steer_g_pitch * sizeof(float));
+    const unsigned oh = yo * (unsigned)(ks->steer_h_pitch * sizeof(float));
+    if constexpr (B::HALF == 0) {
+        static_assert(B::KIND == 2, "the whole-bank form exists for G2 only");
+        float gq, hq;
+        g2_steer_weights(b, a.steer_w, gq, hq);
+        CVS_BST(STREAM, rg, xbr, og, gq);
+        CVS_BST(STREAM, rh, xbr, oh, hq);
+    } else if constexpr (B::HALF == 1) {  // the G sum of G2.cpp:143 / G4.cpp:120, left to right
+        float gq = __fadd_rn(__fmul_rn(a.steer_w[0], b[0]), __fmul_rn(a.steer_w[1], b[1]));
+#pragma unroll
+        for (int p = 2; p < NB; ++p) gq = __fadd_rn(gq, __fmul_rn(a.steer_w[p], b[p]));
+        CVS_BST(STREAM, rg, xbr, og, gq);
+    } else {  // the H sum of G2.cpp:144 / G4.cpp:121
+        float hq = __fadd_rn(__fmul_rn(a.steer_w[B::PLANE0], b[0]), __fmul_rn(a.steer_w[B::PLANE0 + 1], b[1]));
+#pragma unroll
+        for (int p = 2; p < NB; ++p) hq = __fadd_rn(hq, __fmul_rn(a.steer_w[B::PLANE0 + p], b[p]));
+        CVS_BST(STREAM, rh, xbr, oh, hq);
+    }
+}
+
+// The pipeline's outputs of one row to the caller's own planes (one image, or a frame table).  One image (FROM_KERNARG): the eight planes are
+// pointer + pitch each -- 32 SGPRs that the row loop has not got; kept across it they are spilled to vector-register lanes, and every
+// v_readlane_b32 costs the SIMD as much as a packed multiply-add (180 of them per output row were 38 % of this variant's vector time).  They are
+// read from the kernel-argument segment again in every row instead (scalar cache); the record count of the resource is the constant maximum
+// -- the range check is only there to drop the lanes right of the image.
+template <bool STREAM, bool FEAT3, bool FROM_KERNARG>
+__device__ __forceinline__ void store_pipe_planes(const PlaneRef (&pipe_out)[8], const float (&q)[8], const unsigned xbr, const unsigned yo, [[maybe_unused]] unsigned& st_tally)
+{
+#pragma unroll
+    for (int k = FEAT3 ? 5 : 0; k < 8; ++k) {
+        PlaneRef po = pipe_out[k];
+        if constexpr (FROM_KERNARG) {
+            const kernarg_ptr_t ka = kernarg_fresh();
+            po.p = ka->pipe_out[k].p;
+            po.pitch = ka->pipe_out[k].pitch;
+        }
+        if (FEAT3 || po.p) CVS_BST(STREAM, plane_rsrc(po.p, kMaxPlaneBytes), xbr, yo * (unsigned)(po.pitch * sizeof(float)), q[k]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // The pieces of a row step that work on values in registers only (no addressing, no stores); basis_body below strings them together.
 // All are inlined into the unrolled row loop: `j` is a constant there and every window slot a fixed register.
@@ -619,11 +675,6 @@ __device__ __forceinline__ float pyr_column(const float (&hw)[5])
     return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(hw[2], 6.0f), __fmul_rn(__fadd_rn(hw[1], hw[3]), 4.0f)), hw[0]), hw[4]);
 }
 
-#ifdef CVS_DIAG_CANARY
-#define CVS_BST(ST, ...) (++st_tally, bst<ST>(__VA_ARGS__))
-#else
-#define CVS_BST(ST, ...) bst<ST>(__VA_ARGS__)
-#endif
 template <class B, int FLAGS, bool STREAM, int BATCH, bool ONE, int WPB, bool U8 = false, bool LIT = false>
 __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& t, float* line, int zframe, const int bx, const int by)
 {
@@ -755,8 +806,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
 
     const int nrows_in = (yend - y0) + 2 * W;
     const int ngroups = (nrows_in + NT - 1) / NT;
+    [[maybe_unused]] unsigned st_tally = 0;   // (the canary twin's store count; dead in the product)
 #ifdef CVS_DIAG_CANARY
-    [[maybe_unused]] unsigned st_tally = 0;
     unsigned cn_stale = 0, cn_short = 0, cn_reads = 0, cn_rows = 0;
     // a ring line filled with the pattern (before the load that refills it is issued; the pattern must be in the LDS before that load can land)
     // (ds_write by hand: a store through the generic `line` pointer could become a FLAT store, which counts in vmcnt as well and would
@@ -966,6 +1017,8 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                     if constexpr (ANY_B) orow2 = yo * pitch2_b;
                     if constexpr ((FLAGS & F_ORIENT) != 0 && (FLAGS & F_NOSTATE) == 0) orow_o = yo * opitch_b;
                 }
+                // (the state-plane stores stay here: taken out into functions over a struct of the strip's addressing they compile to the same code
+                // for every single-resource instance and to 3-5 % more spill moves for the per-plane ones -- round 6, tools/isa_summary.py)
                 if constexpr ((FLAGS & F_NOSTATE) == 0) {
 #pragma unroll
                     for (int p = 0; p < NB; ++p) {
@@ -1010,49 +1063,11 @@ __device__ __forceinline__ void basis_body(const BasisArgs& a, const Folded<B>& 
                                     if (a.out_mask & (1u << k)) CVS_BST(STREAM, r_out, xbr, orow_out + a.out_off[k], q[k]);
                             }
                         } else {
-#pragma unroll
-                            for (int k = FEAT3 ? 5 : 0; k < 8; ++k) {
-                                // One image: the eight output planes are the caller's own (pointer + pitch each: 32 SGPRs that the row loop has
-                                // not got; kept across it they are spilled to vector-register lanes, and every v_readlane_b32 costs the SIMD as
-                                // much as a packed multiply-add -- 180 of them per output row were 38 % of this variant's vector time).  They are
-                                // read from the kernel-argument segment again in every row instead (scalar cache); the record count of the
-                                // resource is the constant maximum -- the range check is only there to drop the lanes right of the image.
-                                PlaneRef po = pipe_out[k];
-                                if constexpr (BATCH == 0) {
-                                    const kernarg_ptr_t ka = kernarg_fresh();
-                                    po.p = ka->pipe_out[k].p;
-                                    po.pitch = ka->pipe_out[k].pitch;
-                                }
-                                if (FEAT3 || po.p) CVS_BST(STREAM, plane_rsrc(po.p, kMaxPlaneBytes), xbr, yo * (unsigned)(po.pitch * sizeof(float)), q[k]);
-                            }
+                            store_pipe_planes<STREAM, FEAT3, BATCH == 0>(pipe_out, q, xbr, yo, st_tally);
                         }
                     }
                 }
-                if constexpr ((FLAGS & F_STEER) != 0) {
-                    // the two steered planes are the caller's own: pointer and pitch read from the kernel arguments per row (see F_PIPE above)
-                    const kernarg_ptr_t ks = kernarg_fresh();
-                    const rsrc_t rg = plane_rsrc(ks->steer_g, kMaxPlaneBytes);
-                    const rsrc_t rh = plane_rsrc(ks->steer_h, kMaxPlaneBytes);
-                    const unsigned og = yo * (unsigned)(ks->steer_g_pitch * sizeof(float));
-                    const unsigned oh = yo * (unsigned)(ks->steer_h_pitch * sizeof(float));
-                    if constexpr (B::HALF == 0) {
-                        static_assert(B::KIND == 2, "the whole-bank form exists for G2 only");
-                        float gq, hq;
-                        g2_steer_weights(b, a.steer_w, gq, hq);
-                        CVS_BST(STREAM, rg, xbr, og, gq);
-                        CVS_BST(STREAM, rh, xbr, oh, hq);
-                    } else if constexpr (B::HALF == 1) {  // the G sum of G2.cpp:143 / G4.cpp:120, left to right
-                        float gq = __fadd_rn(__fmul_rn(a.steer_w[0], b[0]), __fmul_rn(a.steer_w[1], b[1]));
-#pragma unroll
-                        for (int p = 2; p < NB; ++p) gq = __fadd_rn(gq, __fmul_rn(a.steer_w[p], b[p]));
-                        CVS_BST(STREAM, rg, xbr, og, gq);
-                    } else {  // the H sum of G2.cpp:144 / G4.cpp:121
-                        float hq = __fadd_rn(__fmul_rn(a.steer_w[B::PLANE0], b[0]), __fmul_rn(a.steer_w[B::PLANE0 + 1], b[1]));
-#pragma unroll
-                        for (int p = 2; p < NB; ++p) hq = __fadd_rn(hq, __fmul_rn(a.steer_w[B::PLANE0 + p], b[p]));
-                        CVS_BST(STREAM, rh, xbr, oh, hq);
-                    }
-                }
+                if constexpr ((FLAGS & F_STEER) != 0) store_steered<B, STREAM>(a, b, xbr, yo, st_tally);
 #ifdef CVS_DIAG_CANARY
                 ++cn_rows;
                 if (st_tally - st_row0 < (unsigned)S_ROW) ++cn_short;   // S_ROW must be a LOWER bound of the stores of every output row
